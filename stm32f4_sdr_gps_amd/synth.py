@@ -1,0 +1,91 @@
+"""Synthetic 1-bit GPS L1 C/A IF stream generator (SURVEY.md 8(d) "Synthetic input").
+
+Host-side tooling for tests and bench.py -- not part of the correlator hot path.  The sample format is the
+reference's: fs = 16.368 MHz, IF = 4.092 MHz, one sign bit per sample, packed LSB first (sample n is bit n & 7 of
+byte n >> 3), 2046 bytes per millisecond (reference: PM/config.h:23-28, PM/signal_capture.c:9-11).
+
+    s[n] = sign( sum_sv A * d * c_sv(floor((n - tau)/16) mod 1023) * cos(2 pi (IF + fd) n / fs + phi) + w[n] )
+
+with w ~ U(-noise, noise) from a fixed-seed PCG64 stream and a continuous sample index across milliseconds.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+FS_HZ = 16_368_000
+IF_HZ = 4_092_000
+SAMPLES_PER_MS = 16368
+BYTES_PER_MS = 2046
+CHIPS = 1023
+
+# IS-GPS-200 G2 phase-selector taps for PRN 1..32
+_G2_TAPS = [(2, 6), (3, 7), (4, 8), (5, 9), (1, 9), (2, 10), (1, 8), (2, 9), (3, 10), (2, 3), (3, 4), (5, 6), (6, 7),
+            (7, 8), (8, 9), (9, 10), (1, 4), (2, 5), (3, 6), (4, 7), (5, 8), (6, 9), (1, 3), (4, 6), (5, 7), (6, 8),
+            (7, 9), (8, 10), (1, 6), (2, 7), (3, 8), (4, 9)]
+
+
+def ca_code(prn: int) -> np.ndarray:
+    """C/A code chips (0/1) for PRN 1..32."""
+    if not 1 <= prn <= 32:
+        raise ValueError("synth.ca_code supports PRN 1..32")
+    t1, t2 = _G2_TAPS[prn - 1]
+    g1 = [1] * 10
+    g2 = [1] * 10
+    out = np.zeros(CHIPS, np.uint8)
+    for i in range(CHIPS):
+        out[i] = g1[9] ^ g2[t1 - 1] ^ g2[t2 - 1]
+        f1 = g1[2] ^ g1[9]
+        f2 = g2[1] ^ g2[2] ^ g2[5] ^ g2[7] ^ g2[8] ^ g2[9]
+        g1 = [f1] + g1[:9]
+        g2 = [f2] + g2[:9]
+    return out
+
+
+@dataclass
+class Sat:
+    prn: int
+    doppler_hz: float
+    delay_samples: float
+    amp: float = 0.6
+    phase_rad: float = 0.0
+    nav_bits: np.ndarray | None = None  # +-1 per 20 ms, optional
+
+
+def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, start_ms: int = 0) -> np.ndarray:
+    """Return uint8 array [n_ms, 2046] of packed 1-bit samples."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((n_ms, BYTES_PER_MS), np.uint8)
+    codes = {s.prn: (1.0 - 2.0 * ca_code(s.prn).astype(np.float64)) for s in sats}
+    n0 = np.arange(SAMPLES_PER_MS, dtype=np.float64)
+    for ms in range(n_ms):
+        n = n0 + float((start_ms + ms) * SAMPLES_PER_MS)
+        x = rng.uniform(-noise_amp, noise_amp, SAMPLES_PER_MS) if noise_amp > 0 else np.zeros(SAMPLES_PER_MS)
+        for s in sats:
+            chip = np.floor((n - s.delay_samples) / 16.0).astype(np.int64) % CHIPS
+            d = 1.0
+            if s.nav_bits is not None:
+                bit_idx = np.floor((n - s.delay_samples) / (16.0 * CHIPS * 20)).astype(np.int64) % len(s.nav_bits)
+                d = s.nav_bits[bit_idx]
+            ph = 2.0 * np.pi * ((IF_HZ + s.doppler_hz) / FS_HZ) * n + s.phase_rad
+            x = x + s.amp * d * codes[s.prn][chip] * np.cos(ph)
+        bits = (x >= 0).astype(np.uint8)
+        out[ms] = np.packbits(bits, bitorder="little")
+    return out
+
+
+def default_four_sv(n_ms: int, seed: int = 7) -> np.ndarray:
+    """The reference's default 4-satellite table (PM/main.c:59-73): PRN 5/14/20/30, hints 900/4000/-1000/2000 Hz."""
+    # true Dopplers sit a few tens of Hz off the hints so the carrier phase walks through all four quadrants (the
+    # reference's one-sided clip, gps_misc.c:108-111, only sees one of them at a time)
+    sats = [Sat(5, 912.5, 1600.0, 0.6, 0.3), Sat(14, 4037.0, 4000.0, 0.6, 1.1), Sat(20, -1025.0, 9000.0, 0.6, 2.5),
+            Sat(30, 2018.0, 13000.0, 0.6, 4.0)]
+    return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+
+
+def cold_start_block(n_ms: int = 1, seed: int = 11) -> np.ndarray:
+    """Config 3/4 input: six satellites in view."""
+    sats = [Sat(3, -3210.0, 777.0, 0.5, 0.7), Sat(5, 912.5, 1600.0, 0.6, 0.3), Sat(11, 4480.0, 12001.0, 0.5, 5.1),
+            Sat(14, 4037.0, 4000.0, 0.6, 1.1), Sat(20, -1025.0, 9000.0, 0.6, 2.5), Sat(30, 2018.0, 13000.0, 0.6, 4.0)]
+    return make_if(n_ms, sats, noise_amp=1.0, seed=seed)

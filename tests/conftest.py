@@ -1,0 +1,39 @@
+"""pytest configuration: marker registration and shared fixtures.
+
+`-m "not gpu"`: oracle vs golden vectors, oracle vs the in-place reference build (when present), host logic,
+                C-ABI symbol checks, gloo multi-process tests.
+`-m gpu`      : parity tests proper -- the HIP engine through the C-ABI against the oracle / golden vectors.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    return pyoracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref_pm():
+    from oracle import pyoracle
+    if not pyoracle.RefPM.available():
+        pyoracle.build_ref()
+    if not pyoracle.RefPM.available():
+        pytest.skip("oracle/_ref/libref_pm.so not built (needs /root/reference)")
+    return pyoracle.RefPM()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
