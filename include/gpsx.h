@@ -1,0 +1,178 @@
+/* include/gpsx.h -- C ABI of libgpsx.so, the MI355X (gfx950) GPS L1 C/A correlator engine.
+ *
+ * This is the "Tier 3" batched interface: plain pointers and sizes, no C++/torch types.  It
+ * replaces, for many channels / hypotheses per call, what the reference firmware does one call at a time through
+ * Firmware/project_main/GPS/gps_misc.h:195-216 (the per-call, symbol-compatible "Tier 1" mirror of that header is
+ * include/gpsx_compat.h).  Everything below executes on the GPU; there is no CPU fallback -- without a usable HIP
+ * device gpsx_create() fails with GPSX_ENODEV and nothing else can be called.
+ *
+ * Sample format (reference: PM/config.h:23-28, PM/signal_capture.c:9-11): 1 bit per sample (MAX2769 sign bit),
+ * LSB first, fs = 16.368 MHz, IF = 4.092 MHz, one "block" = 1 ms = 16368 samples = 2046 bytes.
+ *
+ * Conventions: functions return 0 (GPSX_OK) or a negative errno-style code; *_dev variants take DEVICE pointers and
+ * only enqueue work on the context's HIP stream (call gpsx_synchronize, or synchronize the stream you passed to
+ * gpsx_create); the variants without _dev take HOST pointers and return when the results are in host memory.
+ * A context is thread-compatible, not thread-safe (one stream, one set of scratch buffers).
+ */
+#ifndef GPSX_H
+#define GPSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPSX_VERSION            100        /* 0.1.0 */
+#define GPSX_BYTES_PER_MS       2046       /* PM/config.h:26-27: 16368 one-bit samples                    */
+#define GPSX_PHASES_BYTE        2046       /* code-phase hypotheses at byte (0.5 chip) granularity         */
+#define GPSX_PHASES_FINE        16368      /* byte offset x 8 replica bit shifts (PM/GPS/tracking.c:23)    */
+#define GPSX_IF_HZ              4092000    /* PM/config.h:23                                               */
+#define GPSX_MAX_PRN            210        /* PM/GPS/gps_misc.c:319-341                                    */
+
+#define GPSX_OK       0
+#define GPSX_EIO     (-5)    /* a HIP runtime call failed (see gpsx_last_error)   */
+#define GPSX_ENOMEM  (-12)
+#define GPSX_ENODEV  (-19)   /* no usable gfx950 device                            */
+#define GPSX_EINVAL  (-22)
+
+typedef struct gpsx_ctx gpsx_ctx;
+
+/* What correlation_search() (PM/GPS/gps_misc.c:155-191) returns, plus the un-divided sum. */
+typedef struct {
+  uint32_t max_val;  /* return value: largest correlation magnitude in the window                            */
+  uint32_t phase;    /* *phase: first byte offset reaching it; 0 if nothing exceeded 0                       */
+  uint32_t sum;      /* sum of magnitudes over the window                                                     */
+  uint32_t avr;      /* *aver_val: sum / 2046 (the divisor is constant whatever the window)                   */
+} gpsx_peak_t;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+
+/* device: HIP device ordinal.  stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let
+ * the context create its own. */
+int         gpsx_create(gpsx_ctx **ctx, int device, void *stream);
+void        gpsx_destroy(gpsx_ctx *ctx);
+int         gpsx_synchronize(gpsx_ctx *ctx);
+const char *gpsx_last_error(const gpsx_ctx *ctx);   /* text of the last failure on this context */
+const char *gpsx_strerror(int code);
+int         gpsx_version(void);
+/* name / CU count / clock of the device behind the context (for bench reports) */
+int         gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *compute_units, int *clock_khz);
+
+/* device memory + HIP-event timing on the context's stream (so a C caller needs no HIP headers) */
+int gpsx_malloc(gpsx_ctx *ctx, void **dptr, size_t bytes);
+int gpsx_free(gpsx_ctx *ctx, void *dptr);
+int gpsx_memcpy_h2d(gpsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int gpsx_memcpy_d2h(gpsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int gpsx_event_create(gpsx_ctx *ctx, void **event);
+int gpsx_event_record(gpsx_ctx *ctx, void *event);
+int gpsx_event_elapsed_ms(gpsx_ctx *ctx, void *start, void *stop, float *ms);  /* synchronizes on `stop` */
+int gpsx_event_destroy(gpsx_ctx *ctx, void *event);
+
+/* ---- K1: C/A Gold codes  (replaces gps_generate_prn / gps_channell_prepare, PM/GPS/gps_misc.c:306-372) -------- */
+
+/* chips_out: n_prn x 1023 bytes of 0/1.  prn must be 1..210 (the reference silently ignores prn < 1; this
+ * interface validates instead and returns GPSX_EINVAL). */
+int gpsx_ca_codes(gpsx_ctx *ctx, const uint8_t *prns, int n_prn, uint8_t *chips_out);
+
+/* ---- K2+K3+K4: acquisition grid  (replaces the data-parallel prefix of acquisition_freq_search /
+ *      acquisition_code_phase_search, PM/GPS/acquisition.c:196-312: gps_generate_prn_data2 + gps_shift_to_zero_freq
+ *      + correlation_search per (channel, Doppler bin, ms), here for every PRN x Doppler x phase in one launch) ---- */
+
+typedef struct {
+  int32_t        n_search;             /* independent searches (e.g. consecutive capture instants)              */
+  int32_t        n_ms;                 /* blocks summed non-coherently per search; 1 = the reference            */
+  int32_t        search_stride_blocks; /* search s starts at block s * stride                                   */
+  int32_t        n_prn;
+  const uint8_t *prns;                 /* HOST pointer, n_prn PRN numbers                                       */
+  int32_t        dopp_min_hz;          /* Doppler bin d is dopp_min_hz + d * dopp_step_hz  (acquisition.c:285)  */
+  int32_t        dopp_step_hz;
+  int32_t        n_dopp;
+  int32_t        phase_mode;           /* GPSX_PHASES_BYTE (replica shift 0 only) or GPSX_PHASES_FINE (0..7)   */
+  int32_t        win_start, win_stop;  /* byte-offset window [start, stop); 0, 2046 for a full search           */
+  int32_t        shard_index;          /* multi-GPU: this process computes work units u with                    */
+  int32_t        shard_count;          /*   u % shard_count == shard_index; 0/1 for a single GPU                */
+} gpsx_acq_grid_t;
+
+/* number of replica bit shifts a phase_mode implies (1 or 8) */
+int gpsx_acq_bits(int phase_mode);
+
+/* Sizes (in elements) of the result arrays for a descriptor: peaks[n_search][n_prn][n_dopp][n_bits],
+ * keys[n_search][n_prn][n_dopp]. */
+size_t gpsx_acq_peaks_count(const gpsx_acq_grid_t *g);
+size_t gpsx_acq_keys_count(const gpsx_acq_grid_t *g);
+
+/* Enqueue one grid.  d_if_blocks: n_blocks x 2046 bytes, blocks contiguous.  d_peaks: gpsx_acq_peaks_count()
+ * entries; entries of (search, PRN, Doppler) units owned by other shards are written as zero.  d_keys (may be NULL):
+ * one packed int64 per (search, PRN, Doppler): (max_val << 14) | (16383 - fine_phase), fine_phase = 8 * phase + bit
+ * shift, maximised over the bit shifts -- zero for units of other shards, so that ONE all-reduce(MAX) over the ranks
+ * yields every unit's peak, ties resolved to the lowest fine phase like correlation_search's strict '>'.
+ * Optional debug/inspection outputs (NULL to skip), indexed like d_peaks with one more trailing axis:
+ *   d_per_ms [..][n_ms]   the triplet the reference would have produced for each single block
+ *   d_energy [..][2046]   accumulated magnitude per byte offset (0 outside the window)
+ *   d_cnt    [..][2046][2] raw popcounts cnt_i, cnt_q of the LAST block (what gps_mult_and_summ returns) */
+int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_blocks, int n_blocks,
+                      gpsx_peak_t *d_peaks, int64_t *d_keys, gpsx_peak_t *d_per_ms, uint32_t *d_energy,
+                      uint16_t *d_cnt);
+
+/* Host-buffer convenience: copies the blocks in, runs, copies peaks (and keys if non-NULL) out. */
+int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks,
+                  gpsx_peak_t *peaks, int64_t *keys);
+
+/* Explicit job list: one search per job, each with its own PRN, carrier frequency, replica shift and window --
+ * what acquisition_process() needs for the reference's 4-channel table with per-channel Doppler hints
+ * (PM/GPS/acquisition.c:51-57,72-79) and what pre-tracking needs (PM/GPS/tracking.c:398-450). */
+typedef struct {
+  int32_t  block;        /* first block of the search                              */
+  int32_t  n_ms;
+  int32_t  prn;
+  float    freq_hz;      /* IF + Doppler, as passed to gps_shift_to_zero_freq      */
+  int32_t  offset_bits;  /* replica shift 0..15 (gps_generate_prn_data2)           */
+  int32_t  win_start, win_stop;
+} gpsx_acq_job_t;
+
+int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const uint8_t *if_blocks, int n_blocks,
+                  gpsx_peak_t *peaks /* n_jobs */, uint32_t *energy_opt /* n_jobs x 2046 or NULL */);
+
+/* unpack a key produced by gpsx_acq_grid* */
+static inline uint32_t gpsx_key_energy(int64_t key) { return (uint32_t)(key >> 14); }
+static inline uint32_t gpsx_key_fine_phase(int64_t key) { return 16383u - (uint32_t)(key & 16383); }
+
+/* ---- K2+K3+K5: Early/Prompt/Late tracking correlators  (replaces the correlator part of
+ *      gps_tracking_data_process, PM/GPS/tracking.c:115-138, for n_ch channels at once) ------------------------- */
+
+typedef struct {
+  int32_t  prn;
+  float    code_phase_fine;    /* gps_tracking_t.code_phase_fine, samples 0..16368       */
+  float    if_freq_offset_hz;  /* gps_tracking_t.if_freq_offset_hz                       */
+  uint32_t if_freq_accum;      /* gps_tracking_t.if_freq_accum: read, advanced, written  */
+} gpsx_trk_state_t;
+
+/* if_block: the current 1 ms block (2046 bytes, shared by all channels).  iq_out: n_ch x {IE,QE,IP,QP,IL,QL}. */
+int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out);
+int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_state_t *d_st, int n_ch,
+                             int16_t *d_iq_out);
+
+/* ---- per-call primitives on caller buffers (the device work behind include/gpsx_compat.h) --------------------- */
+
+/* gps_shift_to_zero_freq(_track): *accum is the NCO accumulator in/out (0 for the stateless call).  Writes bytes
+ * 0..2043 of data_i / data_q only (PM/GPS/gps_misc.c:229: the last 16 samples are never mixed). */
+int gpsx_wipeoff(gpsx_ctx *ctx, const uint8_t *signal, float freq_hz, uint32_t *accum, uint8_t *data_i,
+                 uint8_t *data_q);
+/* gps_generate_prn_data2: chips = 1023 bytes 0/1; out = 1024 words, word 1023 is OR-ed with the spill. */
+int gpsx_replica(gpsx_ctx *ctx, const uint8_t *chips, unsigned offset_bits, uint16_t *out);
+/* gps_mult_and_summ + gps_correlation8 + gps_correlation_iq for a list of byte offsets (each 0..2046) on arbitrary
+ * 2046-byte buffers.  Any of cnt_i/cnt_q (raw popcounts), corr8 may be NULL. */
+int gpsx_corr_offsets(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
+                      const uint16_t *offsets, int n, uint16_t *cnt_i, uint16_t *cnt_q, int16_t *corr8);
+/* correlation_search on arbitrary buffers */
+int gpsx_corr_search(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
+                     unsigned start_shift, unsigned stop_shift, gpsx_peak_t *peak);
+/* gps_rewind_if_phase (PM/GPS/gps_misc.c:196-204) for n channel states (device arithmetic, same rounding) */
+int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *steps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSX_H */

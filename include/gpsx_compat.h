@@ -1,0 +1,156 @@
+/* include/gpsx_compat.h -- per-call, symbol-compatible mirror of the reference's correlator interface
+ * (Firmware/project_main/GPS/gps_misc.h:195-216 of iliasam/STM32F4_SDR_GPS), backed by the MI355X engine.
+ *
+ * A C program written against the reference header links against libgpsx.so unchanged: same function names,
+ * argument meaning and (silent) error behaviour; the channel structures below keep the reference's field names
+ * and, on LP64 x86-64, its exact layout (gps_misc.h:43-99,184-193; checked by static asserts in gpsx_compat.cpp
+ * and against the reference header by tests/test_compat_layout.py).  Every call runs on the GPU through the
+ * process-wide default context (device $GPSX_DEVICE, default 0); if no gfx950 device can be opened the first call
+ * prints a diagnostic and aborts -- there is no CPU path.
+ *
+ * One call = a few small copies + one or two kernel launches (tens of microseconds).  That is the price of keeping
+ * the reference's call granularity; throughput work belongs on the batched interface in gpsx.h.
+ * Like the reference (global scratch buffers, PM/GPS/common_ram.c), this interface is not re-entrant.
+ */
+#ifndef GPSX_COMPAT_H
+#define GPSX_COMPAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* signal geometry, PM/config.h:23-28,41-59 */
+#define IF_FREQ_HZ                 4092000
+#define SPI_BAUDRATE_HZ            16368000
+#define BITS_IN_PRN                16368
+#define PRN_SPI_WORDS_CNT          1023
+#define PRN_LENGTH                 1023
+#define ACQ_SEARCH_FREQ_HZ         7000
+#define ACQ_SEARCH_STEP_HZ         500
+#define ACQ_COUNT                  (ACQ_SEARCH_FREQ_HZ * 2 / ACQ_SEARCH_STEP_HZ + 1)
+#define ACQ_PHASE1_HIST_SIZE       32
+#define PRE_TRACK_POINTS_MAX_CNT   30
+#define TRACKING_CH_LENGTH         4
+#define GPS_SAT_CNT                4
+#define GPS_DATA_WORDS_CNT         (PRN_SPI_WORDS_CNT + 1)   /* PM/GPS/common_ram.h:10 */
+
+typedef enum {
+  GPS_ACQ_NEED_FREQ_SEARCH = 0,
+  GPS_ACQ_FREQ_SEARCH_RUN,
+  GPS_ACQ_FREQ_SEARCH_DONE,
+  GPS_ACQ_CODE_PHASE_SEARCH1,
+  GPS_ACQ_CODE_PHASE_SEARCH1_DONE,
+  GPS_ACQ_CODE_PHASE_SEARCH2,
+  GPS_ACQ_CODE_PHASE_SEARCH2_DONE,
+  GPS_ACQ_CODE_PHASE_SEARCH3,
+  GPS_ACQ_CODE_PHASE_SEARCH3_DONE,
+  GPS_ACQ_DONE
+} gps_acq_state_t;
+
+typedef enum {
+  GPS_TRACKNG_IDLE = 0,
+  GPS_NEED_PRE_TRACK,
+  GPS_PRE_TRACK_RUN,
+  GPS_PRE_TRACK_DONE,
+  GPS_TRACKING_RUN
+} gps_tracking_state_t;
+
+/* acquisition state of one channel (gps_misc.h:43-60) */
+typedef struct {
+  uint8_t  freq_index;             /* Doppler bin under test: -7000 Hz + index * 500 Hz            */
+  int16_t  found_freq_offset_hz;
+  int16_t  given_freq_offset_hz;   /* user hint; non-zero skips the frequency search               */
+  uint16_t found_code_phase;       /* byte offsets, 0 .. 2046                                      */
+  uint16_t code_search_start;
+  uint16_t code_search_stop;
+  uint16_t code_hist_step;
+  gps_acq_state_t state;
+  uint8_t  code_phase_histogram[ACQ_PHASE1_HIST_SIZE];
+  uint32_t start_timestamp;
+  float    hist_ratio;
+} gps_acq_t;
+
+/* tracking state of one channel (gps_misc.h:62-99, ENABLE_CODE_FILTER == 1) */
+typedef struct {
+  uint16_t code_search_start;
+  uint16_t code_search_stop;
+  float    if_freq_offset_hz;      /* Doppler estimate the carrier NCO runs at                     */
+  uint32_t if_freq_accum;          /* carrier NCO accumulator carried across milliseconds          */
+  uint16_t pre_track_phases[PRE_TRACK_POINTS_MAX_CNT];
+  uint8_t  pre_track_count;
+  uint32_t prev_track_timestamp;
+  float    code_phase_fine;        /* samples, 0 .. 16368                                          */
+  float    old_code_phase_fine;
+  uint8_t  code_phase_swap_flag;
+  float    dll_code_err;
+  float    pll_code_err;
+  int16_t  fll_old_i;
+  int16_t  fll_old_q;
+  float    fll_err;
+  int16_t  pll_check_buf[TRACKING_CH_LENGTH];
+  uint8_t  pll_bad_state_cnt;
+  uint16_t pll_bad_state_master_cnt;
+  uint32_t i_part_summ;
+  uint32_t q_part_summ;
+  uint16_t snr_summ_cnt;
+  float    snr_value;
+  uint32_t filt_start_time_ms;
+  uint16_t code_filt_cnt;
+  float    code_phase_fine_filt;
+  gps_tracking_state_t state;
+} gps_tracking_t;
+
+/* Navigation-message, observation and ephemeris state are outside the correlator path; they are carried as
+ * opaque storage of the reference's size so that gps_ch_t keeps its layout (gps_misc.h:101-182). */
+typedef union {
+  uint8_t  period_sync_ok_flag;    /* first member of the reference's gps_nav_data_t; read by the PLL */
+  uint32_t opaque_[28];
+} gps_nav_data_t;
+typedef struct { double opaque_[2]; }  gps_obs_data_t;
+typedef struct { double opaque_[40]; } sdreph_t;
+
+typedef struct {
+  gps_acq_t      acq_data;
+  gps_tracking_t tracking_data;
+  gps_nav_data_t nav_data;
+  gps_obs_data_t obs_data;
+  sdreph_t       eph_data;
+  uint8_t        prn;                    /* satellite PRN number, 1 .. 210                          */
+  uint8_t        prn_code[PRN_LENGTH];   /* C/A chips as 0/1 bytes                                  */
+} gps_ch_t;
+
+/* --- the nine functions of gps_misc.h:195-216 ------------------------------------------------------------- */
+
+/* The reference fills a 64 KiB popcount table here (gps_misc.c:19-25); the GPU has v_bcnt_u32_b32, so this only
+ * opens the default context (and aborts loudly if there is no GPU). */
+void gps_fill_summ_table(void);
+/* channel->prn < 1: silent return (gps_misc.c:306-311) */
+void gps_channell_prepare(gps_ch_t *channel);
+/* dest: 1023 bytes; prn < 1: silent return (gps_misc.c:317-372; global in the reference though not in its header) */
+void gps_generate_prn(uint8_t *dest, int prn);
+
+int16_t gps_correlation8(uint16_t *prn_p, uint16_t *data_i, uint16_t *data_q, uint16_t offset);
+void gps_correlation_iq(uint16_t *prn_p, uint16_t *data_i, uint16_t *data_q, uint16_t offset, int16_t *res_i,
+                        int16_t *res_q);
+uint16_t correlation_search(uint16_t *prn_p, uint16_t *data_i, uint16_t *data_q, uint16_t start_shift,
+                            uint16_t stop_shift, uint16_t *aver_val, uint16_t *phase);
+void gps_shift_to_zero_freq(uint8_t *signal_data, uint8_t *data_i, uint8_t *data_q, float freq_hz);
+void gps_shift_to_zero_freq_track(gps_tracking_t *trk_channel, uint8_t *signal_data, uint8_t *data_i,
+                                  uint8_t *data_q);
+void gps_generate_prn_data2(gps_ch_t *channel, uint16_t *data, uint16_t offset_bits);
+void gps_rewind_if_phase(gps_tracking_t *trk_channel, uint8_t steps);
+
+/* The three scratch buffers of PM/GPS/common_ram.c:3-5 (1023 words + 1 pad, zero-initialised). */
+extern uint16_t tmp_prn_data[GPS_DATA_WORDS_CNT];
+extern uint16_t tmp_data_i[GPS_DATA_WORDS_CNT];
+extern uint16_t tmp_data_q[GPS_DATA_WORDS_CNT];
+
+/* not in the reference: release the default context (optional, for leak checkers) */
+void gpsx_compat_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSX_COMPAT_H */

@@ -1,0 +1,288 @@
+"""ctypes binding of the C ABI in include/gpsx.h / include/gpsx_compat.h (libgpsx.so).
+
+Used by tests/ and bench.py.  It adds nothing to the computation: arrays in, arrays out, every call forwarded to the
+shared library, which runs on the GPU or fails.  If the library has not been built, or there is no gfx950 device,
+construction raises -- there is no Python/CPU fallback.
+
+Import torch BEFORE this module in processes that use both (one HIP runtime per process: torch's bundled
+libamdhip64 and /opt/rocm's share a SONAME, whichever loads first serves both).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libgpsx.so")
+
+BYTES_PER_MS = 2046
+PHASES_BYTE = 2046
+PHASES_FINE = 16368
+IF_HZ = 4092000
+
+PEAK_DTYPE = np.dtype([("max_val", "<u4"), ("phase", "<u4"), ("sum", "<u4"), ("avr", "<u4")])
+TRK_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"),
+                      ("if_freq_accum", "<u4")])
+JOB_DTYPE = np.dtype([("block", "<i4"), ("n_ms", "<i4"), ("prn", "<i4"), ("freq_hz", "<f4"), ("offset_bits", "<i4"),
+                      ("win_start", "<i4"), ("win_stop", "<i4")])
+
+
+class AcqGrid(C.Structure):
+    _fields_ = [("n_search", C.c_int32), ("n_ms", C.c_int32), ("search_stride_blocks", C.c_int32),
+                ("n_prn", C.c_int32), ("prns", C.c_void_p), ("dopp_min_hz", C.c_int32), ("dopp_step_hz", C.c_int32),
+                ("n_dopp", C.c_int32), ("phase_mode", C.c_int32), ("win_start", C.c_int32), ("win_stop", C.c_int32),
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32)]
+
+
+class GpsxError(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise GpsxError(f"{LIB_PATH} is missing: run `python -m stm32f4_sdr_gps_amd.build` (needs hipcc)")
+    lib = C.CDLL(LIB_PATH)
+    lib.gpsx_last_error.restype = C.c_char_p
+    lib.gpsx_strerror.restype = C.c_char_p
+    lib.gpsx_acq_peaks_count.restype = C.c_size_t
+    lib.gpsx_acq_keys_count.restype = C.c_size_t
+    lib.gpsx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    lib.gpsx_destroy.argtypes = [C.c_void_p]
+    for name in ("gpsx_synchronize",):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.gpsx_last_error.argtypes = [C.c_void_p]
+    lib.gpsx_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
+    lib.gpsx_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gpsx_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gpsx_event_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.gpsx_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.gpsx_event_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.gpsx_ca_codes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_acq_grid_dev.argtypes = [C.c_void_p, C.POINTER(AcqGrid), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gpsx_acq_grid.argtypes = [C.c_void_p, C.POINTER(AcqGrid), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gpsx_acq_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gpsx_track_epl_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_track_epl_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_rewind.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_wipeoff.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
+    lib.gpsx_replica.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+    lib.gpsx_corr_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gpsx_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+    # compat (reference names)
+    lib.gps_generate_prn.argtypes = [C.c_void_p, C.c_int]
+    lib.gps_channell_prepare.argtypes = [C.c_void_p]
+    lib.gps_correlation8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16]
+    lib.gps_correlation8.restype = C.c_int16
+    lib.gps_correlation_iq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16, C.POINTER(C.c_int16),
+                                       C.POINTER(C.c_int16)]
+    lib.correlation_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16,
+                                       C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
+    lib.correlation_search.restype = C.c_uint16
+    lib.gps_shift_to_zero_freq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+    lib.gps_shift_to_zero_freq_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gps_generate_prn_data2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16]
+    lib.gps_rewind_if_phase.argtypes = [C.c_void_p, C.c_uint8]
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class Engine:
+    """One gpsx context.  `stream` may be a raw hipStream_t handle (int), e.g. torch.cuda.current_stream().cuda_stream."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.gpsx_create(C.byref(h), device, C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise GpsxError(f"gpsx_create(device={device}) -> {rc}: {self.lib.gpsx_strerror(rc).decode()} "
+                            "(the correlator engine needs an MI355X; it has no CPU path)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gpsx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise GpsxError(f"{what} -> {rc}: {self.lib.gpsx_strerror(rc).decode()}: "
+                            f"{self.lib.gpsx_last_error(self.h).decode()}")
+
+    # -- plumbing ----------------------------------------------------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cus, khz = C.c_int(), C.c_int()
+        self.lib.gpsx_device_info(self.h, name, 128, C.byref(cus), C.byref(khz))
+        return name.value.decode(), cus.value, khz.value
+
+    def synchronize(self):
+        self._chk(self.lib.gpsx_synchronize(self.h), "gpsx_synchronize")
+
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self.lib.gpsx_malloc(self.h, C.byref(p), nbytes), "gpsx_malloc")
+        return p.value
+
+    def free(self, dptr: int):
+        self._chk(self.lib.gpsx_free(self.h, dptr), "gpsx_free")
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.gpsx_memcpy_h2d(self.h, dptr, arr.ctypes.data, arr.nbytes), "gpsx_memcpy_h2d")
+
+    def d2h(self, arr: np.ndarray, dptr: int):
+        assert arr.flags.c_contiguous
+        self._chk(self.lib.gpsx_memcpy_d2h(self.h, arr.ctypes.data, dptr, arr.nbytes), "gpsx_memcpy_d2h")
+
+    def event(self) -> int:
+        e = C.c_void_p()
+        self._chk(self.lib.gpsx_event_create(self.h, C.byref(e)), "gpsx_event_create")
+        return e.value
+
+    def record(self, ev: int):
+        self._chk(self.lib.gpsx_event_record(self.h, ev), "gpsx_event_record")
+
+    def elapsed_ms(self, ev0: int, ev1: int) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.gpsx_event_elapsed_ms(self.h, ev0, ev1, C.byref(ms)), "gpsx_event_elapsed_ms")
+        return ms.value
+
+    # -- K1 ---------------------------------------------------------------------------------------------------
+    def ca_codes(self, prns) -> np.ndarray:
+        prns = np.ascontiguousarray(prns, np.uint8)
+        out = np.zeros((len(prns), 1023), np.uint8)
+        self._chk(self.lib.gpsx_ca_codes(self.h, prns.ctypes.data, len(prns), out.ctypes.data), "gpsx_ca_codes")
+        return out
+
+    # -- acquisition ------------------------------------------------------------------------------------------
+    @staticmethod
+    def grid_desc(prns: np.ndarray, n_search=1, n_ms=1, search_stride_blocks=None, dopp_min_hz=-5000,
+                  dopp_step_hz=500, n_dopp=21, phase_mode=PHASES_FINE, win=(0, 2046), shard=(0, 1)) -> AcqGrid:
+        g = AcqGrid()
+        g.n_search, g.n_ms = n_search, n_ms
+        g.search_stride_blocks = n_ms if search_stride_blocks is None else search_stride_blocks
+        g.n_prn, g.prns = len(prns), prns.ctypes.data
+        g.dopp_min_hz, g.dopp_step_hz, g.n_dopp = dopp_min_hz, dopp_step_hz, n_dopp
+        g.phase_mode = phase_mode
+        g.win_start, g.win_stop = win
+        g.shard_index, g.shard_count = shard
+        return g
+
+    def acq_grid(self, if_blocks: np.ndarray, prns, want_keys=True, **kw):
+        """Host-buffer grid search.  Returns (peaks[n_search, n_prn, n_dopp, n_bits], keys[n_search, n_prn, n_dopp])."""
+        prns = np.ascontiguousarray(prns, np.uint8)
+        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, BYTES_PER_MS)
+        g = self.grid_desc(prns, **kw)
+        n_bits = 8 if g.phase_mode == PHASES_FINE else 1
+        peaks = np.zeros((g.n_search, g.n_prn, g.n_dopp, n_bits), PEAK_DTYPE)
+        keys = np.zeros((g.n_search, g.n_prn, g.n_dopp), np.int64) if want_keys else None
+        self._chk(self.lib.gpsx_acq_grid(self.h, C.byref(g), blocks.ctypes.data, len(blocks), peaks.ctypes.data,
+                                         _ptr(keys)), "gpsx_acq_grid")
+        return peaks, keys
+
+    def acq_grid_debug(self, if_blocks: np.ndarray, prns, want_per_ms=False, want_energy=False, want_cnt=False, **kw):
+        """Device-pointer path with the optional inspection outputs, staged through gpsx_malloc'ed buffers."""
+        prns = np.ascontiguousarray(prns, np.uint8)
+        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, BYTES_PER_MS)
+        g = self.grid_desc(prns, **kw)
+        n_bits = 8 if g.phase_mode == PHASES_FINE else 1
+        shape = (g.n_search, g.n_prn, g.n_dopp, n_bits)
+        peaks = np.zeros(shape, PEAK_DTYPE)
+        keys = np.zeros(shape[:3], np.int64)
+        per_ms = np.zeros(shape + (g.n_ms,), PEAK_DTYPE) if want_per_ms else None
+        energy = np.zeros(shape + (2046,), np.uint32) if want_energy else None
+        cnt = np.zeros(shape + (2046, 2), np.uint16) if want_cnt else None
+        bufs = []
+
+        def dev(arr):
+            if arr is None:
+                return None
+            p = self.malloc(arr.nbytes)
+            self.h2d(p, arr)
+            bufs.append(p)
+            return p
+
+        try:
+            d_if = dev(np.concatenate([blocks.reshape(-1), np.zeros(2, np.uint8)]))
+            d_peaks, d_keys, d_per, d_en, d_cnt = dev(peaks), dev(keys), dev(per_ms), dev(energy), dev(cnt)
+            self._chk(self.lib.gpsx_acq_grid_dev(self.h, C.byref(g), d_if, len(blocks), d_peaks, d_keys, d_per, d_en,
+                                                 d_cnt), "gpsx_acq_grid_dev")
+            self.synchronize()
+            for arr, p in ((peaks, d_peaks), (keys, d_keys), (per_ms, d_per), (energy, d_en), (cnt, d_cnt)):
+                if arr is not None:
+                    self.d2h(arr, p)
+        finally:
+            for p in bufs:
+                self.free(p)
+        return dict(peaks=peaks, keys=keys, per_ms=per_ms, energy=energy, cnt=cnt)
+
+    def acq_jobs(self, if_blocks: np.ndarray, jobs: np.ndarray, want_energy=False):
+        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, BYTES_PER_MS)
+        jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
+        peaks = np.zeros(len(jobs), PEAK_DTYPE)
+        energy = np.zeros((len(jobs), 2046), np.uint32) if want_energy else None
+        self._chk(self.lib.gpsx_acq_jobs(self.h, jobs.ctypes.data, len(jobs), blocks.ctypes.data, len(blocks),
+                                         peaks.ctypes.data, _ptr(energy)), "gpsx_acq_jobs")
+        return peaks, energy
+
+    # -- tracking ---------------------------------------------------------------------------------------------
+    def track_epl(self, if_block: np.ndarray, states: np.ndarray) -> np.ndarray:
+        """states: TRK_DTYPE array, updated in place (if_freq_accum).  Returns int16 [n_ch, 6] = IE,QE,IP,QP,IL,QL."""
+        assert states.dtype == TRK_DTYPE and states.flags.c_contiguous
+        blk = np.ascontiguousarray(if_block, np.uint8)
+        iq = np.zeros((len(states), 6), np.int16)
+        self._chk(self.lib.gpsx_track_epl_batch(self.h, blk.ctypes.data, states.ctypes.data, len(states),
+                                                iq.ctypes.data), "gpsx_track_epl_batch")
+        return iq
+
+    def rewind(self, states: np.ndarray, steps) -> None:
+        steps = np.ascontiguousarray(steps, np.uint8)
+        self._chk(self.lib.gpsx_rewind(self.h, states.ctypes.data, len(states), steps.ctypes.data), "gpsx_rewind")
+
+    # -- per-call primitives ------------------------------------------------------------------------------------
+    def wipeoff(self, signal, freq_hz, accum=0, prefill=None):
+        di = np.zeros(1024, np.uint16) if prefill is None else prefill[0].copy()
+        dq = np.zeros(1024, np.uint16) if prefill is None else prefill[1].copy()
+        acc = C.c_uint32(accum)
+        sig = np.ascontiguousarray(signal, np.uint8)
+        self._chk(self.lib.gpsx_wipeoff(self.h, sig.ctypes.data, np.float32(freq_hz), C.byref(acc), di.ctypes.data,
+                                        dq.ctypes.data), "gpsx_wipeoff")
+        return di, dq, acc.value
+
+    def replica(self, chips, offset_bits, pad_in=0):
+        out = np.zeros(1024, np.uint16)
+        out[1023] = pad_in
+        chips = np.ascontiguousarray(chips, np.uint8)
+        self._chk(self.lib.gpsx_replica(self.h, chips.ctypes.data, offset_bits, out.ctypes.data), "gpsx_replica")
+        return out
+
+    def corr_offsets(self, rep, di, dq, offsets):
+        offsets = np.ascontiguousarray(offsets, np.uint16)
+        n = len(offsets)
+        ci, cq, c8 = np.zeros(n, np.uint16), np.zeros(n, np.uint16), np.zeros(n, np.int16)
+        self._chk(self.lib.gpsx_corr_offsets(self.h, rep.ctypes.data, di.ctypes.data, dq.ctypes.data,
+                                             offsets.ctypes.data, n, ci.ctypes.data, cq.ctypes.data, c8.ctypes.data),
+                  "gpsx_corr_offsets")
+        return ci, cq, c8
+
+    def corr_search(self, rep, di, dq, start, stop):
+        pk = np.zeros(1, PEAK_DTYPE)
+        self._chk(self.lib.gpsx_corr_search(self.h, rep.ctypes.data, di.ctypes.data, dq.ctypes.data, start, stop,
+                                            pk.ctypes.data), "gpsx_corr_search")
+        return int(pk["max_val"][0]), int(pk["avr"][0]), int(pk["phase"][0])

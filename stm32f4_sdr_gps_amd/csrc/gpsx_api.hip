@@ -1,0 +1,652 @@
+// gpsx_api.hip -- the C ABI of libgpsx.so (include/gpsx.h): context, device buffers, argument checking, launches.
+// Host code only; every computation named in the header happens in the kernels of k_*.hip.  No CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gpsx_kernels.hpp"
+
+using namespace gpsx;
+
+struct gpsx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // tables for every PRN, slot == prn (slot 0 is the empty code): K1 output
+  uint8_t *d_chips_all = nullptr;    // [211][1024]
+  uint32_t *d_bits_all = nullptr;    // [211][32]
+  uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
+
+  // grouped tables for the PRN list of the last grid call
+  std::vector<uint8_t> grid_prns;
+  int grid_slots = 0;
+  uint8_t *d_grid_prns = nullptr;
+  uint8_t *d_grid_chips = nullptr;
+  uint32_t *d_grid_bits = nullptr;
+  uint32_t *d_grid_cw = nullptr;
+
+  // grow-only scratch arena for the host-pointer entry points
+  char *d_arena = nullptr;
+  size_t arena_bytes = 0;
+  size_t arena_used = 0;
+};
+
+namespace {
+
+int fail(gpsx_ctx *ctx, int code, const std::string &msg)
+{
+  if (ctx)
+    ctx->err = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((ctx), GPSX_EIO, std::string(#call) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+#define LAUNCHCHK(ctx, what)                                                                     \
+  do {                                                                                           \
+    hipError_t e_ = hipGetLastError();                                                           \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((ctx), GPSX_EIO, std::string(what) + " launch: " + hipGetErrorString(e_));     \
+  } while (0)
+
+int arena_reset(gpsx_ctx *ctx, size_t need)
+{
+  ctx->arena_used = 0;
+  if (need <= ctx->arena_bytes)
+    return GPSX_OK;
+  if (ctx->d_arena) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(ctx->d_arena));
+    ctx->d_arena = nullptr;
+    ctx->arena_bytes = 0;
+  }
+  const size_t want = std::max(need, (size_t)1 << 20);
+  if (hipMalloc((void **)&ctx->d_arena, want) != hipSuccess)
+    return fail(ctx, GPSX_ENOMEM, "hipMalloc(arena) failed");
+  ctx->arena_bytes = want;
+  return GPSX_OK;
+}
+
+template <typename T>
+T *arena_take(gpsx_ctx *ctx, size_t count)
+{
+  const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  T *p = reinterpret_cast<T *>(ctx->d_arena + ctx->arena_used);
+  ctx->arena_used += bytes;
+  return p;
+}
+
+size_t arena_size(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+int use_device(gpsx_ctx *ctx)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return GPSX_OK;
+}
+
+int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
+{
+  if ((int)ctx->grid_prns.size() == n_prn && std::equal(prns, prns + n_prn, ctx->grid_prns.begin()))
+    return GPSX_OK;
+  const int slots = (n_prn + kAcqGroup - 1) / kAcqGroup * kAcqGroup;
+  if (slots > ctx->grid_slots) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_grid_prns) {
+      (void)hipFree(ctx->d_grid_prns);
+      (void)hipFree(ctx->d_grid_chips);
+      (void)hipFree(ctx->d_grid_bits);
+      (void)hipFree(ctx->d_grid_cw);
+    }
+    ctx->grid_slots = 0;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_prns, slots));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_chips, (size_t)slots * 1024));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_bits, (size_t)slots * 32 * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_cw, (size_t)slots * kCodeWords * 4));
+    ctx->grid_slots = slots;
+  }
+  std::vector<uint8_t> padded(slots, 0);
+  std::copy(prns, prns + n_prn, padded.begin());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_grid_prns, padded.data(), slots, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `padded` goes out of scope
+  launch_build_codes(ctx->stream, ctx->d_grid_prns, slots, kAcqGroup, ctx->d_grid_chips, ctx->d_grid_bits,
+                     ctx->d_grid_cw);
+  LAUNCHCHK(ctx, "k_build_codes");
+  ctx->grid_prns.assign(prns, prns + n_prn);
+  return GPSX_OK;
+}
+
+int check_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, int n_blocks)
+{
+  if (!g || !g->prns)
+    return fail(ctx, GPSX_EINVAL, "null descriptor");
+  if (g->n_search < 1 || g->n_ms < 1 || g->n_ms > kMaxMs || g->n_prn < 1 || g->n_prn > 255 || g->n_dopp < 1)
+    return fail(ctx, GPSX_EINVAL, "n_search/n_ms/n_prn/n_dopp out of range (n_ms <= 128)");
+  if (g->phase_mode != GPSX_PHASES_BYTE && g->phase_mode != GPSX_PHASES_FINE)
+    return fail(ctx, GPSX_EINVAL, "phase_mode must be 2046 or 16368");
+  if (g->win_start < 0 || g->win_stop > GPSX_PHASES_BYTE || g->win_start > g->win_stop)
+    return fail(ctx, GPSX_EINVAL, "window must satisfy 0 <= start <= stop <= 2046");
+  if (g->shard_count < 0 || (g->shard_count > 0 && (g->shard_index < 0 || g->shard_index >= g->shard_count)))
+    return fail(ctx, GPSX_EINVAL, "bad shard_index/shard_count");
+  if (g->search_stride_blocks < 0)
+    return fail(ctx, GPSX_EINVAL, "negative search stride");
+  const long last = (long)(g->n_search - 1) * g->search_stride_blocks + g->n_ms;
+  if (last > n_blocks)
+    return fail(ctx, GPSX_EINVAL, "descriptor reads past the supplied IF blocks");
+  for (int i = 0; i < g->n_prn; i++)
+    if (g->prns[i] < 1 || g->prns[i] > GPSX_MAX_PRN)
+      return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
+  const long f_lo = (long)GPSX_IF_HZ + g->dopp_min_hz;
+  const long f_hi = f_lo + (long)(g->n_dopp - 1) * g->dopp_step_hz;
+  if (f_lo <= 0 || f_hi <= 0 || f_lo >= 16368000 || f_hi >= 16368000)
+    return fail(ctx, GPSX_EINVAL, "carrier frequency outside (0, fs)");
+  return GPSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpsx_version(void) { return GPSX_VERSION; }
+
+const char *gpsx_strerror(int code)
+{
+  switch (code) {
+    case GPSX_OK: return "ok";
+    case GPSX_EIO: return "HIP runtime failure";
+    case GPSX_ENOMEM: return "out of device memory";
+    case GPSX_ENODEV: return "no usable gfx950 device";
+    case GPSX_EINVAL: return "invalid argument";
+    default: return "unknown gpsx error";
+  }
+}
+
+const char *gpsx_last_error(const gpsx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int gpsx_create(gpsx_ctx **out, int device, void *stream)
+{
+  if (!out)
+    return GPSX_EINVAL;
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+    (void)hipGetLastError();
+    return GPSX_ENODEV;
+  }
+  gpsx_ctx *ctx = new (std::nothrow) gpsx_ctx();
+  if (!ctx)
+    return GPSX_ENOMEM;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
+    delete ctx;
+    return GPSX_ENODEV;
+  }
+  if (std::strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
+    std::fprintf(stderr, "libgpsx: device %d is %s; this library carries gfx950 (MI355X) code only\n", device,
+                 ctx->prop.gcnArchName);
+    delete ctx;
+    return GPSX_ENODEV;
+  }
+  if (stream) {
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return GPSX_EIO;
+    }
+    ctx->own_stream = true;
+  }
+  // K1 for every PRN once: slot == prn
+  const int slots = GPSX_MAX_PRN + 1;
+  uint8_t *d_prns = nullptr;
+  std::vector<uint8_t> prns(slots);
+  for (int i = 0; i < slots; i++)
+    prns[i] = (uint8_t)i;
+  bool ok = hipMalloc((void **)&d_prns, slots) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_chips_all, (size_t)slots * 1024) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_bits_all, (size_t)slots * 32 * 4) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_cw_all, (size_t)slots * kCodeWords * 4) == hipSuccess &&
+            hipMemcpyAsync(d_prns, prns.data(), slots, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+  if (ok) {
+    launch_build_codes(ctx->stream, d_prns, slots, 1, ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+  }
+  if (d_prns)
+    (void)hipFree(d_prns);
+  if (!ok) {
+    std::fprintf(stderr, "libgpsx: device initialisation failed: %s\n", hipGetErrorString(hipGetLastError()));
+    gpsx_destroy(ctx);
+    return GPSX_EIO;
+  }
+  *out = ctx;
+  return GPSX_OK;
+}
+
+void gpsx_destroy(gpsx_ctx *ctx)
+{
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream)
+    (void)hipStreamSynchronize(ctx->stream);
+  void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_grid_prns, ctx->d_grid_chips,
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_arena};
+  for (void *p : bufs)
+    if (p)
+      (void)hipFree(p);
+  if (ctx->own_stream && ctx->stream)
+    (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int gpsx_synchronize(gpsx_ctx *ctx)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *compute_units, int *clock_khz)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  if (name && name_len) {
+    std::snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = ctx->prop.clockRate;
+  return GPSX_OK;
+}
+
+int gpsx_malloc(gpsx_ctx *ctx, void **dptr, size_t bytes)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!dptr)
+    return fail(ctx, GPSX_EINVAL, "null dptr");
+  if (hipMalloc(dptr, bytes ? bytes : 1) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, GPSX_ENOMEM, "hipMalloc failed");
+  }
+  return GPSX_OK;
+}
+
+int gpsx_free(gpsx_ctx *ctx, void *dptr)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipFree(dptr));
+  return GPSX_OK;
+}
+
+int gpsx_memcpy_h2d(gpsx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_memcpy_d2h(gpsx_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_event_create(gpsx_ctx *ctx, void **event)
+{
+  if (int rc = use_device(ctx)) return rc;
+  hipEvent_t e;
+  HIPCHK(ctx, hipEventCreate(&e));
+  *event = e;
+  return GPSX_OK;
+}
+
+int gpsx_event_record(gpsx_ctx *ctx, void *event)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipEventRecord(reinterpret_cast<hipEvent_t>(event), ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_event_elapsed_ms(gpsx_ctx *ctx, void *start, void *stop, float *ms)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+  HIPCHK(ctx, hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+  return GPSX_OK;
+}
+
+int gpsx_event_destroy(gpsx_ctx *ctx, void *event)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+  return GPSX_OK;
+}
+
+/* ---- K1 ----------------------------------------------------------------------------------------------------- */
+
+int gpsx_ca_codes(gpsx_ctx *ctx, const uint8_t *prns, int n_prn, uint8_t *chips_out)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!prns || !chips_out || n_prn < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  for (int i = 0; i < n_prn; i++) {
+    if (prns[i] < 1 || prns[i] > GPSX_MAX_PRN)
+      return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
+    HIPCHK(ctx, hipMemcpyAsync(chips_out + (size_t)i * 1023, ctx->d_chips_all + (size_t)prns[i] * 1024, 1023,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+/* ---- acquisition ---------------------------------------------------------------------------------------------- */
+
+int gpsx_acq_bits(int phase_mode) { return phase_mode == GPSX_PHASES_FINE ? 8 : 1; }
+
+size_t gpsx_acq_keys_count(const gpsx_acq_grid_t *g)
+{
+  return g ? (size_t)g->n_search * g->n_prn * g->n_dopp : 0;
+}
+
+size_t gpsx_acq_peaks_count(const gpsx_acq_grid_t *g)
+{
+  return g ? gpsx_acq_keys_count(g) * gpsx_acq_bits(g->phase_mode) : 0;
+}
+
+int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_blocks, int n_blocks,
+                      gpsx_peak_t *d_peaks, int64_t *d_keys, gpsx_peak_t *d_per_ms, uint32_t *d_energy, uint16_t *d_cnt)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (int rc = check_grid(ctx, g, n_blocks)) return rc;
+  if (!d_if_blocks || !d_peaks)
+    return fail(ctx, GPSX_EINVAL, "null device pointer");
+  if (int rc = ensure_grid_tables(ctx, g->prns, g->n_prn)) return rc;
+
+  const int shard_count = g->shard_count > 0 ? g->shard_count : 1;
+  const int shard_index = g->shard_count > 0 ? g->shard_index : 0;
+  const int n_bits = gpsx_acq_bits(g->phase_mode);
+  const int n_groups = (g->n_prn + kAcqGroup - 1) / kAcqGroup;
+  const long n_units = (long)g->n_search * n_groups * g->n_dopp;
+  const long local_units = n_units > shard_index ? (n_units - shard_index + shard_count - 1) / shard_count : 0;
+  if (local_units * n_bits > 0x7FFFFFFFL)
+    return fail(ctx, GPSX_EINVAL, "grid too large for one launch");
+
+  if (shard_count > 1) {
+    // entries owned by other shards must read as zero
+    HIPCHK(ctx, hipMemsetAsync(d_peaks, 0, gpsx_acq_peaks_count(g) * sizeof(gpsx_peak_t), ctx->stream));
+  }
+  AcqParams prm{};
+  prm.n_ms = g->n_ms;
+  prm.search_stride_blocks = g->search_stride_blocks;
+  prm.n_prn = g->n_prn;
+  prm.n_groups = n_groups;
+  prm.n_dopp = g->n_dopp;
+  prm.dopp_min_hz = g->dopp_min_hz;
+  prm.dopp_step_hz = g->dopp_step_hz;
+  prm.n_bits = n_bits;
+  prm.shard_index = shard_index;
+  prm.shard_count = shard_count;
+  prm.win_start = g->win_start;
+  prm.win_stop = g->win_stop;
+  prm.jobs = nullptr;
+  prm.peaks = d_peaks;
+  prm.per_ms = d_per_ms;
+  prm.energy = d_energy;
+  prm.cnt = d_cnt;
+  launch_acq(ctx->stream, kAcqGroup, (int)(local_units * n_bits), prm, static_cast<const uint8_t *>(d_if_blocks),
+             ctx->d_grid_cw, ctx->d_grid_bits);
+  LAUNCHCHK(ctx, "k_acq");
+  if (d_keys) {
+    launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
+                    shard_count);
+    LAUNCHCHK(ctx, "k_acq_keys");
+  }
+  return GPSX_OK;
+}
+
+int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks, gpsx_peak_t *peaks,
+                  int64_t *keys)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (int rc = check_grid(ctx, g, n_blocks)) return rc;
+  if (!if_blocks || !peaks)
+    return fail(ctx, GPSX_EINVAL, "null host pointer");
+  const size_t n_peaks = gpsx_acq_peaks_count(g), n_keys = gpsx_acq_keys_count(g);
+  const size_t if_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS;
+  if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_peaks * sizeof(gpsx_peak_t)) +
+                                    arena_size(n_keys * sizeof(int64_t))))
+    return rc;
+  uint8_t *d_if = arena_take<uint8_t>(ctx, if_bytes + 2);
+  gpsx_peak_t *d_peaks = arena_take<gpsx_peak_t>(ctx, n_peaks);
+  int64_t *d_keys = keys ? arena_take<int64_t>(ctx, n_keys) : nullptr;
+  HIPCHK(ctx, hipMemcpyAsync(d_if, if_blocks, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = gpsx_acq_grid_dev(ctx, g, d_if, n_blocks, d_peaks, d_keys, nullptr, nullptr, nullptr)) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_peaks * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (keys)
+    HIPCHK(ctx, hipMemcpyAsync(keys, d_keys, n_keys * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const uint8_t *if_blocks, int n_blocks,
+                  gpsx_peak_t *peaks, uint32_t *energy_opt)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!jobs || !if_blocks || !peaks || n_jobs < 1 || n_blocks < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  std::vector<AcqJobRec> recs(n_jobs);
+  const int n_ms = jobs[0].n_ms;
+  for (int i = 0; i < n_jobs; i++) {
+    const gpsx_acq_job_t &j = jobs[i];
+    if (j.n_ms != n_ms)
+      return fail(ctx, GPSX_EINVAL, "all jobs of one call must share n_ms");
+    if (j.n_ms < 1 || j.n_ms > kMaxMs || j.block < 0 || j.block + j.n_ms > n_blocks)
+      return fail(ctx, GPSX_EINVAL, "job block range outside the supplied IF blocks");
+    if (j.prn < 1 || j.prn > GPSX_MAX_PRN)
+      return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
+    if (j.offset_bits < 0 || j.offset_bits > 7)
+      return fail(ctx, GPSX_EINVAL, "offset_bits must be 0..7");
+    if (j.win_start < 0 || j.win_stop > GPSX_PHASES_BYTE || j.win_start > j.win_stop)
+      return fail(ctx, GPSX_EINVAL, "window must satisfy 0 <= start <= stop <= 2046");
+    if (!(j.freq_hz > 0.0f && j.freq_hz < 16368000.0f))
+      return fail(ctx, GPSX_EINVAL, "carrier frequency outside (0, fs)");
+    recs[i] = AcqJobRec{j.block, j.prn, j.freq_hz, j.offset_bits, j.win_start, j.win_stop, i};
+  }
+  const size_t if_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS;
+  const size_t e_count = energy_opt ? (size_t)n_jobs * GPSX_PHASES_BYTE : 0;
+  if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_jobs * sizeof(AcqJobRec)) +
+                                    arena_size(n_jobs * sizeof(gpsx_peak_t)) + arena_size(e_count * 4)))
+    return rc;
+  uint8_t *d_if = arena_take<uint8_t>(ctx, if_bytes + 2);
+  AcqJobRec *d_jobs = arena_take<AcqJobRec>(ctx, n_jobs);
+  gpsx_peak_t *d_peaks = arena_take<gpsx_peak_t>(ctx, n_jobs);
+  uint32_t *d_energy = energy_opt ? arena_take<uint32_t>(ctx, e_count) : nullptr;
+  HIPCHK(ctx, hipMemcpyAsync(d_if, if_blocks, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_jobs, recs.data(), n_jobs * sizeof(AcqJobRec), hipMemcpyHostToDevice, ctx->stream));
+  if (d_energy)
+    HIPCHK(ctx, hipMemsetAsync(d_energy, 0, e_count * 4, ctx->stream));
+  AcqParams prm{};
+  prm.n_ms = n_ms;
+  prm.n_bits = 1;
+  prm.jobs = d_jobs;
+  prm.peaks = d_peaks;
+  prm.energy = d_energy;
+  launch_acq(ctx->stream, 1, n_jobs, prm, d_if, ctx->d_cw_all, ctx->d_bits_all);
+  LAUNCHCHK(ctx, "k_acq(jobs)");
+  HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_jobs * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (energy_opt)
+    HIPCHK(ctx, hipMemcpyAsync(energy_opt, d_energy, e_count * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `recs` alive until the copy has been consumed
+  return GPSX_OK;
+}
+
+/* ---- tracking ------------------------------------------------------------------------------------------------- */
+
+int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_state_t *d_st, int n_ch, int16_t *d_iq_out)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), d_st, n_ch, ctx->d_chips_all, nullptr,
+                   d_iq_out);
+  LAUNCHCHK(ctx, "k_track_epl");
+  return GPSX_OK;
+}
+
+int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!if_block || !st || !iq_out || n_ch < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  for (int i = 0; i < n_ch; i++)
+    if (st[i].prn < 1 || st[i].prn > GPSX_MAX_PRN)
+      return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
+  if (int rc = arena_reset(ctx, arena_size(GPSX_BYTES_PER_MS + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
+                                    arena_size((size_t)n_ch * 12)))
+    return rc;
+  uint8_t *d_if = arena_take<uint8_t>(ctx, GPSX_BYTES_PER_MS + 2);
+  gpsx_trk_state_t *d_st = arena_take<gpsx_trk_state_t>(ctx, n_ch);
+  int16_t *d_iq = arena_take<int16_t>(ctx, (size_t)n_ch * 6);
+  HIPCHK(ctx, hipMemcpyAsync(d_if, if_block, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = gpsx_track_epl_batch_dev(ctx, d_if, d_st, n_ch, d_iq)) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(iq_out, d_iq, (size_t)n_ch * 12, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *steps)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!st || !steps || n_ch < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  if (int rc = arena_reset(ctx, arena_size(n_ch * sizeof(gpsx_trk_state_t)) + arena_size(n_ch)))
+    return rc;
+  gpsx_trk_state_t *d_st = arena_take<gpsx_trk_state_t>(ctx, n_ch);
+  uint8_t *d_steps = arena_take<uint8_t>(ctx, n_ch);
+  HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_steps, steps, n_ch, hipMemcpyHostToDevice, ctx->stream));
+  launch_rewind(ctx->stream, d_st, n_ch, d_steps);
+  LAUNCHCHK(ctx, "k_rewind");
+  HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+/* ---- per-call primitives -------------------------------------------------------------------------------------- */
+
+int gpsx_wipeoff(gpsx_ctx *ctx, const uint8_t *signal, float freq_hz, uint32_t *accum, uint8_t *data_i, uint8_t *data_q)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!signal || !accum || !data_i || !data_q)
+    return fail(ctx, GPSX_EINVAL, "null argument");
+  if (int rc = arena_reset(ctx, 3 * arena_size(2048) + arena_size(4))) return rc;
+  uint8_t *d_sig = arena_take<uint8_t>(ctx, 2048);
+  uint8_t *d_i = arena_take<uint8_t>(ctx, 2048);
+  uint8_t *d_q = arena_take<uint8_t>(ctx, 2048);
+  uint32_t *d_acc = arena_take<uint32_t>(ctx, 1);
+  HIPCHK(ctx, hipMemcpyAsync(d_sig, signal, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  launch_wipeoff(ctx->stream, d_sig, freq_hz, *accum, d_i, d_q, d_acc);
+  LAUNCHCHK(ctx, "k_wipeoff");
+  // bytes 2044, 2045 of the caller's buffers are left alone, as the reference leaves them
+  HIPCHK(ctx, hipMemcpyAsync(data_i, d_i, 2044, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(data_q, d_q, 2044, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(accum, d_acc, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_replica(gpsx_ctx *ctx, const uint8_t *chips, unsigned offset_bits, uint16_t *out)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!chips || !out)
+    return fail(ctx, GPSX_EINVAL, "null argument");
+  if (int rc = arena_reset(ctx, arena_size(1024) + arena_size(2048))) return rc;
+  uint8_t *d_chips = arena_take<uint8_t>(ctx, 1024);
+  uint16_t *d_out = arena_take<uint16_t>(ctx, 1024);
+  HIPCHK(ctx, hipMemcpyAsync(d_chips, chips, 1023, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_out + 1023, out + 1023, 2, hipMemcpyHostToDevice, ctx->stream));  // pad word is OR-ed
+  launch_replica(ctx->stream, d_chips, offset_bits, d_out);
+  LAUNCHCHK(ctx, "k_replica");
+  HIPCHK(ctx, hipMemcpyAsync(out, d_out, 2048, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_corr_offsets(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
+                      const uint16_t *offsets, int n, uint16_t *cnt_i, uint16_t *cnt_q, int16_t *corr8)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!replica || !data_i || !data_q || !offsets || n < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  for (int i = 0; i < n; i++)
+    if (offsets[i] > GPSX_PHASES_BYTE)
+      return fail(ctx, GPSX_EINVAL, "offset must be 0..2046");
+  if (int rc = arena_reset(ctx, 3 * arena_size(2048) + 4 * arena_size((size_t)n * 2))) return rc;
+  uint8_t *d_rep = arena_take<uint8_t>(ctx, 2048);
+  uint8_t *d_i = arena_take<uint8_t>(ctx, 2048);
+  uint8_t *d_q = arena_take<uint8_t>(ctx, 2048);
+  uint16_t *d_off = arena_take<uint16_t>(ctx, n);
+  uint16_t *d_ci = arena_take<uint16_t>(ctx, n);
+  uint16_t *d_cq = arena_take<uint16_t>(ctx, n);
+  int16_t *d_c8 = arena_take<int16_t>(ctx, n);
+  HIPCHK(ctx, hipMemcpyAsync(d_rep, replica, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_i, data_i, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_q, data_q, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_off, offsets, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
+  launch_corr_offsets(ctx->stream, d_rep, d_i, d_q, d_off, 0, n, d_ci, d_cq, d_c8);
+  LAUNCHCHK(ctx, "k_corr_offsets");
+  if (cnt_i) HIPCHK(ctx, hipMemcpyAsync(cnt_i, d_ci, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+  if (cnt_q) HIPCHK(ctx, hipMemcpyAsync(cnt_q, d_cq, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+  if (corr8) HIPCHK(ctx, hipMemcpyAsync(corr8, d_c8, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+int gpsx_corr_search(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
+                     unsigned start_shift, unsigned stop_shift, gpsx_peak_t *peak)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!replica || !data_i || !data_q || !peak)
+    return fail(ctx, GPSX_EINVAL, "null argument");
+  if (stop_shift > (unsigned)GPSX_PHASES_BYTE + 1u)
+    return fail(ctx, GPSX_EINVAL, "stop_shift must be <= 2047");
+  const int n = stop_shift > start_shift ? (int)(stop_shift - start_shift) : 0;
+  if (int rc = arena_reset(ctx, 3 * arena_size(2048) + arena_size((size_t)(n + 1) * 2) + arena_size(sizeof(gpsx_peak_t))))
+    return rc;
+  uint8_t *d_rep = arena_take<uint8_t>(ctx, 2048);
+  uint8_t *d_i = arena_take<uint8_t>(ctx, 2048);
+  uint8_t *d_q = arena_take<uint8_t>(ctx, 2048);
+  int16_t *d_c8 = arena_take<int16_t>(ctx, n + 1);
+  gpsx_peak_t *d_peak = arena_take<gpsx_peak_t>(ctx, 1);
+  HIPCHK(ctx, hipMemcpyAsync(d_rep, replica, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_i, data_i, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_q, data_q, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  launch_corr_offsets(ctx->stream, d_rep, d_i, d_q, nullptr, (int)start_shift, n, nullptr, nullptr, d_c8);
+  LAUNCHCHK(ctx, "k_corr_offsets");
+  launch_search_reduce(ctx->stream, d_c8, n, (int)start_shift, d_peak);
+  LAUNCHCHK(ctx, "k_search_reduce");
+  HIPCHK(ctx, hipMemcpyAsync(peak, d_peak, sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
+}  // extern "C"

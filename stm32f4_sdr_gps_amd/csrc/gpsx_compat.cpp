@@ -1,0 +1,152 @@
+// gpsx_compat.cpp -- the reference's per-call correlator interface (include/gpsx_compat.h) on top of the engine.
+// Host marshalling only: every function forwards to a gpsx_* entry point that runs HIP kernels.
+#include "../../include/gpsx_compat.h"
+
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/gpsx.h"
+
+// layout parity with the reference header on LP64 (probed with the reference's gps_misc.h)
+#if defined(__x86_64__) && defined(__LP64__)
+static_assert(sizeof(gps_acq_t) == 60, "gps_acq_t layout");
+static_assert(offsetof(gps_acq_t, state) == 16 && offsetof(gps_acq_t, code_phase_histogram) == 20, "gps_acq_t layout");
+static_assert(sizeof(gps_tracking_t) == 152, "gps_tracking_t layout");
+static_assert(offsetof(gps_tracking_t, if_freq_offset_hz) == 4 && offsetof(gps_tracking_t, if_freq_accum) == 8,
+              "gps_tracking_t layout");
+static_assert(offsetof(gps_tracking_t, code_phase_fine) == 80 && offsetof(gps_tracking_t, state) == 148,
+              "gps_tracking_t layout");
+static_assert(offsetof(gps_ch_t, tracking_data) == 60 && offsetof(gps_ch_t, nav_data) == 212, "gps_ch_t layout");
+static_assert(offsetof(gps_ch_t, obs_data) == 328 && offsetof(gps_ch_t, eph_data) == 344, "gps_ch_t layout");
+static_assert(offsetof(gps_ch_t, prn) == 664 && offsetof(gps_ch_t, prn_code) == 665 && sizeof(gps_ch_t) == 1688,
+              "gps_ch_t layout");
+#endif
+
+extern "C" {
+uint16_t tmp_prn_data[GPS_DATA_WORDS_CNT];
+uint16_t tmp_data_i[GPS_DATA_WORDS_CNT];
+uint16_t tmp_data_q[GPS_DATA_WORDS_CNT];
+}
+
+namespace {
+
+gpsx_ctx *g_ctx = nullptr;
+
+[[noreturn]] void die(const char *what, int rc)
+{
+  std::fprintf(stderr, "libgpsx (compat): %s failed: %s (%s). The correlator runs on the GPU only; there is no CPU path.\n",
+               what, gpsx_strerror(rc), g_ctx ? gpsx_last_error(g_ctx) : "no context");
+  std::abort();
+}
+
+gpsx_ctx *ctx()
+{
+  if (!g_ctx) {
+    const char *dev = std::getenv("GPSX_DEVICE");
+    const int rc = gpsx_create(&g_ctx, dev ? std::atoi(dev) : 0, nullptr);
+    if (rc != GPSX_OK)
+      die("gpsx_create", rc);
+  }
+  return g_ctx;
+}
+
+}  // namespace
+
+extern "C" {
+
+void gpsx_compat_shutdown(void)
+{
+  gpsx_destroy(g_ctx);
+  g_ctx = nullptr;
+}
+
+void gps_fill_summ_table(void) { (void)ctx(); }
+
+void gps_generate_prn(uint8_t *dest, int prn)
+{
+  if (prn < 1)
+    return;
+  const uint8_t p = (uint8_t)prn;
+  const int rc = gpsx_ca_codes(ctx(), &p, 1, dest);
+  if (rc != GPSX_OK)
+    die("gps_generate_prn", rc);
+}
+
+void gps_channell_prepare(gps_ch_t *channel)
+{
+  if (channel->prn < 1)
+    return;
+  gps_generate_prn(channel->prn_code, channel->prn);
+}
+
+int16_t gps_correlation8(uint16_t *prn_p, uint16_t *data_i, uint16_t *data_q, uint16_t offset)
+{
+  int16_t corr = 0;
+  const int rc = gpsx_corr_offsets(ctx(), prn_p, data_i, data_q, &offset, 1, nullptr, nullptr, &corr);
+  if (rc != GPSX_OK)
+    die("gps_correlation8", rc);
+  return corr;
+}
+
+void gps_correlation_iq(uint16_t *prn_p, uint16_t *data_i, uint16_t *data_q, uint16_t offset, int16_t *res_i,
+                        int16_t *res_q)
+{
+  uint16_t ci = 0, cq = 0;
+  const int rc = gpsx_corr_offsets(ctx(), prn_p, data_i, data_q, &offset, 1, &ci, &cq, nullptr);
+  if (rc != GPSX_OK)
+    die("gps_correlation_iq", rc);
+  *res_i = (int16_t)((int)ci - BITS_IN_PRN / 2);
+  *res_q = (int16_t)((int)cq - BITS_IN_PRN / 2);
+}
+
+uint16_t correlation_search(uint16_t *prn_p, uint16_t *data_i, uint16_t *data_q, uint16_t start_shift,
+                            uint16_t stop_shift, uint16_t *aver_val, uint16_t *phase)
+{
+  gpsx_peak_t pk;
+  const int rc = gpsx_corr_search(ctx(), prn_p, data_i, data_q, start_shift, stop_shift, &pk);
+  if (rc != GPSX_OK)
+    die("correlation_search", rc);
+  *aver_val = (uint16_t)pk.avr;
+  *phase = (uint16_t)pk.phase;
+  return (uint16_t)pk.max_val;
+}
+
+void gps_shift_to_zero_freq(uint8_t *signal_data, uint8_t *data_i, uint8_t *data_q, float freq_hz)
+{
+  uint32_t accum = 0;
+  const int rc = gpsx_wipeoff(ctx(), signal_data, freq_hz, &accum, data_i, data_q);
+  if (rc != GPSX_OK)
+    die("gps_shift_to_zero_freq", rc);
+}
+
+void gps_shift_to_zero_freq_track(gps_tracking_t *trk_channel, uint8_t *signal_data, uint8_t *data_i, uint8_t *data_q)
+{
+  const float freq_hz = (float)IF_FREQ_HZ + trk_channel->if_freq_offset_hz;
+  const int rc = gpsx_wipeoff(ctx(), signal_data, freq_hz, &trk_channel->if_freq_accum, data_i, data_q);
+  if (rc != GPSX_OK)
+    die("gps_shift_to_zero_freq_track", rc);
+}
+
+void gps_generate_prn_data2(gps_ch_t *channel, uint16_t *data, uint16_t offset_bits)
+{
+  const int rc = gpsx_replica(ctx(), channel->prn_code, offset_bits, data);
+  if (rc != GPSX_OK)
+    die("gps_generate_prn_data2", rc);
+}
+
+void gps_rewind_if_phase(gps_tracking_t *trk_channel, uint8_t steps)
+{
+  gpsx_trk_state_t st;
+  st.prn = 1;
+  st.code_phase_fine = 0.0f;
+  st.if_freq_offset_hz = trk_channel->if_freq_offset_hz;
+  st.if_freq_accum = trk_channel->if_freq_accum;
+  const int rc = gpsx_rewind(ctx(), &st, 1, &steps);
+  if (rc != GPSX_OK)
+    die("gps_rewind_if_phase", rc);
+  trk_channel->if_freq_accum = st.if_freq_accum;
+}
+
+}  // extern "C"

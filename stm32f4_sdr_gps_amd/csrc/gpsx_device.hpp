@@ -1,0 +1,97 @@
+// gpsx_device.hpp -- shared device-side definitions for the gfx950 correlator kernels.
+//
+// Signal geometry and arithmetic follow the reference firmware (PM = Firmware/project_main):
+//   PM/config.h:23-28   fs 16.368 MHz, IF 4.092 MHz, 16368 one-bit samples (2046 bytes) per C/A code period
+//   PM/config.h:50      NCO resolution constant 0.003810972f (Hz per accumulator LSB, float32)
+//   PM/GPS/gps_misc.c   the nine correlator primitives whose results these kernels reproduce bit for bit
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpsx {
+
+constexpr int kChips = 1023;          // C/A code length
+constexpr int kSamples = 16368;       // samples per code period
+constexpr int kBytes = 2046;          // packed bytes per code period
+constexpr int kWords16 = 1023;        // 16-bit words per code period (one chip each at zero shift)
+constexpr int kWords32 = 511;         // whole 32-sample words the carrier NCO mixes (the last 16 samples are not)
+constexpr int kHalf = kSamples / 2;   // 8184: popcount centre
+constexpr int kIfHz = 4092000;
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+// Fs/4 square wave, 32 samples per word, indexed by the NCO's top two bits (its quadrant).  The 7-nibble literal
+// 0x09999999 in quadrant 0 (in-phase) / 1 (quadrature) is the reference's, PM/GPS/gps_misc.c:216-217.
+__device__ __forceinline__ u32 carrier_i(u32 quadrant)
+{
+  const u32 t[4] = {0x09999999u, 0xCCCCCCCCu, 0x66666666u, 0x33333333u};
+  return t[quadrant & 3u];
+}
+__device__ __forceinline__ u32 carrier_q(u32 quadrant)
+{
+  const u32 t[4] = {0x33333333u, 0x09999999u, 0xCCCCCCCCu, 0x66666666u};
+  return t[quadrant & 3u];
+}
+
+// NCO accumulator increment per SAMPLE: (uint32)(freq_hz / 0.003810972f) evaluated in IEEE binary32
+// (PM/GPS/gps_misc.c:219,250).  The library is compiled with -fhip-fp32-correctly-rounded-divide-sqrt.
+__device__ __forceinline__ u32 nco_step_per_sample(float freq_hz)
+{
+  const float q = __fdiv_rn(freq_hz, 0.003810972f);
+  return (u32)q;
+}
+// ... per 32-sample word (the NCO is only advanced once per word, PM/GPS/gps_misc.c:220-221,234)
+__device__ __forceinline__ u32 nco_step_per_word(float freq_hz)
+{
+  return (u32)((u64)nco_step_per_sample(freq_hz) * 32ull);
+}
+
+// gps_correlation8's magnitude (PM/GPS/gps_misc.c:106-118): centre, one-sided clip, sqrtf of float32 squares,
+// truncation.  sqrtf must be correctly rounded for the truncation to agree with the host libm.
+__device__ __forceinline__ int mag8(int cnt_i, int cnt_q)
+{
+  int i = cnt_i - kHalf;
+  int q = cnt_q - kHalf;
+  i = i < 0 ? 0 : i;
+  q = q < 0 ? 0 : q;
+  const float e = (float)(i * i) + (float)(q * q);
+  return (int)__fsqrt_rn(e);
+}
+
+__device__ __forceinline__ u32 pop16(u32 v) { return (u32)__popc(v & 0xFFFFu); }
+
+// wave64 all-lanes reductions by butterfly shuffles
+__device__ __forceinline__ u32 wave_max_u32(u32 v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const u32 o = (u32)__shfl_xor((int)v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ u32 wave_sum_u32(u32 v)
+{
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+    v += (u32)__shfl_xor((int)v, m, 64);
+  return v;
+}
+
+// IS-GPS-200 G2 register delay in chips for PRN 1..210 (PM/GPS/gps_misc.c:319-341 uses the same assignment,
+// including the PRN 34 / PRN 37 duplicate).
+__device__ const uint16_t kG2Delay[210] = {
+  5, 6, 7, 8, 17, 18, 139, 140, 141, 251, 252, 254, 255, 256, 257, 258, 469, 470, 471, 472, 473, 474, 509, 512, 513, 514,
+  515, 516, 859, 860, 861, 862, 863, 950, 947, 948, 950, 67, 103, 91, 19, 679, 225, 625, 946, 638, 161, 1001, 554, 280,
+  710, 709, 775, 864, 558, 220, 397, 55, 898, 759, 367, 299, 1018, 729, 695, 780, 801, 788, 732, 34, 320, 327, 389, 407,
+  525, 405, 221, 761, 260, 326, 955, 653, 699, 422, 188, 438, 959, 539, 879, 677, 586, 153, 792, 814, 446, 264, 1015, 278,
+  536, 819, 156, 957, 159, 712, 885, 461, 248, 713, 126, 807, 279, 122, 197, 693, 632, 771, 467, 647, 203, 145, 175, 52,
+  21, 237, 235, 886, 657, 634, 762, 355, 1012, 176, 603, 130, 359, 595, 68, 386, 797, 456, 499, 883, 307, 127, 211, 121,
+  118, 163, 628, 853, 484, 289, 811, 202, 1021, 463, 568, 904, 670, 230, 911, 684, 309, 644, 932, 12, 314, 891, 212, 185,
+  675, 503, 150, 395, 345, 846, 798, 992, 357, 995, 877, 112, 144, 476, 193, 109, 445, 291, 87, 399, 292, 901, 339, 208,
+  711, 189, 263, 537, 663, 942, 173, 900, 30, 500, 935, 556, 373, 85, 652, 310
+};
+
+}  // namespace gpsx

@@ -1,0 +1,71 @@
+// gpsx_kernels.hpp -- host-visible launch interface of the HIP kernels (implemented in k_*.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gpsx.h"
+
+namespace gpsx {
+
+constexpr int kAcqGroup = 8;      // PRNs sharing one workgroup's wiped data in the grid kernel
+constexpr int kCodeWords = 256;   // 4-chip code words per PRN (1023 chips + 1 masked pad)
+constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window sum inside 32 bits
+
+// One search = one workgroup pass: `count` (<= group size) consecutive code-table slots, one carrier frequency,
+// one replica bit shift, n_ms consecutive blocks.
+struct AcqJobRec {
+  int32_t block;        // first IF block
+  int32_t slot;         // first code-table slot
+  float freq_hz;        // IF + Doppler
+  int32_t offset_bits;  // replica shift b
+  int32_t win_start, win_stop;
+  int32_t out_index;    // index of slot 0's result
+};
+
+struct AcqParams {
+  // arithmetic job decode (grid mode, jobs == nullptr)
+  int32_t n_ms;
+  int32_t search_stride_blocks;
+  int32_t n_prn, n_groups, n_dopp, dopp_min_hz, dopp_step_hz;
+  int32_t n_bits;
+  int32_t shard_index, shard_count;
+  int32_t win_start, win_stop;
+  // explicit job list (job mode)
+  const AcqJobRec *jobs;
+  // outputs (optional ones may be null)
+  gpsx_peak_t *peaks;
+  gpsx_peak_t *per_ms;
+  uint32_t *energy;
+  uint16_t *cnt;
+};
+
+// K1: Gold codes + derived tables for `n_slots` code-table slots (padded slots have prn 0 -> all-zero tables).
+//   chips    [n_slots][1024]  0/1 bytes
+//   chipbits [n_slots][32]    packed, bit (i & 31) of word (i >> 5) = chip i
+//   cw       [n_slots/group][256][group]  4 chips per word as SAD reference bytes: 17 (chip 1), 1 (chip 0), 0 (pad)
+void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int group, uint8_t *d_chips,
+                        uint32_t *d_chipbits, uint32_t *d_cw);
+
+// K2+K3+K4 fused acquisition search.  group = kAcqGroup (grid) or 1 (job list).
+void launch_acq(hipStream_t s, int group, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
+                const uint32_t *d_cw, const uint32_t *d_chipbits);
+// keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
+void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
+                     int n_dopp, int n_bits, int shard_index, int shard_count);
+
+// generic per-call primitives on caller-shaped buffers
+void launch_wipeoff(hipStream_t s, const uint8_t *d_signal, float freq_hz, uint32_t accum_in, uint8_t *d_i,
+                    uint8_t *d_q, uint32_t *d_accum_out);
+void launch_replica(hipStream_t s, const uint8_t *d_chips, unsigned offset_bits, uint16_t *d_out);
+void launch_corr_offsets(hipStream_t s, const uint8_t *d_rep, const uint8_t *d_i, const uint8_t *d_q,
+                         const uint16_t *d_offsets, int first_offset, int n, uint16_t *d_cnt_i, uint16_t *d_cnt_q,
+                         int16_t *d_corr8);
+void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int first_offset, gpsx_peak_t *d_peak);
+
+// K2+K3+K5 tracking correlators, one workgroup per channel
+void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_chips,
+                      const int32_t *d_slot_of_channel, int16_t *d_iq);
+void launch_rewind(hipStream_t s, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps);
+
+}  // namespace gpsx

@@ -1,0 +1,412 @@
+// k_acq_grid.hip -- the acquisition search kernel (K2 + K3 + K4 of SURVEY.md 2.1, fused), gfx950 / wave64.
+//
+// What it replaces (PM = Firmware/project_main of the reference):
+//   gps_generate_prn_data2   PM/GPS/gps_misc.c:282-300   replica, 16 samples per chip, shifted by b bits
+//   gps_shift_to_zero_freq   PM/GPS/gps_misc.c:211-240   1-bit carrier wipe-off, NCO restarted at phase 0
+//   gps_mult_and_summ        PM/GPS/gps_misc.c:48-93     XOR + popcount of I and Q against the replica
+//   gps_correlation8         PM/GPS/gps_misc.c:98-122    centre, clip, sqrtf(I^2 + Q^2)
+//   correlation_search       PM/GPS/gps_misc.c:155-191   max / first argmax / sum over byte offsets
+// called once per (channel, Doppler bin, ms) by PM/GPS/acquisition.c:196-312; here one workgroup does one
+// (search, Doppler, bit shift) for G PRNs at once and returns exactly the triplets those calls would return.
+//
+// Formulation (derivation + CPU model: tests/test_formulation.py):
+//   With D the wiped 16368-sample stream (circular; samples 16352.. are 0 because the NCO loop never mixes them)
+//   and s = 8 o + b = 16 q + t0:
+//       cnt(o, b) = C0(s) + [chip1022] (2 pop(D[8o, 8o+b)) - b) - [o odd] (w(p1) + [p1 != 1022] w(1022))
+//       C0(16 q + t0) = sum_c | S'_t0[q + c] - B[c] |
+//   S'_t0[k] = 1 + popcount(D[16k + t0, +16)) are block sums of the data, B[c] = 17 / 1 for chip 1 / 0.
+//   So the 2 x 16368 one-bit MACs of a hypothesis become 2 x 256 byte-SADs (v_msad_u8: four chips per instruction,
+//   the masked form drops the 1024th pad chip).  No matrix cores: this is integer compare-accumulate.
+//
+// Work split: 256 lanes; lane l owns chip offsets q = 4l .. 4l+3 (byte offsets o = 2q + t0/8) for G PRNs and both
+// I and Q: 4 x G x 2 accumulators.  Per 4-chip step j it reads one new dword of S' per stream from LDS, forms the
+// three unaligned windows with v_alignbyte_b32 and issues 8 G SADs against G wave-uniform code words (SGPRs).
+#include "gpsx_device.hpp"
+#include "gpsx_kernels.hpp"
+
+namespace gpsx {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kSDwords = 520;  // S' arrays: 2046 + pad bytes, doubled circular copy, as dwords
+
+template <int G>
+struct AcqShared {
+  uint16_t x[1024];              // raw IF block
+  u32 d[2][514];                 // wiped I / Q streams: 511 words, word 511 = wrap-around copy, zero pad
+  u32 s[2][2][kSDwords];         // [t0 index][I/Q] S' bytes
+  u32 chipbits[G][34];           // 32 words of chips + zero pad for the 64-bit window reads
+  u32 red[4][G][2];              // cross-wave reduction scratch
+};
+
+__device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
+{
+  return (words[byte_index >> 2] >> ((byte_index & 3) * 8)) & 0xFFu;
+}
+
+}  // namespace
+
+template <int G, bool MULTI>
+__global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
+                                                  const u32 *__restrict__ cw, const u32 *__restrict__ chipbits)
+{
+  __shared__ AcqShared<G> sh;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // ---- decode this workgroup's search ------------------------------------------------------------------------
+  int first_block, slot0, b, win_start, win_stop, out0, out_pstride, n_valid;
+  float freq_hz;
+  if (prm.jobs) {
+    const AcqJobRec jr = prm.jobs[blockIdx.x];
+    first_block = jr.block;
+    slot0 = jr.slot;
+    freq_hz = jr.freq_hz;
+    b = jr.offset_bits & 15;
+    win_start = jr.win_start;
+    win_stop = jr.win_stop;
+    out0 = jr.out_index;
+    out_pstride = 1;
+    n_valid = 1;
+  } else {
+    const int unit_local = blockIdx.x / prm.n_bits;
+    b = blockIdx.x - unit_local * prm.n_bits;
+    const int unit = prm.shard_index + unit_local * prm.shard_count;
+    const int dopp = unit % prm.n_dopp;
+    const int t = unit / prm.n_dopp;
+    const int group = t % prm.n_groups;
+    const int search = t / prm.n_groups;
+    first_block = search * prm.search_stride_blocks;
+    slot0 = group * G;
+    // int arithmetic, then one conversion: PM/GPS/acquisition.c:285-289
+    freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);
+    win_start = prm.win_start;
+    win_stop = prm.win_stop;
+    out_pstride = prm.n_dopp * prm.n_bits;
+    out0 = ((search * prm.n_prn + slot0) * prm.n_dopp + dopp) * prm.n_bits + b;
+    n_valid = prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G;
+  }
+  const u32 step_word = nco_step_per_word(freq_hz);
+  const u32 low_mask = (1u << b) - 1u;                 // replica bits of word i that still belong to chip i-1
+  const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;      // ... and to chip i
+  const u32 *cw_group = cw + (size_t)(slot0 / G) * kCodeWords * G;
+
+  for (int i = tid; i < G * 34; i += kThreads) {
+    const int p = i / 34, w = i - p * 34;
+    sh.chipbits[p][w] = w < 32 ? chipbits[(size_t)(slot0 + p) * 32 + w] : 0u;
+  }
+
+  // running result per PRN: packed (value << 11 | 2047 - offset) maximum and the window sum
+  u32 best[G], total[G];
+  u32 energy[MULTI ? 2 : 1][MULTI ? 4 : 1][MULTI ? G : 1];
+#pragma unroll
+  for (int p = 0; p < G; p++) {
+    best[p] = 0;
+    total[p] = 0;
+  }
+  if (MULTI) {
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int p = 0; p < G; p++)
+          energy[MULTI ? a : 0][MULTI ? i : 0][MULTI ? p : 0] = 0;
+  }
+
+  for (int ms = 0; ms < prm.n_ms; ms++) {
+    const bool last_ms = ms == prm.n_ms - 1;
+    // ---- A1: IF block -> LDS (coalesced 16-bit loads: a block starts on an even byte) -------------------------
+    const uint16_t *blk = reinterpret_cast<const uint16_t *>(if_blocks + (size_t)(first_block + ms) * kBytes);
+    __syncthreads();  // previous iteration's readers of sh.* are done
+    for (int i = tid; i < 1024; i += kThreads)
+      sh.x[i] = i < kWords16 ? blk[i] : (uint16_t)0;
+    __syncthreads();
+    // ---- A2: carrier wipe-off (K3).  Word w sees the NCO after w steps from zero. -----------------------------
+    const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
+    for (int w = tid; w < 514; w += kThreads) {
+      u32 vi = 0, vq = 0;
+      if (w < kWords32) {
+        const u32 quad = (step_word * (u32)w) >> 30;
+        vi = carrier_i(quad) ^ x32[w];
+        vq = carrier_q(quad) ^ x32[w];
+      }
+      sh.d[0][w] = vi;
+      sh.d[1][w] = vq;
+    }
+    __syncthreads();
+    if (tid < 2)  // word 511: samples 16352..16367 are zero, then the stream wraps to sample 0
+      sh.d[tid][511] = sh.d[tid][0] << 16;
+    __syncthreads();
+    // ---- A3: block sums S'_t0[k] = 1 + pop(D[16k + t0, +16)), k circular over 1023, for t0 = b and b + 8 --------
+    for (int m = tid; m < 4 * kSDwords; m += kThreads) {
+      const int arr = m / kSDwords;       // 0..3 = (t0 index, I/Q)
+      const int dw = m - arr * kSDwords;
+      const int t0 = b + 8 * (arr >> 1);
+      const u32 *dd = sh.d[arr & 1];
+      u32 packed = 0;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        int k = dw * 4 + e;
+        k = k >= 2 * kChips ? k - 2 * kChips : (k >= kChips ? k - kChips : k);
+        const int pos = 16 * k + t0;
+        const u32 win = __builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31));
+        packed |= (1u + pop16(win)) << (8 * e);
+      }
+      sh.s[arr >> 1][arr & 1][dw] = packed;
+    }
+    __syncthreads();
+
+    const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8;  // data bytes (2045, 0): the word odd offsets skip at the wrap
+    const u32 wrap_q = (sh.d[1][0] & 0xFFu) << 8;
+
+    // ---- B: the SAD loops, t0 = b (even byte offsets) then t0 = b + 8 (odd byte offsets) ------------------------
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+      u32 acc_i[4][G], acc_q[4][G];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          acc_i[i][p] = 0;
+          acc_q[i][p] = 0;
+        }
+      const u32 *si = sh.s[half][0] + tid;
+      const u32 *sq = sh.s[half][1] + tid;
+      u32 cur_i = si[0], cur_q = sq[0];
+#pragma unroll 2
+      for (int j = 0; j < kCodeWords; j++) {
+        const u32 nxt_i = si[j + 1];
+        const u32 nxt_q = sq[j + 1];
+        u32 wi[4], wq[4];
+        wi[0] = cur_i;
+        wq[0] = cur_q;
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+          wi[i] = __builtin_amdgcn_alignbyte(nxt_i, cur_i, (u32)i);
+          wq[i] = __builtin_amdgcn_alignbyte(nxt_q, cur_q, (u32)i);
+        }
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          const u32 code = cw_group[j * G + p];  // wave-uniform -> scalar load
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            acc_i[i][p] = __builtin_amdgcn_msad_u8(wi[i], code, acc_i[i][p]);
+            acc_q[i][p] = __builtin_amdgcn_msad_u8(wq[i], code, acc_q[i][p]);
+          }
+        }
+        cur_i = nxt_i;
+        cur_q = nxt_q;
+      }
+
+      // ---- C: per-hypothesis corrections, magnitude, running search result -------------------------------------
+      // Odd offsets: replica word p1 = 1022 - q meets the buffer wrap.  The lane's four q need chips
+      // p1 - 1 .. p1 for p1 = 1022 - 4 tid - i, i.e. the five chips starting at 1018 - 4 tid (chips below 0 = 0).
+      const int chip_base = kChips - 5 - 4 * tid;
+      const int chip_lo = chip_base < 0 ? 0 : chip_base;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = tid * 4 + i;
+        const int o = 2 * q + half;
+        const bool exists = q < kChips;
+        const bool in_win = exists && o >= win_start && o < win_stop;
+        const int oc = exists ? o : 0;
+        const u32 head_i = __popc(lds_byte(sh.d[0], oc) & low_mask);
+        const u32 head_q = __popc(lds_byte(sh.d[1], oc) & low_mask);
+        u32 prev_i = 0, prev_q = 0;
+        const bool odd_tail = half && q > 0 && exists;  // the last replica word (1022) is skipped too, unless it IS p1
+        if (odd_tail) {
+          prev_i = lds_byte(sh.d[0], oc - 2) | (lds_byte(sh.d[0], oc - 1) << 8);
+          prev_q = lds_byte(sh.d[1], oc - 2) | (lds_byte(sh.d[1], oc - 1) << 8);
+        }
+        const u32 key_lo = (u32)(2047 - o);
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          const u32 tail_bits = chipbits[(size_t)(slot0 + p) * 32 + 31];  // wave-uniform -> scalar load
+          const u32 c1022 = (tail_bits >> 30) & 1u, c1021 = (tail_bits >> 29) & 1u;
+          int ci = (int)acc_i[i][p], cq = (int)acc_q[i][p];
+          if (c1022) {  // replica shift is not circular (chip 1022's last b samples are lost, b zeros lead)
+            ci += 2 * (int)head_i - b;
+            cq += 2 * (int)head_q - b;
+          }
+          if (half) {
+            const u64 two = (u64)sh.chipbits[p][chip_lo >> 5] | ((u64)sh.chipbits[p][(chip_lo >> 5) + 1] << 32);
+            u32 five = (u32)(two >> (chip_lo & 31)) & 31u;
+            five = chip_base < 0 ? five << (chip_lo - chip_base) : five;
+            const u32 cp1 = (five >> (4 - i)) & 1u, cp0 = (five >> (3 - i)) & 1u;
+            const u32 r_wrap = (cp0 ? low_mask : 0u) | (cp1 ? high_mask : 0u);
+            ci -= (int)pop16(wrap_i ^ r_wrap);
+            cq -= (int)pop16(wrap_q ^ r_wrap);
+            if (odd_tail) {
+              const u32 r_last = (c1021 ? low_mask : 0u) | (c1022 ? high_mask : 0u);
+              ci -= (int)pop16(prev_i ^ r_last);
+              cq -= (int)pop16(prev_q ^ r_last);
+            }
+          }
+          u32 val = in_win ? (u32)mag8(ci, cq) : 0u;
+          const int out_idx = out0 + p * out_pstride;
+          if (prm.cnt && last_ms && exists && p < n_valid) {
+            prm.cnt[((size_t)out_idx * kBytes + o) * 2 + 0] = (uint16_t)ci;
+            prm.cnt[((size_t)out_idx * kBytes + o) * 2 + 1] = (uint16_t)cq;
+          }
+          if (MULTI) {
+            if (prm.per_ms) {  // single-block triplet of this ms (what correlation_search would have returned)
+              const u32 key = in_win ? (val << 11) | key_lo : 0u;
+              best[p] = key > best[p] ? key : best[p];
+              total[p] += val;
+            }
+            if (half == 0) {
+              energy[0][MULTI ? i : 0][MULTI ? p : 0] += val;
+              val = energy[0][MULTI ? i : 0][MULTI ? p : 0];
+            } else {
+              energy[MULTI ? 1 : 0][MULTI ? i : 0][MULTI ? p : 0] += val;
+              val = energy[MULTI ? 1 : 0][MULTI ? i : 0][MULTI ? p : 0];
+            }
+          } else {
+            const u32 key = in_win ? (val << 11) | key_lo : 0u;
+            best[p] = key > best[p] ? key : best[p];
+            total[p] += val;
+          }
+          if (prm.energy && last_ms && exists && p < n_valid)
+            prm.energy[(size_t)out_idx * kBytes + o] = val;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the four q epilogues sequential: registers, not ILP, are scarce
+      }
+    }  // half
+
+    // ---- D: workgroup reduction -> one triplet per PRN (per ms in MULTI mode only if asked) ----------------------
+    const bool reduce_now = MULTI ? (prm.per_ms != nullptr) : true;
+    if (reduce_now) {
+#pragma unroll
+      for (int p = 0; p < G; p++) {
+        const u32 k = wave_max_u32(best[p]);
+        const u32 t = wave_sum_u32(total[p]);
+        if (lane == 0) {
+          sh.red[wave][p][0] = k;
+          sh.red[wave][p][1] = t;
+        }
+      }
+      __syncthreads();
+      if (tid < n_valid) {
+        u32 k = 0, t = 0;
+        for (int w = 0; w < 4; w++) {
+          k = sh.red[w][tid][0] > k ? sh.red[w][tid][0] : k;
+          t += sh.red[w][tid][1];
+        }
+        gpsx_peak_t pk;
+        pk.max_val = k >> 11;
+        pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+        pk.sum = t;
+        pk.avr = t / (2u * kChips);
+        const int out_idx = out0 + tid * out_pstride;
+        if (MULTI)
+          prm.per_ms[(size_t)out_idx * prm.n_ms + ms] = pk;
+        else
+          prm.peaks[out_idx] = pk;
+      }
+#pragma unroll
+      for (int p = 0; p < G; p++) {
+        best[p] = 0;
+        total[p] = 0;
+      }
+    }
+  }  // ms
+
+  if (MULTI) {
+    // search over the accumulated energies
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      u32 k = 0, t = 0;
+#pragma unroll
+      for (int half = 0; half < 2; half++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int q = tid * 4 + i;
+          const int o = 2 * q + half;
+          const bool in_win = q < kChips && o >= win_start && o < win_stop;
+          const u32 e = energy[MULTI ? half : 0][MULTI ? i : 0][MULTI ? p : 0];
+          const u32 key = in_win ? (e << 11) | (u32)(2047 - o) : 0u;
+          k = key > k ? key : k;
+          t += in_win ? e : 0u;
+        }
+      k = wave_max_u32(k);
+      t = wave_sum_u32(t);
+      if (lane == 0) {
+        sh.red[wave][p][0] = k;
+        sh.red[wave][p][1] = t;
+      }
+    }
+    __syncthreads();
+    if (tid < n_valid) {
+      u32 k = 0, t = 0;
+      for (int w = 0; w < 4; w++) {
+        k = sh.red[w][tid][0] > k ? sh.red[w][tid][0] : k;
+        t += sh.red[w][tid][1];
+      }
+      gpsx_peak_t pk;
+      pk.max_val = k >> 11;
+      pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+      pk.sum = t;
+      pk.avr = t / (2u * kChips);
+      prm.peaks[out0 + tid * out_pstride] = pk;
+    }
+  }
+}
+
+void launch_acq(hipStream_t s, int group, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
+                const uint32_t *d_cw, const uint32_t *d_chipbits)
+{
+  if (n_workgroups <= 0)
+    return;
+  const dim3 grid(n_workgroups), block(kThreads);
+  const bool multi = prm.n_ms > 1;
+  if (group == kAcqGroup) {
+    if (multi)
+      hipLaunchKernelGGL((k_acq<kAcqGroup, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    else
+      hipLaunchKernelGGL((k_acq<kAcqGroup, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  } else {
+    if (multi)
+      hipLaunchKernelGGL((k_acq<1, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    else
+      hipLaunchKernelGGL((k_acq<1, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  }
+}
+
+// One packed key per (search, PRN, Doppler): max over the bit shifts, zero for units this shard did not compute.
+__global__ void k_acq_keys(const gpsx_peak_t *__restrict__ peaks, int64_t *__restrict__ keys, int n_search, int n_prn,
+                           int n_groups, int n_dopp, int n_bits, int shard_index, int shard_count)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = n_search * n_prn * n_dopp;
+  if (idx >= n)
+    return;
+  const int dopp = idx % n_dopp;
+  const int prn = (idx / n_dopp) % n_prn;
+  const int search = idx / (n_dopp * n_prn);
+  const int unit = (search * n_groups + prn / kAcqGroup) * n_dopp + dopp;
+  int64_t best = 0;
+  if (unit % shard_count == shard_index) {
+    for (int b = 0; b < n_bits; b++) {
+      const gpsx_peak_t pk = peaks[(size_t)idx * n_bits + b];
+      const int64_t key = ((int64_t)pk.max_val << 14) | (int64_t)(16383 - (int)(8 * pk.phase + b));
+      best = key > best ? key : best;
+    }
+  }
+  keys[idx] = best;
+}
+
+void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
+                     int n_dopp, int n_bits, int shard_index, int shard_count)
+{
+  const int n = n_search * n_prn * n_dopp;
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(k_acq_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_peaks, d_keys, n_search, n_prn, n_groups,
+                     n_dopp, n_bits, shard_index, shard_count);
+}
+
+}  // namespace gpsx

@@ -1,0 +1,373 @@
+"""GPU parity tests: the HIP engine, called through the C ABI (libgpsx.so via ctypes), against
+  (a) the committed golden vectors produced by the reference's own C (tests/golden/), and
+  (b) the CPU oracle (oracle/liboracle.so) on seeded inputs.
+Everything here is integer/bit work: the bar is bit-exact equality.  Nothing reads /root/reference.
+"""
+import numpy as np
+import pytest
+
+from golden_util import IF_HZ, fnv1a32, known_answers, load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from stm32f4_sdr_gps_amd import capi
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def stream():
+    from stm32f4_sdr_gps_amd import synth
+    return synth.default_four_sv(12, seed=7)
+
+
+def _peak_tuple(p):
+    return int(p["max_val"]), int(p["phase"]), int(p["sum"]), int(p["avr"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K1
+def test_ca_codes_golden(eng):
+    g = load("f1_ca_codes.npz")
+    chips = eng.ca_codes(np.arange(1, 211))
+    assert np.array_equal(chips[:32], g["chips_1_32"])
+    for prn in range(1, 211):
+        assert fnv1a32(chips[prn - 1]) == int(g["fnv_1_210"][prn - 1]), prn
+
+
+def test_ca_codes_rejects_bad_prn(eng):
+    from stm32f4_sdr_gps_amd.capi import GpsxError
+    with pytest.raises(GpsxError):
+        eng.ca_codes([0])
+    with pytest.raises(GpsxError):
+        eng.ca_codes([211])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# per-call primitives (the device work behind the reference-named functions)
+def test_wipeoff_golden(eng):
+    g = load("f2_wipeoff.npz")
+    for k in range(3):
+        for j, d in enumerate(g["doppler_hz"]):
+            di, dq, _ = eng.wipeoff(g["blocks"][k], float(IF_HZ + int(d)))
+            assert fnv1a32(di[:1022]) == int(g["fnv_i"][k, j]) and fnv1a32(dq[:1022]) == int(g["fnv_q"][k, j])
+    di, dq, _ = eng.wipeoff(g["blocks"][0], float(IF_HZ + 900))
+    assert np.array_equal(di, g["example_i"]) and np.array_equal(dq, g["example_q"])
+    # stateful NCO over 20 ms + rewind
+    from stm32f4_sdr_gps_amd.capi import TRK_DTYPE
+    acc = int(g["track_acc0"])
+    for ms in range(20):
+        off = np.float32(g["track_offsets"][ms])
+        di, dq, acc = eng.wipeoff(g["blocks"][ms % 3], float(np.float32(IF_HZ) + off), acc)
+        assert acc == int(g["track_accs"][ms])
+        assert [fnv1a32(di[:1022]), fnv1a32(dq[:1022])] == list(map(int, g["track_fnv"][ms]))
+        st = np.zeros(1, TRK_DTYPE)
+        st["prn"], st["if_freq_offset_hz"], st["if_freq_accum"] = 1, off, acc
+        eng.rewind(st, [int(g["rewind_steps"][ms])])
+        assert int(st["if_freq_accum"][0]) == int(g["rewind_out"][ms])
+
+
+def test_wipeoff_leaves_last_16_samples_alone(eng):
+    rng = np.random.default_rng(5)
+    pre = (rng.integers(0, 65536, 1024).astype(np.uint16), rng.integers(0, 65536, 1024).astype(np.uint16))
+    sig = rng.integers(0, 256, 2046, dtype=np.uint8)
+    di, dq, _ = eng.wipeoff(sig, 4092000.0 + 1234.0, 0, prefill=pre)
+    assert di[1022] == pre[0][1022] and dq[1022] == pre[1][1022] and di[1023] == pre[0][1023]
+
+
+def test_nco_step_float_division_matches_host(eng, oracle):
+    # (uint32)(freq / 0.003810972f) must round as IEEE binary32 on the device: compare accumulators after one block
+    rng = np.random.default_rng(6)
+    sig = np.zeros(2046, np.uint8)
+    freqs = np.concatenate([np.float32(IF_HZ) + rng.uniform(-10000, 10000, 300).astype(np.float32),
+                            rng.uniform(1e3, 1.6e7, 100).astype(np.float32)])
+    for f in freqs:
+        _, _, acc = eng.wipeoff(sig, float(f), 0)
+        want = (oracle.nco_step(float(f)) * 32 * 511) & 0xFFFFFFFF
+        assert acc == want, float(f)
+
+
+def test_replica_golden(eng):
+    g = load("f3_replica.npz")
+    codes = eng.ca_codes(g["prns"])
+    for a in range(3):
+        for b in range(16):
+            assert np.array_equal(eng.replica(codes[a], b), g["replica"][a, b])
+    # the pad word is OR-ed, never cleared (gps_misc.c:284)
+    out = eng.replica(codes[1], 5, pad_in=0xA500)
+    assert out[1023] == (0xA500 | int(g["replica"][1, 5][1023]))
+
+
+def test_corr_offsets_golden_planes(eng):
+    g = load("f4_corr.npz")
+    blk = g["stream"][int(g["block_index"])]
+    offsets = np.arange(2047, dtype=np.uint16)
+    for a, (prn, d) in enumerate(g["full_cases"]):
+        di, dq, _ = eng.wipeoff(blk, float(IF_HZ + int(d)))
+        chips = eng.ca_codes([int(prn)])[0]
+        for b in range(8):
+            rep = eng.replica(chips, b)
+            ci, cq, c8 = eng.corr_offsets(rep, di, dq, offsets)
+            assert np.array_equal(ci, g["cnt_i"][a, b]) and np.array_equal(cq, g["cnt_q"][a, b])
+            assert np.array_equal(c8, g["corr8"][a, b])
+
+
+def test_corr_offsets_arbitrary_buffers_vs_oracle(eng, oracle):
+    # buffers that are NOT chip-shaped / wiped: the per-call interface must be exact for any contents
+    rng = np.random.default_rng(7)
+    offsets = np.arange(2047, dtype=np.uint16)
+    for _ in range(3):
+        rep = rng.integers(0, 65536, 1024).astype(np.uint16)
+        di = rng.integers(0, 65536, 1024).astype(np.uint16)
+        dq = rng.integers(0, 65536, 1024).astype(np.uint16)
+        ci, cq, c8 = eng.corr_offsets(rep, di, dq, offsets)
+        want = np.array([oracle.mult_and_summ(di, dq, rep, int(o)) for o in offsets])
+        assert np.array_equal(ci, want[:, 0]) and np.array_equal(cq, want[:, 1])
+        assert np.array_equal(c8, [oracle.mag8(int(a), int(b)) for a, b in want])
+
+
+def test_corr_search_golden(eng):
+    g = load("f4_corr.npz")
+    blk = g["stream"][int(g["block_index"])]
+    for prn, d, b, s0, s1, mx, av, ph in g["search"]:
+        di, dq, _ = eng.wipeoff(blk, float(IF_HZ + int(d)))
+        rep = eng.replica(eng.ca_codes([int(prn)])[0], int(b))
+        assert eng.corr_search(rep, di, dq, int(s0), int(s1)) == (int(mx), int(av), int(ph))
+    z = np.zeros(1024, np.uint16)
+    assert eng.corr_search(z, z, z, 300, 400) == (0, 0, 0)   # nothing above zero: phase 0 whatever the window
+
+
+def test_config1_reference_self_test_through_reference_named_calls(eng):
+    """BASELINE.json configs[0] / SS/main.c:59-69, written the way the reference writes it."""
+    import ctypes as C
+    lib = eng.lib
+    g = load("f6_config1.npz")
+    ka = known_answers()["f6_config1"]
+    ch = np.zeros(1688, np.uint8)          # gps_ch_t
+    ch[664] = 1                            # .prn = SIM_PRN_CODE
+    lib.gps_fill_summ_table()
+    lib.gps_channell_prepare(ch.ctypes.data)
+    assert np.array_equal(ch[665:665 + 1023], load("f1_ca_codes.npz")["chips_1_32"][0])
+    tmp_prn, tmp_i, tmp_q = (np.zeros(1024, np.uint16) for _ in range(3))
+    for k, noise in enumerate(g["noise_levels"]):
+        signal = np.ascontiguousarray(g["blocks"][k])
+        lib.gps_generate_prn_data2(ch.ctypes.data, tmp_prn.ctypes.data, 0)
+        lib.gps_shift_to_zero_freq(signal.ctypes.data, tmp_i.ctypes.data, tmp_q.ctypes.data, C.c_float(IF_HZ + 2000))
+        avr, phase = C.c_uint16(), C.c_uint16()
+        mx = lib.correlation_search(tmp_prn.ctypes.data, tmp_i.ctypes.data, tmp_q.ctypes.data, 0, 2046,
+                                    C.byref(avr), C.byref(phase))
+        want = ka[str(int(noise))]
+        assert (mx, avr.value, phase.value) == (want["max"], want["avr"], want["phase"])
+        ri, rq = C.c_int16(), C.c_int16()
+        lib.gps_correlation_iq(tmp_prn.ctypes.data, tmp_i.ctypes.data, tmp_q.ctypes.data, 100, C.byref(ri), C.byref(rq))
+        assert (ri.value, rq.value) == (want["i_at_100"], want["q_at_100"])
+        assert lib.gps_correlation8(tmp_prn.ctypes.data, tmp_i.ctypes.data, tmp_q.ctypes.data, 100) == want["max"]
+    assert ka["0"]["max"] == 7904 and ka["0"]["phase"] == 100
+
+
+def test_reference_named_tracking_calls(eng, oracle):
+    import ctypes as C
+    lib = eng.lib
+    rng = np.random.default_rng(8)
+    trk = np.zeros(152, np.uint8)          # gps_tracking_t
+    off, acc = np.float32(-1234.5), 0xDEADBEEF
+    trk[4:8] = np.frombuffer(off.tobytes(), np.uint8)
+    trk[8:12] = np.frombuffer(np.uint32(acc).tobytes(), np.uint8)
+    sig = rng.integers(0, 256, 2046, dtype=np.uint8)
+    di, dq = np.zeros(1024, np.uint16), np.zeros(1024, np.uint16)
+    lib.gps_shift_to_zero_freq_track(trk.ctypes.data, sig.ctypes.data, di.ctypes.data, dq.ctypes.data)
+    oi, oq, oacc = oracle.wipeoff(sig, float(np.float32(IF_HZ) + off), acc)
+    assert np.array_equal(di, oi) and np.array_equal(dq, oq)
+    assert int(trk[8:12].view(np.uint32)[0]) == oacc
+    lib.gps_rewind_if_phase(trk.ctypes.data, 13)
+    assert int(trk[8:12].view(np.uint32)[0]) == oracle.rewind(float(off), oacc, 13)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K2+K3+K4: the acquisition grid kernel
+def test_acq_grid_raw_counts_and_energy_vs_golden_planes(eng):
+    g = load("f4_corr.npz")
+    blk = g["stream"][int(g["block_index"])][None, :]
+    for a, (prn, d) in enumerate(g["full_cases"]):
+        out = eng.acq_grid_debug(blk, [int(prn)], dopp_min_hz=int(d), n_dopp=1, want_cnt=True, want_energy=True)
+        for b in range(8):
+            assert np.array_equal(out["cnt"][0, 0, 0, b, :, 0], g["cnt_i"][a, b, :2046]), (prn, d, b)
+            assert np.array_equal(out["cnt"][0, 0, 0, b, :, 1], g["cnt_q"][a, b, :2046]), (prn, d, b)
+            assert np.array_equal(out["energy"][0, 0, 0, b], g["corr8"][a, b, :2046].astype(np.uint32))
+
+
+def test_acq_grid_peaks_vs_golden_search_triplets(eng):
+    g = load("f4_corr.npz")
+    blk = g["stream"][int(g["block_index"])][None, :]
+    for prn, d, b, s0, s1, mx, av, ph in g["search"]:
+        peaks, _ = eng.acq_grid(blk, [int(prn)], dopp_min_hz=int(d), n_dopp=1, win=(int(s0), int(s1)))
+        p = peaks[0, 0, 0, int(b)]
+        assert (int(p["max_val"]), int(p["avr"]), int(p["phase"])) == (int(mx), int(av), int(ph))
+    for prn, d, b, h, mx, av, ph in g["hashed"]:
+        out = eng.acq_grid_debug(blk, [int(prn)], dopp_min_hz=int(d), n_dopp=1, want_energy=True)
+        assert fnv1a32(out["energy"][0, 0, 0, int(b)].astype(np.int16)) == int(h)
+        p = out["peaks"][0, 0, 0, int(b)]
+        assert (int(p["max_val"]), int(p["avr"]), int(p["phase"])) == (int(mx), int(av), int(ph))
+
+
+def test_acq_grid_full_cold_start_grid_vs_oracle(eng, oracle):
+    """BASELINE.json configs[2] at full size: 32 PRN x 21 Doppler x 16368 phases on one block, every triplet."""
+    from stm32f4_sdr_gps_amd import synth
+    blk = synth.cold_start_block(1, seed=11)
+    prns = np.arange(1, 33, dtype=np.uint8)
+    peaks, keys = eng.acq_grid(blk, prns, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
+    want = oracle.acq_grid(blk, 1, prns, -5000, 500, 21, 8, n_threads=8)
+    for f in ("max_val", "phase", "sum", "avr"):
+        assert np.array_equal(peaks[0][f], want[f]), f
+    # packed keys: energy and lowest fine phase of the best bit shift
+    fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+    k = (want["max_val"].astype(np.int64) << 14) | (16383 - fine)
+    assert np.array_equal(keys[0], k.max(axis=2))
+    # the six satellites of the synthetic block dominate their (PRN, Doppler) neighbourhood
+    assert int(peaks["max_val"].max()) > 1500
+
+
+def test_acq_grid_reference_native_grid_29_bins_byte_phases(eng, oracle, stream):
+    prns = np.array([5, 14, 20, 30, 1], np.uint8)
+    from stm32f4_sdr_gps_amd.capi import PHASES_BYTE
+    peaks, _ = eng.acq_grid(stream[4:5], prns, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=PHASES_BYTE)
+    want = oracle.acq_grid(stream[4:5], 1, prns, -7000, 500, 29, 1, n_threads=4)
+    for f in ("max_val", "phase", "sum", "avr"):
+        assert np.array_equal(peaks[0][f], want[f]), f
+
+
+def test_acq_grid_non_coherent_10ms_and_per_ms_triplets(eng, oracle, stream):
+    """BASELINE.json configs[3] semantics: energy = sum over 10 blocks of the per-block magnitude."""
+    prns = np.array([5, 14, 20, 30, 7, 9, 11, 13, 15], np.uint8)   # 9 PRNs: exercises a partial PRN group
+    out = eng.acq_grid_debug(stream[:10], prns, n_ms=10, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5,
+                             want_per_ms=True, want_energy=True)
+    want = oracle.acq_grid(stream[:10], 10, prns, -1000, 500, 5, 8, n_threads=8)
+    for f in ("max_val", "phase", "sum", "avr"):
+        assert np.array_equal(out["peaks"][0][f], want[f]), f
+    for p, d, b in [(0, 3, 0), (1, 4, 5), (8, 0, 7), (3, 2, 2)]:
+        pk, energy, per_ms = oracle.search_job(stream[:10], 10, oracle.ca_code(int(prns[p])),
+                                               float(IF_HZ - 1000 + 500 * d), b, want_energy=True, want_per_ms=True)
+        assert np.array_equal(out["energy"][0, p, d, b], energy)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(out["per_ms"][0, p, d, b][f], per_ms[f]), f
+    # PRN 5 at +900 Hz bin (index 4 is +1000, index 3 is +500): the 10 ms sum must find delay 1600 samples = 200 bytes
+    assert int(out["peaks"][0, 0, 4, 0]["phase"]) == 200 or int(out["peaks"][0, 0, 3, 0]["phase"]) == 200
+
+
+def test_acq_grid_multiple_searches_and_stride(eng, oracle, stream):
+    prns = np.array([5, 30], np.uint8)
+    peaks, _ = eng.acq_grid(stream[:9], prns, n_search=3, n_ms=2, search_stride_blocks=3, dopp_min_hz=500,
+                            dopp_step_hz=500, n_dopp=4)
+    for s in range(3):
+        want = oracle.acq_grid(stream[3 * s:3 * s + 2], 2, prns, 500, 500, 4, 8, n_threads=4)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(peaks[s][f], want[f]), (s, f)
+
+
+def test_acq_grid_windows(eng, oracle, stream):
+    prns = np.array([5, 14], np.uint8)
+    for win in [(0, 500), (250, 751), (2045, 2046), (7, 7), (1, 2)]:
+        peaks, _ = eng.acq_grid(stream[6:7], prns, dopp_min_hz=1000, n_dopp=1, win=win)
+        for p, prn in enumerate(prns):
+            for b in range(8):
+                pk, _, _ = oracle.search_job(stream[6:7], 1, oracle.ca_code(int(prn)), float(IF_HZ + 1000), b,
+                                             win[0], win[1])
+                assert _peak_tuple(peaks[0, p, 0, b]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"])
+
+
+def test_acq_grid_sharding_union_equals_single(eng, stream):
+    """Multi-GPU contract: shards compute disjoint (search, PRN-group, Doppler) units; max over shards of the key
+    tables equals the unsharded table; peaks of foreign units are zero."""
+    prns = np.arange(1, 21, dtype=np.uint8)      # 20 PRNs -> 3 groups
+    kw = dict(n_search=2, n_ms=1, search_stride_blocks=1, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
+    full_peaks, full_keys = eng.acq_grid(stream[:2], prns, **kw)
+    for world in (2, 3, 8):
+        acc = np.zeros_like(full_keys)
+        owned = np.zeros(full_keys.shape, np.int32)
+        for r in range(world):
+            pk, ks = eng.acq_grid(stream[:2], prns, shard=(r, world), **kw)
+            acc = np.maximum(acc, ks)
+            mine = ks != 0
+            owned += mine
+            assert np.array_equal(pk["max_val"][mine], full_peaks["max_val"][mine])
+            assert not pk["sum"][~mine].any()
+        assert np.array_equal(acc, full_keys)
+        assert (owned == 1).all()
+
+
+def test_acq_jobs_per_channel_hints_and_windows(eng, oracle, stream):
+    """acquisition_process() shape: the reference's 4-channel table, each with its own Doppler hint and window."""
+    from stm32f4_sdr_gps_amd.capi import JOB_DTYPE
+    jobs = np.zeros(7, JOB_DTYPE)
+    rows = [(0, 1, 5, IF_HZ + 900, 0, 0, 2046), (0, 1, 14, IF_HZ + 4000, 0, 0, 2046), (1, 1, 20, IF_HZ - 1000, 0, 875, 1375),
+            (2, 1, 30, IF_HZ + 2000, 0, 1595, 1655), (3, 1, 5, 4092912.5, 3, 185, 215), (0, 1, 120, IF_HZ + 33.25, 7, 0, 2046),
+            (4, 1, 32, 4089000.75, 1, 2000, 2046)]
+    for i, r in enumerate(rows):
+        jobs[i] = r
+    peaks, energy = eng.acq_jobs(stream, jobs, want_energy=True)
+    for i, (blk, n_ms, prn, f, b, s0, s1) in enumerate(rows):
+        pk, en, _ = oracle.search_job(stream[blk:blk + n_ms], n_ms, oracle.ca_code(prn), float(np.float32(f)), b, s0, s1,
+                                      want_energy=True)
+        assert _peak_tuple(peaks[i]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), i
+        assert np.array_equal(energy[i], en), i
+
+
+def test_acq_rejects_bad_arguments(eng, stream):
+    from stm32f4_sdr_gps_amd.capi import GpsxError, JOB_DTYPE
+    with pytest.raises(GpsxError):
+        eng.acq_grid(stream[:1], [0])
+    with pytest.raises(GpsxError):
+        eng.acq_grid(stream[:1], [1], n_ms=2)                 # reads past the supplied blocks
+    with pytest.raises(GpsxError):
+        eng.acq_grid(stream[:1], [1], win=(5, 3000))
+    with pytest.raises(GpsxError):
+        eng.acq_grid(stream[:1], [1], phase_mode=1234)
+    jobs = np.zeros(1, JOB_DTYPE)
+    jobs[0] = (0, 1, 5, float(IF_HZ), 9, 0, 2046)            # offset_bits > 7
+    with pytest.raises(GpsxError):
+        eng.acq_jobs(stream[:1], jobs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K2+K3+K5: tracking correlators
+def test_track_epl_256_channels_vs_oracle(eng, oracle, stream):
+    """BASELINE.json configs[4] shape: 256 concurrent channels on one shared IF stream, several milliseconds."""
+    from stm32f4_sdr_gps_amd.capi import TRK_DTYPE
+    rng = np.random.default_rng(9)
+    n = 256
+    st = np.zeros(n, TRK_DTYPE)
+    st["prn"] = (np.arange(n) % 32) + 1
+    st["code_phase_fine"] = rng.uniform(0, 16368, n).astype(np.float32)
+    st["code_phase_fine"][:8] = [0.0, 0.99, 7.5, 8.0, 15.9, 16367.9, 16368.0, 16360.0]   # E/L wrap cases
+    st["if_freq_offset_hz"] = (-5000 + 39 * np.arange(n)).astype(np.float32) + rng.uniform(-1, 1, n).astype(np.float32)
+    st["if_freq_accum"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    ref_acc = st["if_freq_accum"].copy()
+    for ms in range(4):
+        fine_before = st["code_phase_fine"].copy()
+        iq = eng.track_epl(stream[ms], st)
+        for c in range(n):
+            want, ref_acc[c] = oracle.track_epl(stream[ms], oracle.ca_code(int(st["prn"][c])), float(fine_before[c]),
+                                                float(st["if_freq_offset_hz"][c]), int(ref_acc[c]))
+            assert np.array_equal(iq[c], want), (ms, c)
+        assert np.array_equal(st["if_freq_accum"], ref_acc)
+        st["code_phase_fine"] = np.mod(st["code_phase_fine"] + rng.uniform(-3, 3, n).astype(np.float32), 16368).astype(np.float32)
+
+
+def test_track_epl_four_sv_default_table_locks_on_signal(eng, stream):
+    """BASELINE.json configs[1]: the reference's 4-SV table (PM/main.c:59-73).  With the true code phase and a
+    Doppler within tens of Hz, the prompt correlator must dominate early/late and carry most of the power."""
+    from stm32f4_sdr_gps_amd.capi import TRK_DTYPE
+    st = np.zeros(4, TRK_DTYPE)
+    st["prn"] = [5, 14, 20, 30]
+    st["code_phase_fine"] = [1600.0, 4000.0, 9000.0, 13000.0]
+    st["if_freq_offset_hz"] = [912.5, 4037.0, -1025.0, 2018.0]
+    power = np.zeros((4, 3))
+    for ms in range(12):
+        iq = eng.track_epl(stream[ms], st).astype(np.int64)
+        power += np.stack([iq[:, 0] ** 2 + iq[:, 1] ** 2, iq[:, 2] ** 2 + iq[:, 3] ** 2, iq[:, 4] ** 2 + iq[:, 5] ** 2], 1)
+    assert (power[:, 1] > power[:, 0]).all() and (power[:, 1] > power[:, 2]).all()
+    assert (np.sqrt(power[:, 1] / 12) > 1500).all()
