@@ -180,6 +180,23 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
 
+    # PCIe-inclusive rate of the host-buffer entry point (H2D of the captures + launch + D2H of peaks and keys); reported
+    # as an extra, never as `value`
+    pcie = None
+    if world == 1:
+        g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+                           dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
+        h_peaks = np.zeros((n_search, N_PRN, N_DOPP, 8), capi.PEAK_DTYPE)
+        h_keys = np.zeros((n_search, N_PRN, N_DOPP), np.int64)
+        reps = 10
+        for i in range(reps + 2):
+            if i == 2:
+                tp = time.perf_counter()
+            rc = eng.lib.gpsx_acq_grid(eng.h, C.byref(g1), blocks.ctypes.data, n_search, h_peaks.ctypes.data,
+                                       h_keys.ctypes.data)
+            assert rc == 0
+        pcie = reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
+
     # sanity outside the timed region: the merged key table must hold the six synthetic satellites' peaks
     keys = d_keys.cpu().numpy()
     energy = keys >> 14
@@ -244,6 +261,9 @@ def main():
             },
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }
+        if pcie is not None:
+            line["pcie_inclusive"] = {"value": pcie, "unit": "hypotheses/s",
+                                      "note": "gpsx_acq_grid() with host buffers: H2D captures + launch + D2H peaks/keys"}
         if not args.no_cpu_baseline and world == 1:
             line.update(cpu_baseline(blocks, args.cpu_budget_s))
             line["cpu_host"] = {"logical_cpus": os.cpu_count()}
