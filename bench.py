@@ -125,8 +125,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GPSX_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL at world 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from stm32f4_sdr_gps_amd import capi, synth  # after torch: one HIP runtime per process
@@ -153,13 +155,13 @@ def main():
                                            d_keys.data_ptr(), None, None, None)
             if rc != 0:
                 raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
-            if world > 1:
+            if use_dist:
                 dist.all_reduce(d_keys, op=dist.ReduceOp.MAX)
 
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = eng.event(), eng.event()
@@ -169,14 +171,14 @@ def main():
             step()
         eng.record(ev1)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         gpu_ms = eng.elapsed_ms(ev0, ev1)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
 
@@ -270,7 +272,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
