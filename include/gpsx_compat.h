@@ -35,6 +35,16 @@ extern "C" {
 #define TRACKING_CH_LENGTH         4
 #define GPS_SAT_CNT                4
 #define GPS_DATA_WORDS_CNT         (PRN_SPI_WORDS_CNT + 1)   /* PM/GPS/common_ram.h:10 */
+#define IF_NCO_STEP_HZ             (0.003810972f)            /* PM/config.h:50 */
+/* tracking loop gains, PM/config.h:61-71 */
+#define TRACKING_DLL1_C1           (1.0f)
+#define TRACKING_DLL1_C2           (300.0f)
+#define TRACKING_PLL1_C1           (4.0f)
+#define TRACKING_PLL1_C2           (3000.0f)
+#define TRACKING_PLL2_C1           (8.0f)
+#define TRACKING_PLL2_C2           (5000.0f)
+#define TRACKING_FLL1_C1           (200.0f)
+#define TRACKING_FLL1_C2           (2000.0f)
 
 typedef enum {
   GPS_ACQ_NEED_FREQ_SEARCH = 0,
@@ -102,11 +112,21 @@ typedef struct {
   gps_tracking_state_t state;
 } gps_tracking_t;
 
-/* Navigation-message, observation and ephemeris state are outside the correlator path; they are carried as
- * opaque storage of the reference's size so that gps_ch_t keeps its layout (gps_misc.h:101-182). */
-typedef union {
-  uint8_t  period_sync_ok_flag;    /* first member of the reference's gps_nav_data_t; read by the PLL */
-  uint32_t opaque_[28];
+/* Navigation-bit synchronisation state: the leading members of the reference's gps_nav_data_t (gps_misc.h:101-133),
+ * which the tracking step reads (PLL gain selection) and its nav-bit hook writes.  Word / subframe assembly, observation
+ * and ephemeris state are outside the correlator path and are carried as opaque storage of the reference's size so that
+ * gps_ch_t keeps its layout (gps_misc.h:134-182). */
+typedef struct {
+  uint8_t  period_sync_ok_flag;    /* 20 ms bit period found                                       */
+  uint8_t  right_period_cnt;
+  uint32_t old_swap_time;          /* ms tick of the last sign change                              */
+  uint8_t  old_reminder;
+  uint8_t  accurate_swap_time;     /* 0..19                                                        */
+  uint8_t  accurate_swap_ok;
+  uint8_t  last_bit_pos_cnt;
+  uint8_t  last_bit_neg_cnt;
+  uint8_t  inv_polarity_flag;
+  uint8_t  opaque_[98];
 } gps_nav_data_t;
 typedef struct { double opaque_[2]; }  gps_obs_data_t;
 typedef struct { double opaque_[40]; } sdreph_t;
@@ -146,6 +166,30 @@ void gps_rewind_if_phase(gps_tracking_t *trk_channel, uint8_t steps);
 extern uint16_t tmp_prn_data[GPS_DATA_WORDS_CNT];
 extern uint16_t tmp_data_i[GPS_DATA_WORDS_CNT];
 extern uint16_t tmp_data_q[GPS_DATA_WORDS_CNT];
+
+/* --- the step-level entry points (PM/GPS/acquisition.h:7-12, PM/GPS/tracking.h:6) ------------------------------ */
+
+/* One acquisition step on one captured millisecond for the GPS_SAT_CNT-channel table: ONE GPU launch computes the
+ * (max, average, best phase) triplet every channel needs in its current state (frequency-search bin or code-phase
+ * window, PRN + Doppler hint honoured), then the reference's voting / histogram logic runs on the host. */
+void      acquisition_process(gps_ch_t *channel /* [GPS_SAT_CNT] */, uint8_t *data);
+uint32_t *acquisition_get_hist(void);
+void      acquisition_start_channel(gps_ch_t *channel);
+void      acquisition_start_code_search_channel(gps_ch_t *channel);
+void      acquisition_start_code_search3_channel(gps_ch_t *channel);
+/* One tracking step (pre-tracking or E/P/L + DLL/PLL/FLL) of one channel; index = 0..3, or 0xFF for the idle slot. */
+void      gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index);
+
+/* Link-time dependencies of the step logic, as in the reference.  libgpsx provides WEAK defaults that a host program
+ * overrides simply by defining the symbol:
+ *   signal_capture_get_packet_cnt  1 ms tick (PM/signal_capture.c:35); default: a counter set by gpsx_compat_set_packet_cnt
+ *   gps_nav_data_analyse_new_code  prompt-I hook (PM/GPS/nav_data.c:46-138); default: 20 ms bit-period synchronisation
+ *                                  and bit integration only, ending in gps_nav_data_words_detection
+ *   gps_nav_data_words_detection   word / preamble assembly (PM/GPS/nav_data.c:258-...): default no-op (out of scope) */
+uint32_t signal_capture_get_packet_cnt(void);
+void     gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t new_i);
+void     gps_nav_data_words_detection(gps_ch_t *channel, uint8_t new_bit);
+void     gpsx_compat_set_packet_cnt(uint32_t ticks_ms);
 
 /* not in the reference: release the default context (optional, for leak checkers) */
 void gpsx_compat_shutdown(void);

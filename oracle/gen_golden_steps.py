@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden_steps.py -- TEST INFRASTRUCTURE.  Records golden state traces of the reference's STEP logic
+(acquisition.c + tracking.c + nav_data.c, compiled in place into oracle/_ref/libref_steps.so together with
+oracle/ref_time_source.c, the one symbol those files expect from the MCU capture driver) driven in the firmware's own
+call order by tests/steps_driver.py on this repo's seeded synthetic IF stream.  Output: tests/golden/f7_steps_*.npz.
+Build container only."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import steps_driver as sd  # noqa: E402
+from golden_util import fnv1a32  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+from stm32f4_sdr_gps_amd import synth  # noqa: E402
+
+SCENARIOS = {
+    # name: (n_ms, prns, Doppler hints (0 = frequency search), stream function)
+    "hints": (3000, [5, 14, 20, 30], [900, 4000, -1000, 2000]),   # PM/main.c:59-73, the firmware's default table
+    "cold": (1800, [5, 14, 20, 30], [0, 4000, -1000, 2000]),      # channel 0 has no hint: full frequency search
+}
+
+
+def main():
+    pyoracle.build_ref()
+    for name, (n_ms, prns, hints) in SCENARIOS.items():
+        lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_steps.so"))
+        C.CDLL("libc.so.6").srand(1)
+        stream = synth.four_sv_with_nav(n_ms, seed=7)
+        snaps = sd.run_scenario(sd.StepsLib(lib, True), stream, prns, hints, n_ms)
+        path = os.path.join(ROOT, "tests", "golden", f"f7_steps_{name}.npz")
+        np.savez_compressed(path, snaps=snaps, prns=np.array(prns), hints=np.array(hints), n_ms=np.int32(n_ms),
+                            stream_fnv=np.uint32(fnv1a32(stream[::97])))
+        print(name, os.path.getsize(path), "bytes")
+        for r in sd.summarize(snaps):
+            print("  ", r)
+        del lib
+
+
+if __name__ == "__main__":
+    main()

@@ -30,28 +30,35 @@ uint16_t tmp_data_i[GPS_DATA_WORDS_CNT];
 uint16_t tmp_data_q[GPS_DATA_WORDS_CNT];
 }
 
+#include "gpsx_compat_internal.hpp"
+
 namespace {
 
 gpsx_ctx *g_ctx = nullptr;
 
-[[noreturn]] void die(const char *what, int rc)
+}  // namespace
+
+[[noreturn]] void gpsx_compat_die(const char *what, int rc)
 {
   std::fprintf(stderr, "libgpsx (compat): %s failed: %s (%s). The correlator runs on the GPU only; there is no CPU path.\n",
                what, gpsx_strerror(rc), g_ctx ? gpsx_last_error(g_ctx) : "no context");
   std::abort();
 }
 
-gpsx_ctx *ctx()
+gpsx_ctx *gpsx_compat_ctx()
 {
   if (!g_ctx) {
     const char *dev = std::getenv("GPSX_DEVICE");
     const int rc = gpsx_create(&g_ctx, dev ? std::atoi(dev) : 0, nullptr);
     if (rc != GPSX_OK)
-      die("gpsx_create", rc);
+      gpsx_compat_die("gpsx_create", rc);
   }
   return g_ctx;
 }
 
+namespace {
+inline gpsx_ctx *ctx() { return gpsx_compat_ctx(); }
+[[noreturn]] inline void die(const char *what, int rc) { gpsx_compat_die(what, rc); }
 }  // namespace
 
 extern "C" {

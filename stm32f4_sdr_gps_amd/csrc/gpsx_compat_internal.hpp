@@ -1,0 +1,7 @@
+// gpsx_compat_internal.hpp -- shared by the reference-named layers (gpsx_compat.cpp, gpsx_steps.cpp)
+#pragma once
+#include "../../include/gpsx.h"
+
+// the process-wide default context of the reference-named interface; aborts loudly if no GPU can be opened
+gpsx_ctx *gpsx_compat_ctx();
+[[noreturn]] void gpsx_compat_die(const char *what, int rc);

@@ -1,0 +1,702 @@
+// gpsx_steps.cpp -- the reference's step-level entry points on top of the batched engine ("Tier 2"):
+//   acquisition_process / acquisition_start_* / acquisition_get_hist      PM/GPS/acquisition.c, acquisition.h:7-12
+//   gps_tracking_process                                                   PM/GPS/tracking.c,    tracking.h:6
+// The data-parallel part of every step (replica, wipe-off, correlation, search) runs on the GPU through
+// gpsx_acq_jobs / gpsx_track_epl_batch / gpsx_rewind; what remains here is the reference's serial decision logic
+// (best-phase voting, histograms, DLL/PLL/FLL float loops), restated with its exact integer widths and float32
+// expression order so that channel state evolves identically (tests/test_gpu_steps.py replays golden traces).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/gpsx_compat.h"
+#include "gpsx_compat_internal.hpp"
+
+namespace {
+
+// gps_misc.h:16 defines M_PI as the float 3.1415926535f, but tracking.c includes <math.h> AFTER gps_misc.h, whose
+// double M_PI replaces it (the compiler's "M_PI redefined" warning): every pi in the tracking loops is a double and
+// the float operands around it are promoted, then the result is rounded back to float on assignment.
+constexpr double kPi = 3.14159265358979323846;
+constexpr int kBinLength = 10;                       // ACQ_SINGLE_FREQ_LENGTH, acquisition.c:18
+constexpr int kBinCapacity = 25;                     // FREQ_SEARCH_POINTS_MAX_CNT, acquisition.c:12
+constexpr uint32_t kCodeSearchTimeoutMs = 120000;    // acquisition.c:13
+constexpr int kStage2Width = 500, kStage3Width = 60; // acquisition.c:15-16
+constexpr int kPreTrackZone = 30;                    // tracking.c:17
+constexpr int kPreTrackStep = kPreTrackZone / TRACKING_CH_LENGTH;   // 7 correlations per ms
+constexpr int kFineRatio = 8;                        // tracking.c:23
+constexpr int kSnrLength = 200;                      // tracking.c:26
+constexpr int kPllBadThreshold = 80;                 // tracking.c:14
+constexpr int kFullRange = 2 * PRN_LENGTH;
+
+uint32_t g_ticks = 0;
+
+// frequency-search bookkeeping shared by all channels, exactly as the reference shares it (acquisition.c:28-33)
+uint32_t g_freq_votes[ACQ_COUNT];
+uint16_t g_bin_phases[kBinCapacity];
+uint8_t g_bin_count = 0;
+
+// pre-tracking running best of the current channel time slot (tracking.c:33-34)
+uint16_t g_slot_best_value = 0;
+uint16_t g_slot_best_phase = 0;
+
+void reset_search_buffers()
+{
+  std::memset(g_freq_votes, 0, sizeof g_freq_votes);
+  std::memset(g_bin_phases, 0, sizeof g_bin_phases);
+  g_bin_count = 0;
+}
+
+void clear_phase_histogram(gps_acq_t &a) { std::memset(a.code_phase_histogram, 0, ACQ_PHASE1_HIST_SIZE); }
+
+// narrowed code-phase window around the current estimate (acquisition.c:112-124,156-167)
+void narrow_window(gps_acq_t &a, int width)
+{
+  a.code_search_start = (uint16_t)(a.found_code_phase - width / 2);
+  a.code_search_stop = (uint16_t)(a.found_code_phase + width / 2);
+  if (a.code_search_start > kFullRange)   // unsigned wrap below zero
+    a.code_search_start = 0;
+  if (a.code_search_stop > kFullRange)
+    a.code_search_stop = kFullRange;
+  a.code_hist_step = (uint16_t)(width / ACQ_PHASE1_HIST_SIZE + 1);
+}
+
+// ---- frequency search: votes of one Doppler bin (acquisition.c:322-416) ----------------------------------------
+void vote_on_bin(gps_ch_t &ch, uint8_t count)
+{
+  std::sort(g_bin_phases, g_bin_phases + count);
+  uint8_t run = 0;
+  uint16_t longest = 0;
+  uint8_t tight = 0;   // some neighbours in the run were closer than 3 half-chips
+  for (uint8_t i = 1; i < count; i++) {
+    const int16_t gap = (int16_t)((int16_t)g_bin_phases[i] - (int16_t)g_bin_phases[i - 1]);
+    if (std::abs((int)gap) < 3)
+      tight = 1;
+    if (std::abs((int)gap) < 15) {
+      run++;
+    } else {
+      if (run > longest && tight)
+        longest = run;
+      run = 0;
+      tight = 0;
+    }
+  }
+  if (run > longest)
+    longest = run;
+  if (longest >= 2)
+    g_freq_votes[ch.acq_data.freq_index] += longest;
+}
+
+void judge_frequency_votes(gps_ch_t &ch)
+{
+  gps_acq_t &a = ch.acq_data;
+  uint8_t nonzero = 0, best_at = 0, best = 0;
+  for (uint8_t i = 0; i < ACQ_COUNT; i++) {
+    if (g_freq_votes[i] > 0)
+      nonzero++;
+    if (g_freq_votes[i] > best) {
+      best = (uint8_t)g_freq_votes[i];
+      best_at = i;
+    }
+  }
+  if (nonzero == 1 && best >= 3) {
+    a.state = GPS_ACQ_FREQ_SEARCH_DONE;
+    a.found_freq_offset_hz = (int16_t)(-ACQ_SEARCH_FREQ_HZ + best_at * ACQ_SEARCH_STEP_HZ);
+    a.hist_ratio = 10.0f;
+  } else if (nonzero > 1) {
+    float worst = 10.0;
+    for (uint8_t i = 0; i < ACQ_COUNT; i++) {
+      if (g_freq_votes[i] > 0 && i != best_at) {
+        const float r = (float)best / (float)g_freq_votes[i];
+        if (r < worst)
+          worst = r;
+      }
+    }
+    if (worst > 1.7f) {
+      a.hist_ratio = worst;
+      a.state = GPS_ACQ_FREQ_SEARCH_DONE;
+      a.found_freq_offset_hz = (int16_t)(-ACQ_SEARCH_FREQ_HZ + best_at * ACQ_SEARCH_STEP_HZ);
+    }
+  }
+  if (a.state == GPS_ACQ_FREQ_SEARCH_DONE)
+    std::printf("PRN=%d FINAL FREQ=%dHz\n", ch.prn, a.found_freq_offset_hz);
+}
+
+void after_frequency_search(gps_ch_t &ch, const gpsx_peak_t &pk)
+{
+  g_bin_phases[g_bin_count] = (uint16_t)pk.phase;
+  g_bin_count++;
+  if (g_bin_count >= kBinLength) {
+    vote_on_bin(ch, g_bin_count);
+    judge_frequency_votes(ch);
+    reset_search_buffers();
+    ch.acq_data.freq_index++;
+    if (ch.acq_data.freq_index >= ACQ_COUNT)
+      ch.acq_data.freq_index = 0;
+  }
+}
+
+// ---- code-phase search: histogram of best phases (acquisition.c:211-274) -----------------------------------------
+void after_code_phase_search(gps_ch_t &ch, const gpsx_peak_t &pk)
+{
+  gps_acq_t &a = ch.acq_data;
+  const uint16_t best_phase = (uint16_t)pk.phase;
+  if (best_phase < a.code_search_start || best_phase >= a.code_search_stop)
+    return;
+  const uint32_t waited = signal_capture_get_packet_cnt() - a.start_timestamp;
+  if (waited > kCodeSearchTimeoutMs) {
+    clear_phase_histogram(a);
+    a.start_timestamp = signal_capture_get_packet_cnt();
+  }
+  const uint8_t bin = (uint8_t)((best_phase - a.code_search_start) / a.code_hist_step);
+  if (bin < ACQ_PHASE1_HIST_SIZE)
+    a.code_phase_histogram[bin]++;
+
+  uint8_t top = 0, top_at = 0, populated = 0;
+  const uint16_t bins = (uint16_t)((a.code_search_stop + 2 - a.code_search_start) / a.code_hist_step);
+  for (uint8_t i = 0; i < bins; i++) {
+    if (a.code_phase_histogram[i] > top) {
+      top = a.code_phase_histogram[i];
+      top_at = i;
+    }
+    if (a.code_phase_histogram[i] > 0)
+      populated++;
+  }
+  if (top < 2)
+    return;
+  uint32_t sum = 0;
+  uint8_t cnt = 0;
+  for (uint8_t i = 0; i < ACQ_PHASE1_HIST_SIZE; i++) {
+    if (a.code_phase_histogram[i] > 0) {
+      sum += a.code_phase_histogram[i];
+      cnt++;
+    }
+  }
+  const float mean = (float)sum / (float)cnt;
+  if (mean < 0.01f)
+    return;
+  float ratio = (float)top / mean;
+  if (populated == 1 && top > 3)
+    ratio = 10.0f;
+  if (ratio > 3.2f) {
+    a.found_code_phase = (uint16_t)(a.code_search_start + top_at * a.code_hist_step);
+    if (a.state == GPS_ACQ_CODE_PHASE_SEARCH1)
+      a.state = GPS_ACQ_CODE_PHASE_SEARCH1_DONE;
+    if (a.state == GPS_ACQ_CODE_PHASE_SEARCH2)
+      a.state = GPS_ACQ_CODE_PHASE_SEARCH2_DONE;
+    if (a.state == GPS_ACQ_CODE_PHASE_SEARCH3)
+      a.state = GPS_ACQ_CODE_PHASE_SEARCH3_DONE;
+  }
+}
+
+bool in_code_phase_search(gps_acq_state_t s)
+{
+  return s == GPS_ACQ_CODE_PHASE_SEARCH1 || s == GPS_ACQ_CODE_PHASE_SEARCH2 || s == GPS_ACQ_CODE_PHASE_SEARCH3;
+}
+
+// ---- tracking loops (tracking.c:175-393) ------------------------------------------------------------------------
+void dll_update(gps_ch_t &ch, int16_t IE, int16_t QE, int16_t IL, int16_t QL)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  const int32_t e2 = (int32_t)IE * (int32_t)IE + (int32_t)QE * (int32_t)QE;
+  const int32_t l2 = (int32_t)IL * (int32_t)IL + (int32_t)QL * (int32_t)QL;
+  const int32_t diff = e2 - l2;
+  const int32_t total = e2 + l2;
+  float err = (float)diff / (float)total;
+  err = -err;
+  const float dt = 0.001f;
+  t.code_phase_fine += (TRACKING_DLL1_C1 * (err - t.dll_code_err) + TRACKING_DLL1_C2 * dt * err);
+
+  const float span = (float)(PRN_LENGTH * 2 * kFineRatio);
+  uint8_t wrapped = 0;
+  if (t.code_phase_fine < 0.0f) {
+    t.code_phase_fine = span - t.code_phase_fine;   // sic (tracking.c:356-361)
+    wrapped = 1;
+  } else if (t.code_phase_fine > span) {
+    t.code_phase_fine = t.code_phase_fine - span;
+    wrapped = 1;
+  }
+  if (wrapped) {
+    t.code_phase_fine_filt = -1.0f;
+  } else if (t.code_phase_fine_filt >= 0.0f) {
+    t.code_phase_fine_filt += t.code_phase_fine;
+    t.code_filt_cnt++;
+  }
+  t.dll_code_err = err;
+}
+
+void pll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  float phase_err;   // in units of pi
+  if (IP > 0)
+    phase_err = (float)((double)atan2f((float)QP, (float)IP) / kPi);
+  else  // the reference calls the double-precision atan2 here (tracking.c:184)
+    phase_err = (float)(atan2((double)(float)-QP, (double)(float)-IP) / kPi);
+  if (index != 0)
+    return;
+  float step = phase_err - t.pll_code_err;
+  if ((double)step > kPi / 2)
+    step = (float)(kPi - (double)step);
+  if ((double)step < -kPi / 2)
+    step = (float)(-kPi - (double)step);
+  const float dt = 0.001f;
+  if (ch.nav_data.period_sync_ok_flag)
+    t.if_freq_offset_hz -= TRACKING_PLL2_C1 * step + (TRACKING_PLL2_C2 * dt * phase_err);
+  else
+    t.if_freq_offset_hz -= TRACKING_PLL1_C1 * step + (TRACKING_PLL1_C2 * dt * phase_err);
+  t.pll_code_err = phase_err;
+}
+
+void false_lock_check(gps_ch_t &ch, uint8_t index, int16_t ip)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  if (index >= TRACKING_CH_LENGTH)
+    return;
+  t.pll_check_buf[index] = ip;
+  if (index < TRACKING_CH_LENGTH - 1)
+    return;
+  uint8_t flips = 0;
+  uint8_t prev = t.pll_check_buf[0] > 0 ? 1 : 0;
+  for (uint8_t i = 1; i < TRACKING_CH_LENGTH; i++) {
+    const uint8_t cur = t.pll_check_buf[i] > 0 ? 1 : 0;
+    if (cur != prev)
+      flips++;
+    prev = cur;
+  }
+  if (flips > 1) {
+    t.pll_bad_state_cnt++;
+    if (t.pll_bad_state_cnt > 10)
+      t.pll_bad_state_cnt = 10;
+  } else if (t.pll_bad_state_cnt > 0) {
+    t.pll_bad_state_cnt--;
+  }
+  if (t.pll_bad_state_cnt > 9)
+    t.pll_bad_state_master_cnt++;
+  else if (t.pll_bad_state_cnt == 0)
+    t.pll_bad_state_master_cnt = 0;
+
+  if (t.pll_bad_state_master_cnt > kPllBadThreshold) {
+    // false lock: jump to a random carrier offset around the acquired one (tracking.c:309-326)
+    t.pll_bad_state_master_cnt = 0;
+    t.pll_bad_state_cnt = 0;
+    int16_t delta = 0, candidate;
+    do {
+      const uint16_t r = (uint16_t)(std::rand() % ACQ_SEARCH_STEP_HZ);
+      candidate = (int16_t)(ch.acq_data.found_freq_offset_hz - r + (ACQ_SEARCH_STEP_HZ / 2));
+      delta = (int16_t)((int16_t)t.if_freq_offset_hz - candidate);
+    } while (std::abs((int)delta) < 200);
+    t.if_freq_offset_hz = (float)candidate;
+  }
+}
+
+void fll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  false_lock_check(ch, index, IP);
+  if (index == 0) {   // first ms after a channel swap: only remember
+    t.fll_old_i = IP;
+    t.fll_old_q = QP;
+    return;
+  }
+  const int16_t oldI = t.fll_old_i, oldQ = t.fll_old_q;
+  const float now = (IP == 0) ? (float)(kPi / 2) : atanf((float)QP / (float)IP);
+  const float before = (oldI == 0) ? (float)(kPi / 2) : atanf((float)oldQ / (float)oldI);
+  float rot = now - before;
+  if ((double)rot > kPi / 2)
+    rot = (float)(kPi - (double)rot);
+  if ((double)rot < -kPi / 2)
+    rot = (float)(-kPi - (double)rot);
+  float change = rot - t.fll_err;
+  if ((double)change > kPi / 2)
+    change = (float)(kPi - (double)change);
+  if ((double)change < -kPi / 2)
+    change = (float)(-kPi - (double)change);
+  const float dt = 0.001f;
+  const float hz = TRACKING_FLL1_C1 * dt * change + (TRACKING_FLL1_C2 * dt * rot);
+  t.if_freq_offset_hz -= hz;
+  t.fll_old_i = IP;
+  t.fll_old_q = QP;
+  t.fll_err = rot;
+}
+
+// ---- pre-tracking (tracking.c:398-499) ----------------------------------------------------------------------------
+void settle_pre_track(gps_ch_t &ch, uint8_t count)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  std::sort(t.pre_track_phases, t.pre_track_phases + count);
+  uint8_t run = 0;
+  uint16_t longest = 0, mode = 0;
+  for (uint8_t i = 1; i < count; i++) {
+    const uint16_t gap = (uint16_t)(t.pre_track_phases[i] - t.pre_track_phases[i - 1]);
+    if (std::abs((int)gap) < 1) {
+      run++;
+    } else {
+      if (run > longest) {
+        longest = run;
+        mode = t.pre_track_phases[i - 1];
+      }
+      run = 0;
+    }
+  }
+  if (run > longest) {
+    longest = run;
+    mode = t.pre_track_phases[count - 1];
+  }
+  if (mode) {
+    t.code_phase_fine = (float)(mode * kFineRatio);
+    t.state = GPS_PRE_TRACK_DONE;
+  }
+}
+
+void pre_track_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  if (index >= TRACKING_CH_LENGTH)
+    return;
+  const uint16_t first = (uint16_t)(t.code_search_start + index * kPreTrackStep);
+  uint16_t last = (uint16_t)(first + kPreTrackStep);
+  if (last > kFullRange)
+    last = kFullRange;
+  if (first < last) {
+    // K2 + K3 + 7 x gps_correlation8 in one launch; the window's first maximum competes with the slot's running best
+    gpsx_acq_job_t job;
+    job.block = 0;
+    job.n_ms = 1;
+    job.prn = ch.prn;
+    job.freq_hz = (float)IF_FREQ_HZ + t.if_freq_offset_hz;
+    job.offset_bits = 0;
+    job.win_start = first;
+    job.win_stop = last;
+    gpsx_peak_t pk;
+    const int rc = gpsx_acq_jobs(gpsx_compat_ctx(), &job, 1, data, 1, &pk, nullptr);
+    if (rc != GPSX_OK)
+      gpsx_compat_die("gps_tracking_process(pre-track)", rc);
+    if ((int16_t)pk.max_val > (int)g_slot_best_value) {
+      g_slot_best_value = (uint16_t)pk.max_val;
+      g_slot_best_phase = (uint16_t)pk.phase;
+    }
+  }
+  if (index == TRACKING_CH_LENGTH - 1) {   // end of this channel's time slot
+    t.pre_track_phases[t.pre_track_count] = g_slot_best_phase;
+    t.pre_track_count++;
+    if (t.pre_track_count > PRE_TRACK_POINTS_MAX_CNT - 10)
+      settle_pre_track(ch, t.pre_track_count);
+    if (t.pre_track_count >= PRE_TRACK_POINTS_MAX_CNT) {
+      t.pre_track_count = 0;
+      std::memset(t.pre_track_phases, 0, PRE_TRACK_POINTS_MAX_CNT * 2);
+    }
+    g_slot_best_value = 0;
+  }
+}
+
+// ---- tracking step (tracking.c:92-170) ------------------------------------------------------------------------------
+void tracking_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  const uint32_t now = signal_capture_get_packet_cnt();
+  if (index >= TRACKING_CH_LENGTH)
+    return;
+  uint32_t elapsed = now - t.prev_track_timestamp;
+  t.prev_track_timestamp = now;
+  if (elapsed > 50)
+    elapsed = 1;
+  if (elapsed != 1)
+    gps_rewind_if_phase(&t, (uint8_t)(elapsed - 1));   // the carrier NCO kept running while other channels were served
+
+  gpsx_trk_state_t st;
+  st.prn = ch.prn;
+  st.code_phase_fine = t.code_phase_fine;
+  st.if_freq_offset_hz = t.if_freq_offset_hz;
+  st.if_freq_accum = t.if_freq_accum;
+  int16_t iq[6];
+  const int rc = gpsx_track_epl_batch(gpsx_compat_ctx(), data, &st, 1, iq);   // K2 + K3 + K5
+  if (rc != GPSX_OK)
+    gpsx_compat_die("gps_tracking_process", rc);
+  t.if_freq_accum = st.if_freq_accum;
+  const int16_t IE = iq[0], QE = iq[1], IP = iq[2], QP = iq[3], IL = iq[4], QL = iq[5];
+
+  dll_update(ch, IE, QE, IL, QL);
+  pll_update(ch, index, IP, QP);
+  fll_update(ch, index, IP, QP);
+  gps_nav_data_analyse_new_code(&ch, index, IP);
+
+  t.i_part_summ += (uint32_t)std::abs((int)IP);
+  t.q_part_summ += (uint32_t)std::abs((int)QP);
+  t.snr_summ_cnt++;
+  if (t.snr_summ_cnt > kSnrLength) {
+    if (t.q_part_summ == 0) {
+      t.snr_value = 1.0f;
+      return;   // sic: the sums are not cleared on this path (tracking.c:152-156)
+    }
+    const float ratio = (float)t.i_part_summ / (float)t.q_part_summ;
+    t.snr_value = 10.0f * log10f(ratio);
+    t.snr_summ_cnt = 0;
+    t.i_part_summ = 0;
+    t.q_part_summ = 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- link-time hooks with weak defaults ---------------------------------------------------------------------------
+void gpsx_compat_set_packet_cnt(uint32_t ticks_ms) { g_ticks = ticks_ms; }
+
+__attribute__((weak)) uint32_t signal_capture_get_packet_cnt(void) { return g_ticks; }
+
+__attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *, uint8_t) {}
+
+// Default prompt-I hook: 20 ms bit-period synchronisation and bit integration (PM/GPS/nav_data.c:46-250), without the
+// word / subframe layer.  A host that links the reference's nav_data.c overrides it.
+namespace {
+uint32_t g_slot_start_ticks = 0;
+int16_t g_slot_ip[TRACKING_CH_LENGTH];
+uint8_t g_slot_bits[TRACKING_CH_LENGTH];
+
+void refine_bit_edge(gps_ch_t *ch, const int16_t *ip)   // nav_data.c:145-218
+{
+  uint8_t edge = 0;
+  if (std::abs((int)ip[1]) > std::abs((int)ip[0]))
+    return;
+  if (ip[3] == 0)
+    return;
+  const float whole = (float)std::abs((int)ip[0]) / (float)std::abs((int)ip[3]);
+  if (whole > 1.5f || whole < 0.7f)
+    return;
+  const int16_t chip = (int16_t)((int16_t)ch->tracking_data.code_phase_fine / 16);
+  if (chip < 0 || chip > PRN_LENGTH)
+    return;
+  if (chip < PRN_LENGTH / 4 || chip > PRN_LENGTH * 3 / 4) {
+    if (ip[1] == 0)
+      return;
+    const float jump = (float)std::abs((int)ip[0]) / (float)std::abs((int)ip[1]);
+    if (jump > 1.5f || jump < 0.7f)
+      return;
+    edge = chip < PRN_LENGTH / 4 ? 2 : 1;
+  } else {
+    const uint16_t d1 = (uint16_t)std::abs(ip[0] - ip[1]);
+    const uint16_t d2 = (uint16_t)std::abs(ip[2] - ip[3]);
+    if (d1 > d2) {
+      if (d2 == 0)
+        return;
+      if ((float)d1 / (float)d2 < 2.5f)
+        return;
+      edge = 1;
+    } else {
+      if (d1 == 0)
+        return;
+      if ((float)d2 / (float)d1 < 2.5f)
+        return;
+      edge = 2;
+    }
+  }
+  if (edge == 0)
+    return;
+  ch->nav_data.accurate_swap_time = (uint8_t)((g_slot_start_ticks + edge) % 20);
+  ch->nav_data.accurate_swap_ok = 1;
+}
+
+void integrate_bit(gps_ch_t *ch, uint8_t ms_bit, uint32_t now)   // nav_data.c:223-253
+{
+  gps_nav_data_t &n = ch->nav_data;
+  const uint32_t since = now - n.old_swap_time;
+  const uint8_t rem = (uint8_t)(since % 20);
+  if (rem < n.old_reminder) {
+    const uint8_t bit = n.last_bit_pos_cnt > n.last_bit_neg_cnt ? 1 : 0;
+    gps_nav_data_words_detection(ch, bit);
+    n.last_bit_pos_cnt = 0;
+    n.last_bit_neg_cnt = 0;
+  }
+  if (ms_bit)
+    n.last_bit_pos_cnt++;
+  else
+    n.last_bit_neg_cnt++;
+  n.old_reminder = rem;
+}
+}  // namespace
+
+__attribute__((weak)) void gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t new_i)
+{
+  if (index >= TRACKING_CH_LENGTH)
+    return;
+  gps_nav_data_t &n = channel->nav_data;
+  uint8_t bit = new_i > 0 ? 1 : 0;
+  if (n.inv_polarity_flag)
+    bit ^= 1;
+  g_slot_bits[index] = bit;
+  g_slot_ip[index] = new_i;
+  const uint32_t now = signal_capture_get_packet_cnt();
+  if (index == 0)
+    g_slot_start_ticks = now;
+  if (n.period_sync_ok_flag == 1)
+    integrate_bit(channel, bit, now);
+  if (index < TRACKING_CH_LENGTH - 1)
+    return;
+
+  uint8_t flips = 0, flip_at = 0, prev = g_slot_bits[0];
+  for (uint8_t i = 1; i < TRACKING_CH_LENGTH; i++) {
+    if (g_slot_bits[i] != prev) {
+      flips++;
+      flip_at = i;
+    }
+    prev = g_slot_bits[i];
+  }
+  if (flips != 1)
+    return;
+  const uint32_t edge_time = g_slot_start_ticks + flip_at;
+  const uint8_t rem = (uint8_t)((edge_time - n.old_swap_time) % 20);
+  if (rem < 2 || rem == 19) {
+    if (n.right_period_cnt < 10)
+      n.right_period_cnt++;
+    if (n.right_period_cnt > 8)
+      n.period_sync_ok_flag = 1;
+  } else {
+    if (n.right_period_cnt > 0)
+      n.right_period_cnt--;
+    if (n.right_period_cnt < 3)
+      n.period_sync_ok_flag = 0;
+  }
+  n.old_swap_time = edge_time;
+  if (n.period_sync_ok_flag && flip_at == 2)
+    refine_bit_edge(channel, g_slot_ip);
+}
+
+// ---- acquisition.h ----------------------------------------------------------------------------------------------------
+uint32_t *acquisition_get_hist(void) { return g_freq_votes; }
+
+void acquisition_start_channel(gps_ch_t *channel)
+{
+  gps_acq_t &a = channel->acq_data;
+  if (a.state != GPS_ACQ_NEED_FREQ_SEARCH)
+    return;
+  if (a.given_freq_offset_hz != 0) {   // Doppler hint: no frequency search (acquisition.c:72-79)
+    a.found_freq_offset_hz = a.given_freq_offset_hz;
+    a.state = GPS_ACQ_FREQ_SEARCH_DONE;
+    return;
+  }
+  reset_search_buffers();
+  a.freq_index = 0;
+  a.state = GPS_ACQ_FREQ_SEARCH_RUN;
+}
+
+void acquisition_start_code_search_channel(gps_ch_t *channel)
+{
+  gps_acq_t &a = channel->acq_data;
+  if (a.state != GPS_ACQ_FREQ_SEARCH_DONE)
+    return;
+  clear_phase_histogram(a);
+  a.code_search_start = 0;
+  a.code_search_stop = kFullRange;
+  a.code_hist_step = 64;   // ACQ_PHASE1_HIST_STEP
+  a.start_timestamp = signal_capture_get_packet_cnt();
+  a.state = GPS_ACQ_CODE_PHASE_SEARCH1;
+}
+
+void acquisition_start_code_search3_channel(gps_ch_t *channel)
+{
+  gps_acq_t &a = channel->acq_data;
+  if (a.state != GPS_ACQ_CODE_PHASE_SEARCH2_DONE)
+    return;
+  clear_phase_histogram(a);
+  narrow_window(a, kStage3Width);
+  reset_search_buffers();
+  a.start_timestamp = signal_capture_get_packet_cnt();
+  a.state = GPS_ACQ_CODE_PHASE_SEARCH3;
+}
+
+void acquisition_process(gps_ch_t *channel, uint8_t *data)
+{
+  // Every channel's search parameters depend only on its own state on entry, so all searches of this millisecond go
+  // out as one job list; the serial logic then consumes the triplets in channel order, as the reference's loop does.
+  gpsx_acq_job_t jobs[GPS_SAT_CNT];
+  int job_of[GPS_SAT_CNT];
+  int n_jobs = 0;
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    job_of[i] = -1;
+    const gps_acq_t &a = channel[i].acq_data;
+    if (channel[i].prn < 1 || a.state == GPS_ACQ_DONE)
+      continue;
+    gpsx_acq_job_t j;
+    j.block = 0;
+    j.n_ms = 1;
+    j.prn = channel[i].prn;
+    j.offset_bits = 0;
+    if (a.state == GPS_ACQ_FREQ_SEARCH_RUN) {
+      const int16_t hz = (int16_t)(-ACQ_SEARCH_FREQ_HZ + a.freq_index * ACQ_SEARCH_STEP_HZ);
+      j.freq_hz = (float)(IF_FREQ_HZ + hz);
+      j.win_start = 0;
+      j.win_stop = kFullRange;
+    } else if (in_code_phase_search(a.state)) {
+      j.freq_hz = (float)(IF_FREQ_HZ + a.found_freq_offset_hz);
+      j.win_start = a.code_search_start;
+      j.win_stop = a.code_search_stop > kFullRange ? kFullRange : a.code_search_stop;
+      if (j.win_start > j.win_stop)
+        j.win_start = j.win_stop;
+    } else {
+      continue;
+    }
+    job_of[i] = n_jobs;
+    jobs[n_jobs++] = j;
+  }
+  gpsx_peak_t peaks[GPS_SAT_CNT];
+  if (n_jobs > 0) {
+    const int rc = gpsx_acq_jobs(gpsx_compat_ctx(), jobs, n_jobs, data, 1, peaks, nullptr);
+    if (rc != GPSX_OK)
+      gpsx_compat_die("acquisition_process", rc);
+  }
+
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    gps_ch_t &ch = channel[i];
+    gps_acq_t &a = ch.acq_data;
+    if (ch.prn < 1 || a.state == GPS_ACQ_DONE)
+      continue;
+    if (a.state == GPS_ACQ_FREQ_SEARCH_RUN) {
+      after_frequency_search(ch, peaks[job_of[i]]);
+      continue;
+    }
+    if (a.state == GPS_ACQ_CODE_PHASE_SEARCH1_DONE) {   // open stage 2 around the stage-1 estimate
+      clear_phase_histogram(a);
+      narrow_window(a, kStage2Width);
+      reset_search_buffers();
+      a.start_timestamp = signal_capture_get_packet_cnt();
+      a.state = GPS_ACQ_CODE_PHASE_SEARCH2;
+      continue;
+    }
+    if (a.state == GPS_ACQ_CODE_PHASE_SEARCH3_DONE) {
+      a.state = GPS_ACQ_DONE;
+      continue;
+    }
+    if (in_code_phase_search(a.state) && job_of[i] >= 0)
+      after_code_phase_search(ch, peaks[job_of[i]]);
+  }
+}
+
+// ---- tracking.h ---------------------------------------------------------------------------------------------------------
+void gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index)
+{
+  gps_tracking_t &t = channel->tracking_data;
+  if (t.state == GPS_NEED_PRE_TRACK) {   // load the acquisition result (tracking.c:52-72)
+    t.code_search_start = (uint16_t)(channel->acq_data.found_code_phase - kPreTrackZone / 2);
+    t.code_search_stop = (uint16_t)(channel->acq_data.found_code_phase + kPreTrackZone / 2);
+    if (t.code_search_start > kFullRange)
+      t.code_search_start = 0;
+    if (t.code_search_stop > kFullRange)
+      t.code_search_stop = kFullRange;
+    t.if_freq_offset_hz = (float)channel->acq_data.found_freq_offset_hz;
+    t.pre_track_count = 0;
+    std::memset(t.pre_track_phases, 0, PRE_TRACK_POINTS_MAX_CNT * 2);
+    t.state = GPS_PRE_TRACK_RUN;
+  }
+  if (t.state == GPS_PRE_TRACK_RUN)
+    pre_track_step(*channel, data, index);
+  else if (t.state == GPS_PRE_TRACK_DONE)
+    t.state = GPS_TRACKING_RUN;
+  if (t.state == GPS_TRACKING_RUN)
+    tracking_step(*channel, data, index);
+}
+
+}  // extern "C"

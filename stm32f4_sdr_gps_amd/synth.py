@@ -84,6 +84,16 @@ def default_four_sv(n_ms: int, seed: int = 7) -> np.ndarray:
     return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
 
 
+def four_sv_with_nav(n_ms: int, seed: int = 7) -> np.ndarray:
+    """The 4-SV table with 50 bit/s navigation data on every satellite (random bits, different per satellite), for the
+    step-level tests: exercises the 20 ms bit synchronisation and the PLL's second gain set."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    bits = [1.0 - 2.0 * rng.integers(0, 2, 400).astype(np.float64) for _ in range(4)]
+    sats = [Sat(5, 912.5, 1600.0, 0.6, 0.3, bits[0]), Sat(14, 4037.0, 4000.0, 0.6, 1.1, bits[1]),
+            Sat(20, -1025.0, 9000.0, 0.6, 2.5, bits[2]), Sat(30, 2018.0, 13000.0, 0.6, 4.0, bits[3])]
+    return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+
+
 def cold_start_block(n_ms: int = 1, seed: int = 11) -> np.ndarray:
     """Config 3/4 input: six satellites in view."""
     sats = [Sat(3, -3210.0, 777.0, 0.5, 0.7), Sat(5, 912.5, 1600.0, 0.6, 0.3), Sat(11, 4480.0, 12001.0, 0.5, 5.1),

@@ -1,0 +1,150 @@
+"""Shared driver for the step-level (Tier 2) tests: runs the reference's call order (PM/main.c:86-168 main loop and the
+channel sequencing of PM/GPS/gps_master.c:68-129) against ANY library exporting the step API -- the reference's own
+acquisition.c/tracking.c built into oracle/_ref/libref_steps.so (to record golden traces, build container only) or
+libgpsx.so (on the GPU box) -- and records every channel's state after every millisecond.
+
+The driver owns the 1 ms clock: `oracle_ref_packet_cnt` (oracle/ref_time_source.c) for the reference build,
+gpsx_compat_set_packet_cnt() for libgpsx.
+"""
+import ctypes as C
+
+import numpy as np
+
+CH_SIZE = 1688          # sizeof(gps_ch_t) on LP64 (tests/test_abi_and_host.py checks the layout against the reference)
+N_CH = 4
+SNAP = 226              # acq_data (60) + tracking_data (152) + first 14 bytes of nav_data
+
+ACQ_DTYPE = np.dtype({"names": ["freq_index", "found_freq_offset_hz", "given_freq_offset_hz", "found_code_phase",
+                                "code_search_start", "code_search_stop", "code_hist_step", "state", "hist",
+                                "start_timestamp", "hist_ratio"],
+                      "formats": ["u1", "<i2", "<i2", "<u2", "<u2", "<u2", "<u2", "<i4", ("u1", 32), "<u4", "<f4"],
+                      "offsets": [0, 2, 4, 6, 8, 10, 12, 16, 20, 52, 56], "itemsize": 60})
+TRK_FIELDS = {"if_freq_offset_hz": (4, "<f4"), "if_freq_accum": (8, "<u4"), "pre_track_count": (72, "u1"),
+              "code_phase_fine": (80, "<f4"), "snr_value": (132, "<f4"), "state": (148, "<i4")}
+
+ACQ_DONE = 9
+TRK_IDLE, TRK_NEED_PRE, TRK_PRE_RUN, TRK_PRE_DONE, TRK_RUN = 0, 1, 2, 3, 4
+
+
+class StepsLib:
+    def __init__(self, lib: C.CDLL, is_reference: bool):
+        self.lib = lib
+        self.is_reference = is_reference
+        for name in ("acquisition_start_channel", "acquisition_start_code_search_channel",
+                     "acquisition_start_code_search3_channel", "gps_channell_prepare"):
+            getattr(lib, name).argtypes = [C.c_void_p]
+            getattr(lib, name).restype = None
+        lib.acquisition_process.argtypes = [C.c_void_p, C.c_void_p]
+        lib.acquisition_process.restype = None
+        lib.gps_tracking_process.argtypes = [C.c_void_p, C.c_void_p, C.c_uint8]
+        lib.gps_tracking_process.restype = None
+        if is_reference:
+            lib.gps_fill_summ_table()
+            self._clock = C.c_uint32.in_dll(lib, "oracle_ref_packet_cnt")
+        else:
+            lib.gpsx_compat_set_packet_cnt.argtypes = [C.c_uint32]
+
+    def set_time(self, t: int):
+        if self.is_reference:
+            self._clock.value = t
+        else:
+            self.lib.gpsx_compat_set_packet_cnt(t)
+
+
+def _acq(table, i):
+    return table[i, :60].view(ACQ_DTYPE)[0]
+
+
+def _trk_get(table, i, name):
+    off, fmt = TRK_FIELDS[name]
+    return table[i, 60 + off:60 + off + np.dtype(fmt).itemsize].view(fmt)[0]
+
+
+def _trk_set(table, i, name, value):
+    off, fmt = TRK_FIELDS[name]
+    table[i, 60 + off:60 + off + np.dtype(fmt).itemsize] = np.frombuffer(np.array([value], fmt).tobytes(), np.uint8)
+
+
+def snapshot(table):
+    out = np.zeros((N_CH, SNAP), np.uint8)
+    out[:, :212] = table[:, :212]
+    out[:, 212:226] = table[:, 212:226]
+    return out
+
+
+def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int):
+    """Cold boot exactly as PM/main.c does: memset the table, set PRN + Doppler hint, gps_channell_prepare, then the main
+    loop: acquisition (one captured block per call) until every channel is GPS_ACQ_DONE, then 17-slot multiplexed
+    tracking.  Returns uint8 snapshots [n_ms, 4, 226] taken after each millisecond's calls."""
+    lib = steps.lib
+    table = np.zeros((N_CH, CH_SIZE), np.uint8)
+    for i in range(N_CH):
+        table[i, 664] = prns[i]
+        table[i, 4:6] = np.frombuffer(np.int16(hints_hz[i]).tobytes(), np.uint8)
+        lib.gps_channell_prepare(table[i].ctypes.data)
+    base = table.ctypes.data
+
+    def ch_ptr(i):
+        return base + i * CH_SIZE
+
+    start_flag = [True]
+
+    def master(index):
+        # PM/GPS/gps_master.c:68-129 without UI / nav / PVT
+        if start_flag[0]:
+            start_flag[0] = False
+            lib.acquisition_start_channel(ch_ptr(0))
+        states = [int(_acq(table, i)["state"]) for i in range(N_CH)]
+        need_acq = any(s != ACQ_DONE for s in states)
+        need_f = any(s < 2 for s in states)
+        stage3_ready = sum(s == 6 for s in states)
+        if need_acq:
+            for i in range(N_CH - 1):
+                if states[i] == 2 and states[i + 1] == 0:
+                    lib.acquisition_start_channel(ch_ptr(i + 1))
+                    return need_acq
+        if (not need_f) and need_acq:
+            for i in range(N_CH):
+                if int(_acq(table, i)["state"]) == 2:
+                    lib.acquisition_start_code_search_channel(ch_ptr(i))
+                if stage3_ready == N_CH:
+                    lib.acquisition_start_code_search3_channel(ch_ptr(i))
+        if not need_acq:
+            for i in range(N_CH):
+                if int(_trk_get(table, i, "state")) == TRK_IDLE:
+                    _trk_set(table, i, "state", TRK_NEED_PRE)
+        return need_acq
+
+    snaps = np.zeros((n_ms, N_CH, SNAP), np.uint8)
+    steps.set_time(0)
+    need_acq = master(0)
+    for t in range(n_ms):
+        steps.set_time(t)
+        blk = np.ascontiguousarray(stream[t])
+        if need_acq:
+            lib.acquisition_process(base, blk.ctypes.data)      # main_process_acq_data, PM/main.c:163-168
+            need_acq = master(0)
+        else:
+            big = t % (4 * N_CH + 1)                               # main_fast_data_proc, PM/main.c:134-158
+            sat = big // 4
+            if sat >= N_CH:
+                sat = 0
+            index = 0xFF if big == 4 * N_CH else big % 4
+            lib.gps_tracking_process(ch_ptr(sat), blk.ctypes.data, index)
+            need_acq = master(index)
+        snaps[t] = snapshot(table)
+    return snaps
+
+
+def summarize(snaps):
+    """Human-readable end state of each channel."""
+    rows = []
+    last = snaps[-1]
+    for i in range(N_CH):
+        a = last[i, :60].view(ACQ_DTYPE)[0]
+        t = last[i, 60:212]
+        rows.append(dict(acq_state=int(a["state"]), found_code_phase=int(a["found_code_phase"]),
+                         found_freq=int(a["found_freq_offset_hz"]), trk_state=int(t[148:152].view("<i4")[0]),
+                         code_phase_fine=float(t[80:84].view("<f4")[0]), freq=float(t[4:8].view("<f4")[0]),
+                         snr=float(t[132:136].view("<f4")[0]), bit_sync=int(last[i, 212])))
+    return rows

@@ -20,7 +20,7 @@ def lib_path():
 def _declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = set(re.findall(r"\b(gpsx_\w+|gps_\w+|correlation_search)\s*\(", text))
+    names = set(re.findall(r"\b(gpsx_\w+|gps_\w+|correlation_search|acquisition_\w+|signal_capture_\w+)\s*\(", text))
     return {n for n in names if not n.endswith("_t")}
 
 
