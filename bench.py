@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--searches", type=int, default=16, help="1 ms captures per GPU per step")
+    ap.add_argument("--amp-scale", type=float, default=1.0,
+                    help="scale of the six synthetic satellites' amplitudes (1.0 = strong test signal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -139,7 +141,7 @@ def main():
 
     n_search = args.searches * world
     # synthetic captures: consecutive milliseconds of one stream; identical on every rank (each rank reads all of it)
-    blocks = synth.cold_start_block(n_search, seed=11)
+    blocks = synth.cold_start_block(n_search, seed=11, amp_scale=args.amp_scale)
     prns = np.arange(1, N_PRN + 1, dtype=np.uint8)
     g = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
                       dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046),
@@ -202,7 +204,7 @@ def main():
     # sanity outside the timed region: the merged key table must hold the six synthetic satellites' peaks
     keys = d_keys.cpu().numpy()
     energy = keys >> 14
-    assert (energy > 0).all() and energy.max() > 1500, "acquisition grid produced no peaks"
+    assert (energy > 0).all() and energy.max() > 1500 * min(1.0, args.amp_scale), "acquisition grid produced no peaks"
 
     if rank == 0:
         total_hyp = float(args.steps) * n_search * HYP_PER_SEARCH

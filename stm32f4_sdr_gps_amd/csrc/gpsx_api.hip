@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -24,6 +25,8 @@ struct gpsx_ctx {
   uint8_t *d_chips_all = nullptr;    // [211][1024]
   uint32_t *d_bits_all = nullptr;    // [211][32]
   uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
+  uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
+  int algo = kAlgoDot8;              // $GPSX_ACQ_ALGO=sad selects the byte-SAD main loop (A/B measurements)
 
   // grouped tables for the PRN list of the last grid call
   std::vector<uint8_t> grid_prns;
@@ -32,6 +35,7 @@ struct gpsx_ctx {
   uint8_t *d_grid_chips = nullptr;
   uint32_t *d_grid_bits = nullptr;
   uint32_t *d_grid_cw = nullptr;
+  uint32_t *d_grid_cw8 = nullptr;
 
   // grow-only scratch arena for the host-pointer entry points
   char *d_arena = nullptr;
@@ -111,12 +115,14 @@ int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
       (void)hipFree(ctx->d_grid_chips);
       (void)hipFree(ctx->d_grid_bits);
       (void)hipFree(ctx->d_grid_cw);
+      (void)hipFree(ctx->d_grid_cw8);
     }
     ctx->grid_slots = 0;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_prns, slots));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_chips, (size_t)slots * 1024));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_bits, (size_t)slots * 32 * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_cw, (size_t)slots * kCodeWords * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_cw8, (size_t)slots * (kCodeWords / 2) * 4));
     ctx->grid_slots = slots;
   }
   std::vector<uint8_t> padded(slots, 0);
@@ -124,7 +130,7 @@ int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_grid_prns, padded.data(), slots, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // `padded` goes out of scope
   launch_build_codes(ctx->stream, ctx->d_grid_prns, slots, kAcqGroup, ctx->d_grid_chips, ctx->d_grid_bits,
-                     ctx->d_grid_cw);
+                     ctx->d_grid_cw, ctx->d_grid_cw8);
   LAUNCHCHK(ctx, "k_build_codes");
   ctx->grid_prns.assign(prns, prns + n_prn);
   return GPSX_OK;
@@ -201,6 +207,8 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     delete ctx;
     return GPSX_ENODEV;
   }
+  if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
+    ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad : kAlgoDot8;
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -220,9 +228,10 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
             hipMalloc((void **)&ctx->d_chips_all, (size_t)slots * 1024) == hipSuccess &&
             hipMalloc((void **)&ctx->d_bits_all, (size_t)slots * 32 * 4) == hipSuccess &&
             hipMalloc((void **)&ctx->d_cw_all, (size_t)slots * kCodeWords * 4) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_cw8_all, (size_t)slots * (kCodeWords / 2) * 4) == hipSuccess &&
             hipMemcpyAsync(d_prns, prns.data(), slots, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
   if (ok) {
-    launch_build_codes(ctx->stream, d_prns, slots, 1, ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all);
+    launch_build_codes(ctx->stream, d_prns, slots, 1, ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
   }
   if (d_prns)
@@ -243,8 +252,8 @@ void gpsx_destroy(gpsx_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
-  void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_grid_prns, ctx->d_grid_chips,
-                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_arena};
+  void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
@@ -410,8 +419,9 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.per_ms = d_per_ms;
   prm.energy = d_energy;
   prm.cnt = d_cnt;
-  launch_acq(ctx->stream, kAcqGroup, (int)(local_units * n_bits), prm, static_cast<const uint8_t *>(d_if_blocks),
-             ctx->d_grid_cw, ctx->d_grid_bits);
+  launch_acq(ctx->stream, kAcqGroup, ctx->algo, (int)(local_units * n_bits), prm,
+             static_cast<const uint8_t *>(d_if_blocks), ctx->algo == kAlgoDot8 ? ctx->d_grid_cw8 : ctx->d_grid_cw,
+             ctx->d_grid_bits);
   LAUNCHCHK(ctx, "k_acq");
   if (d_keys) {
     launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
@@ -488,7 +498,8 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
   prm.jobs = d_jobs;
   prm.peaks = d_peaks;
   prm.energy = d_energy;
-  launch_acq(ctx->stream, 1, n_jobs, prm, d_if, ctx->d_cw_all, ctx->d_bits_all);
+  launch_acq(ctx->stream, 1, ctx->algo, n_jobs, prm, d_if, ctx->algo == kAlgoDot8 ? ctx->d_cw8_all : ctx->d_cw_all,
+             ctx->d_bits_all);
   LAUNCHCHK(ctx, "k_acq(jobs)");
   HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_jobs * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
   if (energy_opt)

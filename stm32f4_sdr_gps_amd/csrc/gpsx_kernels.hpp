@@ -11,6 +11,8 @@ namespace gpsx {
 constexpr int kAcqGroup = 8;      // PRNs sharing one workgroup's wiped data in the grid kernel
 constexpr int kCodeWords = 256;   // 4-chip code words per PRN (1023 chips + 1 masked pad)
 constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window sum inside 32 bits
+constexpr int kAlgoSad = 0;       // main loop: v_msad_u8 on 8-bit block sums, 4 chips per instruction
+constexpr int kAlgoDot8 = 1;      // main loop: v_dot8_u32_u4 on 4-bit block sums, 8 chips per instruction (default)
 
 // One search = one workgroup pass: `count` (<= group size) consecutive code-table slots, one carrier frequency,
 // one replica bit shift, n_ms consecutive blocks.
@@ -44,11 +46,13 @@ struct AcqParams {
 //   chips    [n_slots][1024]  0/1 bytes
 //   chipbits [n_slots][32]    packed, bit (i & 31) of word (i >> 5) = chip i
 //   cw       [n_slots/group][256][group]  4 chips per word as SAD reference bytes: 17 (chip 1), 1 (chip 0), 0 (pad)
+//   cw8      [n_slots/group][128][group]  8 chips per word as 0/1 nibbles (pad chip 1023 = 0)
 void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int group, uint8_t *d_chips,
-                        uint32_t *d_chipbits, uint32_t *d_cw);
+                        uint32_t *d_chipbits, uint32_t *d_cw, uint32_t *d_cw8);
 
 // K2+K3+K4 fused acquisition search.  group = kAcqGroup (grid) or 1 (job list).
-void launch_acq(hipStream_t s, int group, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
+// d_cw is the table matching `algo` (cw for kAlgoSad, cw8 for kAlgoDot8).
+void launch_acq(hipStream_t s, int group, int algo, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits);
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,

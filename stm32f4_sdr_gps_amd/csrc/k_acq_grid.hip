@@ -21,6 +21,14 @@
 // Work split: 256 lanes; lane l owns chip offsets q = 4l .. 4l+3 (byte offsets o = 2q + t0/8) for G PRNs and both
 // I and Q: 4 x G x 2 accumulators.  Per 4-chip step j it reads one new dword of S' per stream from LDS, forms the
 // three unaligned windows with v_alignbyte_b32 and issues 8 G SADs against G wave-uniform code words (SGPRs).
+//
+// ALGO_DOT8 (default) halves the main loop again: with 0/1 code nibbles,
+//       C0(16 q + t0) = pop(D) + 8192 - 2 M,     M = sum_c chip[c] * S_t0[q + c]
+//   and v_dot8_u32_u4 multiplies EIGHT 4-bit block sums by eight chips per instruction.  A block sum is 0..16; the one
+//   value that does not fit a nibble (16 = a window of sixteen ones) is stored as 15 and its deficit restored exactly
+//   by E = sum_c chip[c] * F[q + c] over the bit plane F of saturated windows -- an AND + popcount pass that only runs
+//   for the (t0, I/Q) arrays that contain such a window at all (2^-16 per window on noise-like data; dense on clean
+//   synthetic carriers, where the pass costs about half of the dot loop).
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
 
@@ -30,12 +38,17 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kSDwords = 520;  // S' arrays: 2046 + pad bytes, doubled circular copy, as dwords
+constexpr int kNibDwords = 264;  // 4-bit block sums: 2046 + pad nibbles, doubled circular copy, as dwords
+constexpr int kFullWords = 68;   // bit plane of saturated windows, doubled circular copy
 
 template <int G>
 struct AcqShared {
   uint16_t x[1024];              // raw IF block
   u32 d[2][514];                 // wiped I / Q streams: 511 words, word 511 = wrap-around copy, zero pad
-  u32 s[2][2][kSDwords];         // [t0 index][I/Q] S' bytes
+  u32 s[2][2][kSDwords];         // [t0 index][I/Q] S' bytes (ALGO_SAD) or 4-bit block sums (ALGO_DOT8, first 264 dwords)
+  u32 full[2][2][kFullWords];    // ALGO_DOT8: windows whose sum is 16
+  u32 any_full[2][2];            // ALGO_DOT8: does the array hold any such window
+  u32 ones[2];                   // ALGO_DOT8: pop(D) per stream
   u32 chipbits[G][34];           // 32 words of chips + zero pad for the 64-bit window reads
   u32 red[4][G][2];              // cross-wave reduction scratch
 };
@@ -45,12 +58,39 @@ __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
   return (words[byte_index >> 2] >> ((byte_index & 3) * 8)) & 0xFFu;
 }
 
+// E[i][p] = sum_c chip_p[c] * F[4 tid + i + c]: AND + popcount of the saturated-window bit plane against the packed chips
+template <int G>
+__device__ __forceinline__ void add_saturation_deficit(u32 (&acc)[4][G], const u32 *full_bits, const u32 *__restrict__ chipbits,
+                                                    int tid)
+{
+#pragma unroll 1
+  for (int w = 0; w < 32; w++) {
+    u32 fwin[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int bit = 4 * tid + i + 32 * w;
+      fwin[i] = __builtin_amdgcn_alignbit(full_bits[(bit >> 5) + 1], full_bits[bit >> 5], (u32)(bit & 31));
+    }
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      const u32 chips32 = chipbits[p * 32 + w];  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        acc[i][p] += __popc(fwin[i] & chips32);
+    }
+  }
+}
+
 }  // namespace
 
-template <int G, bool MULTI>
-__global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
+// waves per SIMD the register allocator must leave room for: the byte-SAD single-block kernel fits 128 VGPRs (4 waves);
+// the dot-product and multi-block variants carry more live state and get 168 (3 waves) instead of spilling
+template <int G, bool MULTI, int ALGO>
+__global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                   const u32 *__restrict__ cw, const u32 *__restrict__ chipbits)
 {
+  constexpr bool DOT8 = ALGO == kAlgoDot8;
+  constexpr int kSteps = DOT8 ? kCodeWords / 2 : kCodeWords;   // 8 or 4 chips per main-loop step
   __shared__ AcqShared<G> sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -91,7 +131,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const 
   const u32 step_word = nco_step_per_word(freq_hz);
   const u32 low_mask = (1u << b) - 1u;                 // replica bits of word i that still belong to chip i-1
   const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;      // ... and to chip i
-  const u32 *cw_group = cw + (size_t)(slot0 / G) * kCodeWords * G;
+  const u32 *cw_group = cw + (size_t)(slot0 / G) * kSteps * G;
 
   for (int i = tid; i < G * 34; i += kThreads) {
     const int p = i / 34, w = i - p * 34;
@@ -123,9 +163,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const 
     __syncthreads();  // previous iteration's readers of sh.* are done
     for (int i = tid; i < 1024; i += kThreads)
       sh.x[i] = i < kWords16 ? blk[i] : (uint16_t)0;
+    if (DOT8) {
+      for (int i = tid; i < 4 * kFullWords; i += kThreads)
+        (&sh.full[0][0][0])[i] = 0;
+      if (tid < 4)
+        (&sh.any_full[0][0])[tid] = 0;
+      if (tid < 2)
+        sh.ones[tid] = 0;
+    }
     __syncthreads();
     // ---- A2: carrier wipe-off (K3).  Word w sees the NCO after w steps from zero. -----------------------------
     const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
+    u32 ones_i = 0, ones_q = 0;
     for (int w = tid; w < 514; w += kThreads) {
       u32 vi = 0, vq = 0;
       if (w < kWords32) {
@@ -135,27 +184,62 @@ __global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const 
       }
       sh.d[0][w] = vi;
       sh.d[1][w] = vq;
+      ones_i += __popc(vi);
+      ones_q += __popc(vq);
+    }
+    if (DOT8) {
+      ones_i = wave_sum_u32(ones_i);
+      ones_q = wave_sum_u32(ones_q);
+      if (lane == 0) {
+        atomicAdd(&sh.ones[0], ones_i);
+        atomicAdd(&sh.ones[1], ones_q);
+      }
     }
     __syncthreads();
     if (tid < 2)  // word 511: samples 16352..16367 are zero, then the stream wraps to sample 0
       sh.d[tid][511] = sh.d[tid][0] << 16;
     __syncthreads();
     // ---- A3: block sums S'_t0[k] = 1 + pop(D[16k + t0, +16)), k circular over 1023, for t0 = b and b + 8 --------
-    for (int m = tid; m < 4 * kSDwords; m += kThreads) {
-      const int arr = m / kSDwords;       // 0..3 = (t0 index, I/Q)
-      const int dw = m - arr * kSDwords;
-      const int t0 = b + 8 * (arr >> 1);
-      const u32 *dd = sh.d[arr & 1];
-      u32 packed = 0;
+    if (!DOT8) {
+      for (int m = tid; m < 4 * kSDwords; m += kThreads) {
+        const int arr = m / kSDwords;       // 0..3 = (t0 index, I/Q)
+        const int dw = m - arr * kSDwords;
+        const int t0 = b + 8 * (arr >> 1);
+        const u32 *dd = sh.d[arr & 1];
+        u32 packed = 0;
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        int k = dw * 4 + e;
-        k = k >= 2 * kChips ? k - 2 * kChips : (k >= kChips ? k - kChips : k);
-        const int pos = 16 * k + t0;
-        const u32 win = __builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31));
-        packed |= (1u + pop16(win)) << (8 * e);
+        for (int e = 0; e < 4; e++) {
+          int k = dw * 4 + e;
+          k = k >= 2 * kChips ? k - 2 * kChips : (k >= kChips ? k - kChips : k);
+          const int pos = 16 * k + t0;
+          const u32 win = __builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31));
+          packed |= (1u + pop16(win)) << (8 * e);
+        }
+        sh.s[arr >> 1][arr & 1][dw] = packed;
       }
-      sh.s[arr >> 1][arr & 1][dw] = packed;
+    } else {
+      // 4-bit sums min(S, 15), eight per dword; windows with S == 16 are flagged in the bit plane `full`
+      for (int m = tid; m < 4 * kNibDwords; m += kThreads) {
+        const int arr = m / kNibDwords;
+        const int dw = m - arr * kNibDwords;
+        const int t0 = b + 8 * (arr >> 1);
+        const u32 *dd = sh.d[arr & 1];
+        u32 packed = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int kd = dw * 8 + e;   // index in the doubled array
+          const int k = kd >= 2 * kChips ? kd - 2 * kChips : (kd >= kChips ? kd - kChips : kd);
+          const int pos = 16 * k + t0;
+          const u32 win = __builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31));
+          const u32 sum = pop16(win);
+          if (sum == 16u) {
+            atomicOr(&sh.full[arr >> 1][arr & 1][kd >> 5], 1u << (kd & 31));
+            sh.any_full[arr >> 1][arr & 1] = 1u;
+          }
+          packed |= (sum > 15u ? 15u : sum) << (4 * e);
+        }
+        sh.s[arr >> 1][arr & 1][dw] = packed;
+      }
     }
     __syncthreads();
 
@@ -173,32 +257,67 @@ __global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const 
           acc_i[i][p] = 0;
           acc_q[i][p] = 0;
         }
-      const u32 *si = sh.s[half][0] + tid;
-      const u32 *sq = sh.s[half][1] + tid;
-      u32 cur_i = si[0], cur_q = sq[0];
+      if (!DOT8) {
+        const u32 *si = sh.s[half][0] + tid;
+        const u32 *sq = sh.s[half][1] + tid;
+        u32 cur_i = si[0], cur_q = sq[0];
 #pragma unroll 2
-      for (int j = 0; j < kCodeWords; j++) {
-        const u32 nxt_i = si[j + 1];
-        const u32 nxt_q = sq[j + 1];
-        u32 wi[4], wq[4];
-        wi[0] = cur_i;
-        wq[0] = cur_q;
+        for (int j = 0; j < kCodeWords; j++) {
+          const u32 nxt_i = si[j + 1];
+          const u32 nxt_q = sq[j + 1];
+          u32 wi[4], wq[4];
+          wi[0] = cur_i;
+          wq[0] = cur_q;
 #pragma unroll
-        for (int i = 1; i < 4; i++) {
-          wi[i] = __builtin_amdgcn_alignbyte(nxt_i, cur_i, (u32)i);
-          wq[i] = __builtin_amdgcn_alignbyte(nxt_q, cur_q, (u32)i);
+          for (int i = 1; i < 4; i++) {
+            wi[i] = __builtin_amdgcn_alignbyte(nxt_i, cur_i, (u32)i);
+            wq[i] = __builtin_amdgcn_alignbyte(nxt_q, cur_q, (u32)i);
+          }
+#pragma unroll
+          for (int p = 0; p < G; p++) {
+            const u32 code = cw_group[j * G + p];  // wave-uniform -> scalar load
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              acc_i[i][p] = __builtin_amdgcn_msad_u8(wi[i], code, acc_i[i][p]);
+              acc_q[i][p] = __builtin_amdgcn_msad_u8(wq[i], code, acc_q[i][p]);
+            }
+          }
+          cur_i = nxt_i;
+          cur_q = nxt_q;
         }
-#pragma unroll
-        for (int p = 0; p < G; p++) {
-          const u32 code = cw_group[j * G + p];  // wave-uniform -> scalar load
+      } else {
+        // lane's four offsets start at nibble 4 tid + i: dword tid / 2, bit 16 (tid & 1) + 4 i
+        const u32 *ni = sh.s[half][0] + (tid >> 1);
+        const u32 *nq = sh.s[half][1] + (tid >> 1);
+        const u32 sh0 = 16u * (u32)(tid & 1);
+        u32 cur_i = ni[0], cur_q = nq[0];
+#pragma unroll 2
+        for (int j = 0; j < kSteps; j++) {
+          const u32 nxt_i = ni[j + 1];
+          const u32 nxt_q = nq[j + 1];
+          u32 wi[4], wq[4];
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            acc_i[i][p] = __builtin_amdgcn_msad_u8(wi[i], code, acc_i[i][p]);
-            acc_q[i][p] = __builtin_amdgcn_msad_u8(wq[i], code, acc_q[i][p]);
+            wi[i] = __builtin_amdgcn_alignbit(nxt_i, cur_i, sh0 + 4u * (u32)i);
+            wq[i] = __builtin_amdgcn_alignbit(nxt_q, cur_q, sh0 + 4u * (u32)i);
           }
+#pragma unroll
+          for (int p = 0; p < G; p++) {
+            const u32 code = cw_group[j * G + p];  // eight 0/1 chip nibbles, wave-uniform -> scalar load
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              acc_i[i][p] = __builtin_amdgcn_udot8(wi[i], code, acc_i[i][p], false);
+              acc_q[i][p] = __builtin_amdgcn_udot8(wq[i], code, acc_q[i][p], false);
+            }
+          }
+          cur_i = nxt_i;
+          cur_q = nxt_q;
         }
-        cur_i = nxt_i;
-        cur_q = nxt_q;
+        // deficit of the saturated windows: E = sum_c chip[c] * F[q + c], only where such windows exist
+        if (sh.any_full[half][0])
+          add_saturation_deficit<G>(acc_i, sh.full[half][0], chipbits + (size_t)slot0 * 32, tid);
+        if (sh.any_full[half][1])
+          add_saturation_deficit<G>(acc_q, sh.full[half][1], chipbits + (size_t)slot0 * 32, tid);
       }
 
       // ---- C: per-hypothesis corrections, magnitude, running search result -------------------------------------
@@ -226,7 +345,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const 
         for (int p = 0; p < G; p++) {
           const u32 tail_bits = chipbits[(size_t)(slot0 + p) * 32 + 31];  // wave-uniform -> scalar load
           const u32 c1022 = (tail_bits >> 30) & 1u, c1021 = (tail_bits >> 29) & 1u;
-          int ci = (int)acc_i[i][p], cq = (int)acc_q[i][p];
+          int ci, cq;
+          if (DOT8) {  // C0 = pop(D) + 8192 - 2 M
+            ci = (int)sh.ones[0] + kHalf + 8 - 2 * (int)acc_i[i][p];
+            cq = (int)sh.ones[1] + kHalf + 8 - 2 * (int)acc_q[i][p];
+          } else {
+            ci = (int)acc_i[i][p];
+            cq = (int)acc_q[i][p];
+          }
           if (c1022) {  // replica shift is not circular (chip 1022's last b samples are lost, b zeros lead)
             ci += 2 * (int)head_i - b;
             cq += 2 * (int)head_q - b;
@@ -356,23 +482,32 @@ __global__ __launch_bounds__(kThreads, 4) void k_acq(const AcqParams prm, const 
   }
 }
 
-void launch_acq(hipStream_t s, int group, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
+template <int G, int ALGO>
+static void launch_acq_t(hipStream_t s, int n_workgroups, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw,
+                         const uint32_t *d_chipbits)
+{
+  const dim3 grid(n_workgroups), block(kThreads);
+  if (prm.n_ms > 1)
+    hipLaunchKernelGGL((k_acq<G, true, ALGO>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  else
+    hipLaunchKernelGGL((k_acq<G, false, ALGO>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+}
+
+void launch_acq(hipStream_t s, int group, int algo, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits)
 {
   if (n_workgroups <= 0)
     return;
-  const dim3 grid(n_workgroups), block(kThreads);
-  const bool multi = prm.n_ms > 1;
   if (group == kAcqGroup) {
-    if (multi)
-      hipLaunchKernelGGL((k_acq<kAcqGroup, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    if (algo == kAlgoDot8)
+      launch_acq_t<kAcqGroup, kAlgoDot8>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
     else
-      hipLaunchKernelGGL((k_acq<kAcqGroup, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+      launch_acq_t<kAcqGroup, kAlgoSad>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
   } else {
-    if (multi)
-      hipLaunchKernelGGL((k_acq<1, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    if (algo == kAlgoDot8)
+      launch_acq_t<1, kAlgoDot8>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
     else
-      hipLaunchKernelGGL((k_acq<1, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+      launch_acq_t<1, kAlgoSad>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
   }
 }
 

@@ -9,7 +9,7 @@
 namespace gpsx {
 
 __global__ void k_build_codes(const uint8_t *__restrict__ prns, int n_slots, int group, uint8_t *__restrict__ chips,
-                              u32 *__restrict__ chipbits, u32 *__restrict__ cw)
+                              u32 *__restrict__ chipbits, u32 *__restrict__ cw, u32 *__restrict__ cw8)
 {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= n_slots)
@@ -61,15 +61,28 @@ __global__ void k_build_codes(const uint8_t *__restrict__ prns, int n_slots, int
       base[(size_t)jw * group] = word;
     }
   }
+  if (cw8) {
+    const bool live = prn >= 1 && prn <= GPSX_MAX_PRN;
+    u32 *base = cw8 + (size_t)(slot / group) * (kCodeWords / 2) * group + (slot % group);
+    for (int jw = 0; jw < kCodeWords / 2; jw++) {
+      u32 word = 0;
+      for (int e = 0; e < 8; e++) {
+        const int c = 8 * jw + e;
+        if (live && c < kChips)
+          word |= ((bits[c >> 5] >> (c & 31)) & 1u) << (4 * e);
+      }
+      base[(size_t)jw * group] = word;
+    }
+  }
 }
 
 void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int group, uint8_t *d_chips,
-                        uint32_t *d_chipbits, uint32_t *d_cw)
+                        uint32_t *d_chipbits, uint32_t *d_cw, uint32_t *d_cw8)
 {
   if (n_slots <= 0)
     return;
   hipLaunchKernelGGL(k_build_codes, dim3((n_slots + 63) / 64), dim3(64), 0, s, d_prns, n_slots, group, d_chips,
-                     d_chipbits, d_cw);
+                     d_chipbits, d_cw, d_cw8);
 }
 
 }  // namespace gpsx

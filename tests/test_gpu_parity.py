@@ -316,6 +316,36 @@ def test_acq_jobs_per_channel_hints_and_windows(eng, oracle, stream):
         assert np.array_equal(energy[i], en), i
 
 
+def test_acq_grid_saturated_block_sums_clean_carriers(eng, oracle):
+    """Clean synthetic inputs make whole 16-sample windows all ones after wipe-off (block sum 16): the 4-bit dot-product
+    path must restore those exactly.  Inputs: the reference simulator's noise-free block (PRN 1, IF + 2000 Hz), an
+    all-ones / all-zeros capture, a bare Fs/4 carrier, and a carrier times PRN 7."""
+    g = load("f6_config1.npz")
+    rng = np.random.default_rng(3)
+    chips7 = oracle.ca_code(7)
+    carrier = np.tile(np.array([0x99], np.uint8), 2046)
+    code_bits = np.repeat(chips7, 16)[:16368]
+    prn_on_carrier = np.packbits(np.unpackbits(carrier, bitorder="little")[:16368] ^ code_bits, bitorder="little")
+    blocks = np.stack([g["blocks"][0], np.full(2046, 0xFF, np.uint8), np.zeros(2046, np.uint8), carrier, prn_on_carrier,
+                       np.roll(prn_on_carrier, 137)])
+    prns = np.array([1, 7, 16, 22], np.uint8)
+    for k in range(len(blocks)):
+        for dopp in (2000, 0, -500):
+            out = eng.acq_grid_debug(blocks[k:k + 1], prns, dopp_min_hz=dopp, n_dopp=1, want_cnt=True)
+            want = oracle.acq_grid(blocks[k:k + 1], 1, prns, dopp, 500, 1, 8, n_threads=4)
+            for f in ("max_val", "phase", "sum", "avr"):
+                assert np.array_equal(out["peaks"][0][f], want[f]), (k, dopp, f)
+            # raw popcounts of a few (PRN, shift) planes against the oracle primitive
+            di, dq, _ = oracle.wipeoff(blocks[k], float(IF_HZ + dopp))
+            for p, b in [(0, 0), (1, 3), (3, 7)]:
+                rep = oracle.replica(oracle.ca_code(int(prns[p])), b)
+                ref_cnt = np.array([oracle.mult_and_summ(di, dq, rep, o) for o in range(0, 2046, 7)])
+                assert np.array_equal(out["cnt"][0, p, 0, b, ::7, :], ref_cnt), (k, dopp, p, b)
+    # config 1 through the grid kernel: same 7904 / 65 / 100 as the reference's self-test
+    peaks, _ = eng.acq_grid(g["blocks"][0:1], [1], dopp_min_hz=2000, n_dopp=1)
+    assert _peak_tuple(peaks[0, 0, 0, 0])[:2] == (7904, 100) and int(peaks[0, 0, 0, 0]["avr"]) == 65
+
+
 def test_acq_rejects_bad_arguments(eng, stream):
     from stm32f4_sdr_gps_amd.capi import GpsxError, JOB_DTYPE
     with pytest.raises(GpsxError):
