@@ -166,6 +166,9 @@ int gpsx_replica(gpsx_ctx *ctx, const uint8_t *chips, unsigned offset_bits, uint
  * 2046-byte buffers.  Any of cnt_i/cnt_q (raw popcounts), corr8 may be NULL. */
 int gpsx_corr_offsets(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
                       const uint16_t *offsets, int n, uint16_t *cnt_i, uint16_t *cnt_q, int16_t *corr8);
+/* the magnitude stage of gps_correlation8 alone (PM/GPS/gps_misc.c:106-118) for n raw popcount pairs: centre by 8184,
+ * clip negatives to zero, (int16) sqrtf((float)(I*I) + (float)(Q*Q)) */
+int gpsx_mag8(gpsx_ctx *ctx, const uint16_t *cnt_i, const uint16_t *cnt_q, int n, int16_t *out);
 /* correlation_search on arbitrary buffers */
 int gpsx_corr_search(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
                      unsigned start_shift, unsigned stop_shift, gpsx_peak_t *peak);

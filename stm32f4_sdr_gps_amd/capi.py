@@ -74,6 +74,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_replica.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
     lib.gpsx_corr_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gpsx_mag8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
     # compat (reference names)
     lib.gps_generate_prn.argtypes = [C.c_void_p, C.c_int]
@@ -280,6 +281,13 @@ class Engine:
                                              offsets.ctypes.data, n, ci.ctypes.data, cq.ctypes.data, c8.ctypes.data),
                   "gpsx_corr_offsets")
         return ci, cq, c8
+
+    def mag8(self, cnt_i, cnt_q) -> np.ndarray:
+        ci = np.ascontiguousarray(cnt_i, np.uint16)
+        cq = np.ascontiguousarray(cnt_q, np.uint16)
+        out = np.zeros(len(ci), np.int16)
+        self._chk(self.lib.gpsx_mag8(self.h, ci.ctypes.data, cq.ctypes.data, len(ci), out.ctypes.data), "gpsx_mag8")
+        return out
 
     def corr_search(self, rep, di, dq, start, stop):
         pk = np.zeros(1, PEAK_DTYPE)

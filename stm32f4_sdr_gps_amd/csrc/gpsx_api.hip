@@ -632,6 +632,24 @@ int gpsx_corr_offsets(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *da
   return GPSX_OK;
 }
 
+int gpsx_mag8(gpsx_ctx *ctx, const uint16_t *cnt_i, const uint16_t *cnt_q, int n, int16_t *out)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!cnt_i || !cnt_q || !out || n < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  if (int rc = arena_reset(ctx, 3 * arena_size((size_t)n * 2))) return rc;
+  uint16_t *d_i = arena_take<uint16_t>(ctx, n);
+  uint16_t *d_q = arena_take<uint16_t>(ctx, n);
+  int16_t *d_o = arena_take<int16_t>(ctx, n);
+  HIPCHK(ctx, hipMemcpyAsync(d_i, cnt_i, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_q, cnt_q, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
+  launch_mag8(ctx->stream, d_i, d_q, n, d_o);
+  LAUNCHCHK(ctx, "k_mag8");
+  HIPCHK(ctx, hipMemcpyAsync(out, d_o, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
 int gpsx_corr_search(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *data_i, const uint16_t *data_q,
                      unsigned start_shift, unsigned stop_shift, gpsx_peak_t *peak)
 {

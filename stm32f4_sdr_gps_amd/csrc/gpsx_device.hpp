@@ -49,7 +49,9 @@ __device__ __forceinline__ u32 nco_step_per_word(float freq_hz)
 }
 
 // gps_correlation8's magnitude (PM/GPS/gps_misc.c:106-118): centre, one-sided clip, sqrtf of float32 squares,
-// truncation.  sqrtf must be correctly rounded for the truncation to agree with the host libm.
+// truncation.  sqrtf must be correctly rounded for the truncation to agree with the host libm: __builtin_sqrtf under
+// -fhip-fp32-correctly-rounded-divide-sqrt expands to v_sqrt_f32 plus the two-FMA fix-up; HIP's __fsqrt_rn does NOT
+// (it lowers to the bare 1-ulp v_sqrt_f32 on gfx950, checked in the ISA), so it must not be used here.
 __device__ __forceinline__ int mag8(int cnt_i, int cnt_q)
 {
   int i = cnt_i - kHalf;
@@ -57,7 +59,7 @@ __device__ __forceinline__ int mag8(int cnt_i, int cnt_q)
   i = i < 0 ? 0 : i;
   q = q < 0 ? 0 : q;
   const float e = (float)(i * i) + (float)(q * q);
-  return (int)__fsqrt_rn(e);
+  return (int)__builtin_sqrtf(e);
 }
 
 __device__ __forceinline__ u32 pop16(u32 v) { return (u32)__popc(v & 0xFFFFu); }

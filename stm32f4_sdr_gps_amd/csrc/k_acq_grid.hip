@@ -58,7 +58,17 @@ __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
   return (words[byte_index >> 2] >> ((byte_index & 3) * 8)) & 0xFFu;
 }
 
-// E[i][p] = sum_c chip_p[c] * F[4 tid + i + c]: AND + popcount of the saturated-window bit plane against the packed chips
+// Which chip offset q (0..1023) hypothesis i (0..3) of lane `tid` is.
+//   byte-SAD loop : four consecutive offsets, q = 4 tid + i (windows formed with v_alignbyte from one dword stream)
+//   dot8 loop     : q = 32 (tid / 8) + (tid % 8) + 8 i -- the lane's offsets are one 8-nibble dword apart, so the data
+//                   window of (i, step j) is the window of (i - 1, step j + 1): ONE new v_alignbit per step serves all four
+template <int ALGO>
+__device__ __forceinline__ int chip_offset_of(int tid, int i)
+{
+  return ALGO == kAlgoDot8 ? 32 * (tid >> 3) + (tid & 7) + 8 * i : 4 * tid + i;
+}
+
+// E[i][p] = sum_c chip_p[c] * F[q_i + c]: AND + popcount of the saturated-window bit plane against the packed chips
 template <int G>
 __device__ __forceinline__ void add_saturation_deficit(u32 (&acc)[4][G], const u32 *full_bits, const u32 *__restrict__ chipbits,
                                                     int tid)
@@ -68,7 +78,7 @@ __device__ __forceinline__ void add_saturation_deficit(u32 (&acc)[4][G], const u
     u32 fwin[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int bit = 4 * tid + i + 32 * w;
+      const int bit = chip_offset_of<kAlgoDot8>(tid, i) + 32 * w;
       fwin[i] = __builtin_amdgcn_alignbit(full_bits[(bit >> 5) + 1], full_bits[bit >> 5], (u32)(bit & 31));
     }
 #pragma unroll
@@ -286,21 +296,26 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
           cur_q = nxt_q;
         }
       } else {
-        // lane's four offsets start at nibble 4 tid + i: dword tid / 2, bit 16 (tid & 1) + 4 i
-        const u32 *ni = sh.s[half][0] + (tid >> 1);
-        const u32 *nq = sh.s[half][1] + (tid >> 1);
-        const u32 sh0 = 16u * (u32)(tid & 1);
-        u32 cur_i = ni[0], cur_q = nq[0];
-#pragma unroll 2
-        for (int j = 0; j < kSteps; j++) {
-          const u32 nxt_i = ni[j + 1];
-          const u32 nxt_q = nq[j + 1];
-          u32 wi[4], wq[4];
+        // lane's offsets q = 32 a + c + 8 i (a = tid / 8, c = tid % 8): nibble q + 8 j sits in dword 4 a + i + j at bit 4 c,
+        // so step j uses windows W[j .. j + 3] of the lane's stream W[m] = alignbit(dw[m + 1], dw[m], 4 c)
+        const u32 *ni = sh.s[half][0] + 4 * (tid >> 3);
+        const u32 *nq = sh.s[half][1] + 4 * (tid >> 3);
+        const u32 shn = 4u * (u32)(tid & 7);
+        u32 wi[4], wq[4];
+        u32 prev_i = ni[3], prev_q = nq[3];
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            wi[i] = __builtin_amdgcn_alignbit(nxt_i, cur_i, sh0 + 4u * (u32)i);
-            wq[i] = __builtin_amdgcn_alignbit(nxt_q, cur_q, sh0 + 4u * (u32)i);
-          }
+        for (int m = 0; m < 3; m++) {
+          wi[m] = __builtin_amdgcn_alignbit(ni[m + 1], ni[m], shn);
+          wq[m] = __builtin_amdgcn_alignbit(nq[m + 1], nq[m], shn);
+        }
+#pragma unroll 4
+        for (int j = 0; j < kSteps; j++) {
+          const u32 new_i = ni[j + 4];
+          const u32 new_q = nq[j + 4];
+          wi[3] = __builtin_amdgcn_alignbit(new_i, prev_i, shn);
+          wq[3] = __builtin_amdgcn_alignbit(new_q, prev_q, shn);
+          prev_i = new_i;
+          prev_q = new_q;
 #pragma unroll
           for (int p = 0; p < G; p++) {
             const u32 code = cw_group[j * G + p];  // eight 0/1 chip nibbles, wave-uniform -> scalar load
@@ -310,8 +325,11 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
               acc_q[i][p] = __builtin_amdgcn_udot8(wq[i], code, acc_q[i][p], false);
             }
           }
-          cur_i = nxt_i;
-          cur_q = nxt_q;
+#pragma unroll
+          for (int m = 0; m < 3; m++) {
+            wi[m] = wi[m + 1];
+            wq[m] = wq[m + 1];
+          }
         }
         // deficit of the saturated windows: E = sum_c chip[c] * F[q + c], only where such windows exist
         if (sh.any_full[half][0])
@@ -321,13 +339,15 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
       }
 
       // ---- C: per-hypothesis corrections, magnitude, running search result -------------------------------------
-      // Odd offsets: replica word p1 = 1022 - q meets the buffer wrap.  The lane's four q need chips
-      // p1 - 1 .. p1 for p1 = 1022 - 4 tid - i, i.e. the five chips starting at 1018 - 4 tid (chips below 0 = 0).
-      const int chip_base = kChips - 5 - 4 * tid;
+      // Odd offsets: replica word p1 = 1022 - q meets the buffer wrap.  The lane's four q need chips p1 - 1 and p1;
+      // they all lie within 26 chips of each other, so one 32-chip window read per PRN serves the four (chips < 0 = 0).
+      // (chip_base is the lowest chip the lane needs: p1 - 1 of its largest q)
+      const int q_hi = chip_offset_of<ALGO>(tid, 3);
+      const int chip_base = kChips - 2 - q_hi;
       const int chip_lo = chip_base < 0 ? 0 : chip_base;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int q = tid * 4 + i;
+        const int q = chip_offset_of<ALGO>(tid, i);
         const int o = 2 * q + half;
         const bool exists = q < kChips;
         const bool in_win = exists && o >= win_start && o < win_stop;
@@ -359,9 +379,10 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
           }
           if (half) {
             const u64 two = (u64)sh.chipbits[p][chip_lo >> 5] | ((u64)sh.chipbits[p][(chip_lo >> 5) + 1] << 32);
-            u32 five = (u32)(two >> (chip_lo & 31)) & 31u;
-            five = chip_base < 0 ? five << (chip_lo - chip_base) : five;
-            const u32 cp1 = (five >> (4 - i)) & 1u, cp0 = (five >> (3 - i)) & 1u;
+            u32 chipwin = (u32)(two >> (chip_lo & 31));                    // chips chip_lo .. chip_lo + 31
+            chipwin = chip_base < 0 ? chipwin << (chip_lo - chip_base) : chipwin;  // bit k = chip (chip_base + k)
+            const int k1 = exists ? (kChips - 1 - q) - chip_base : 1;       // p1 = 1022 - q
+            const u32 cp1 = (chipwin >> k1) & 1u, cp0 = (chipwin >> (k1 - 1)) & 1u;
             const u32 r_wrap = (cp0 ? low_mask : 0u) | (cp1 ? high_mask : 0u);
             ci -= (int)pop16(wrap_i ^ r_wrap);
             cq -= (int)pop16(wrap_q ^ r_wrap);
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
       for (int half = 0; half < 2; half++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int q = tid * 4 + i;
+          const int q = chip_offset_of<ALGO>(tid, i);
           const int o = 2 * q + half;
           const bool in_win = q < kChips && o >= win_start && o < win_stop;
           const u32 e = energy[MULTI ? half : 0][MULTI ? i : 0][MULTI ? p : 0];

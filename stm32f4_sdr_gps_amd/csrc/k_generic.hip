@@ -127,6 +127,21 @@ void launch_corr_offsets(hipStream_t s, const uint8_t *d_rep, const uint8_t *d_i
                      d_cnt_i, d_cnt_q, d_corr8);
 }
 
+__global__ void k_mag8(const uint16_t *__restrict__ cnt_i, const uint16_t *__restrict__ cnt_q, int n,
+                       int16_t *__restrict__ out)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n)
+    out[idx] = (int16_t)mag8((int)cnt_i[idx], (int)cnt_q[idx]);
+}
+
+void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q, int n, int16_t *d_out)
+{
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(k_mag8, dim3((n + 255) / 256), dim3(256), 0, s, d_cnt_i, d_cnt_q, n, d_out);
+}
+
 // max (strict: first maximum wins, nothing above 0 leaves phase 0), sum, sum / 2046 over n consecutive offsets
 __global__ __launch_bounds__(256) void k_search_reduce(const int16_t *__restrict__ corr8, int n, int first_offset,
                                                        gpsx_peak_t *__restrict__ peak)

@@ -130,6 +130,32 @@ def test_corr_offsets_arbitrary_buffers_vs_oracle(eng, oracle):
         assert np.array_equal(c8, [oracle.mag8(int(a), int(b)) for a, b in want])
 
 
+def test_mag8_sqrt_is_correctly_rounded_everywhere_it_matters(eng):
+    """(int16) sqrtf(float(I*I) + float(Q*Q)) truncates a ROUNDED root: wherever the true root sits just below an integer
+    a 1-ulp-approximate hardware sqrt can land on the wrong side.  Sweep every I with Q = 0 and Q = I, the pairs around
+    every integer radius, and two million random pairs, against numpy's correctly rounded float32 sqrt."""
+    def want(ci, cq):
+        i = np.clip(ci.astype(np.int64) - 8184, 0, None)
+        q = np.clip(cq.astype(np.int64) - 8184, 0, None)
+        e = (i * i).astype(np.float32) + (q * q).astype(np.float32)
+        return np.sqrt(e).astype(np.int16)
+    rng = np.random.default_rng(12)
+    a = np.arange(0, 16369, dtype=np.int64)
+    sets = [(a, np.full_like(a, 8184)), (a, a), (a, 16368 - a)]
+    # pairs (i, q) with i*i + q*q within +-2 of k*k for every radius k: the truncation boundaries
+    ks = np.arange(1, 11574, dtype=np.int64)
+    for frac in (0.0, 0.38, 0.6, 0.71, 0.92):
+        i = np.floor(ks * frac).astype(np.int64)
+        for dq in (-1, 0, 1):
+            q = np.floor(np.sqrt(np.maximum(ks * ks - i * i, 0))).astype(np.int64) + dq
+            ok = (i <= 8184) & (q >= 0) & (q <= 8184)
+            sets.append((8184 + i[ok], 8184 + q[ok]))
+    sets.append((rng.integers(8184, 16369, 2_000_000), rng.integers(8184, 16369, 2_000_000)))
+    for ci, cq in sets:
+        got = eng.mag8(ci, cq)
+        assert np.array_equal(got, want(ci, cq))
+
+
 def test_corr_search_golden(eng):
     g = load("f4_corr.npz")
     blk = g["stream"][int(g["block_index"])]

@@ -19,7 +19,7 @@ def main(tag="r01", searches=16):
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
     summary = {"tag": tag, "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline (one rocprofv3 --pmc pass "
-                                       "per counter group, --kernel-trace only)", "kernel": "gpsx::k_acq<8,false>",
+                                       "per counter group, --kernel-trace only)", "kernel": "gpsx::k_acq<8,false,ALGO> (the acquisition grid kernel of the run)",
                "counters_avg_per_launch": {}}
     for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         path = os.path.join(src, name, "pmc_counter_collection.csv")
@@ -59,9 +59,13 @@ def main(tag="r01", searches=16):
             "gpu_cycles_per_launch": cycles,
             "valu_issue_cycles_per_simd": c["SQ_INSTS_VALU"] * 4.0 / 1024.0,   # 4 cycles per wave64 int op, 1024 SIMDs
             "valu_issue_utilisation": c["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cycles,
-            "msad_wave_instructions_expected": searches * 672 * 4 * 2 * 256 * 64,
+            # main-loop instructions the formulation needs: workgroups x 4 waves x 2 halves x steps x 64
+            "main_loop_wave_instructions_sad": searches * 672 * 4 * 2 * 256 * 64,
+            "main_loop_wave_instructions_dot8": searches * 672 * 4 * 2 * 128 * 64,
         }
-        summary["derived"]["msad_share_of_valu"] = summary["derived"]["msad_wave_instructions_expected"] / c["SQ_INSTS_VALU"]
+        d = summary["derived"]
+        d["sad_share_of_valu"] = d["main_loop_wave_instructions_sad"] / c["SQ_INSTS_VALU"]
+        d["dot8_share_of_valu"] = d["main_loop_wave_instructions_dot8"] / c["SQ_INSTS_VALU"]
     with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
