@@ -637,16 +637,22 @@ int gpsx_mag8(gpsx_ctx *ctx, const uint16_t *cnt_i, const uint16_t *cnt_q, int n
   if (int rc = use_device(ctx)) return rc;
   if (!cnt_i || !cnt_q || !out || n < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
-  if (int rc = arena_reset(ctx, 3 * arena_size((size_t)n * 2))) return rc;
+  if (int rc = arena_reset(ctx, 3 * arena_size((size_t)n * 2) + arena_size(4))) return rc;
   uint16_t *d_i = arena_take<uint16_t>(ctx, n);
   uint16_t *d_q = arena_take<uint16_t>(ctx, n);
   int16_t *d_o = arena_take<int16_t>(ctx, n);
+  uint32_t *d_bad = arena_take<uint32_t>(ctx, 1);
+  uint32_t bad = 0;
   HIPCHK(ctx, hipMemcpyAsync(d_i, cnt_i, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_q, cnt_q, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
-  launch_mag8(ctx->stream, d_i, d_q, n, d_o);
+  HIPCHK(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+  launch_mag8(ctx->stream, d_i, d_q, n, d_o, d_bad);
   LAUNCHCHK(ctx, "k_mag8");
   HIPCHK(ctx, hipMemcpyAsync(out, d_o, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (bad)  // the grid kernel's trimmed magnitude must be the same function
+    return fail(ctx, GPSX_EIO, "internal: mag8_fast disagrees with mag8 on " + std::to_string(bad) + " inputs");
   return GPSX_OK;
 }
 

@@ -62,6 +62,30 @@ __device__ __forceinline__ int mag8(int cnt_i, int cnt_q)
   return (int)__builtin_sqrtf(e);
 }
 
+// The same value for the hot epilogue of the grid kernel, with the instruction count trimmed:
+//  * i, q <= 8184 < 2^24, so the squares are one full-rate v_mul_u32_u24 each instead of the quarter-rate v_mul_lo_u32;
+//  * e is 0 or >= 1 and finite, so the denormal pre-scaling and the inf/zero class check of the generic sqrtf expansion
+//    are dead weight; what remains is v_sqrt_f32 (<= 1 ulp) and the standard one-step correction that makes it the
+//    correctly rounded root: with r- / r+ the floats next to r, pick r- if e - r-*r <= 0, r+ if e - r+*r > 0 (fused
+//    residuals are exact enough to decide, this is the fix-up LLVM itself emits for a correctly rounded f32 sqrt).
+//    e == 0: r = 0, r- is a NaN pattern, both tests fail, r stays 0.
+__device__ __forceinline__ int mag8_fast(int cnt_i, int cnt_q)
+{
+  int i = cnt_i - kHalf;
+  int q = cnt_q - kHalf;
+  i = i < 0 ? 0 : i;
+  q = q < 0 ? 0 : q;
+  const float e = (float)__umul24((u32)i, (u32)i) + (float)__umul24((u32)q, (u32)q);
+  float r = __builtin_amdgcn_sqrtf(e);
+  const float r_dn = __uint_as_float(__float_as_uint(r) - 1u);
+  const float r_up = __uint_as_float(__float_as_uint(r) + 1u);
+  const float res_dn = __builtin_fmaf(-r_dn, r, e);
+  const float res_up = __builtin_fmaf(-r_up, r, e);
+  r = res_dn <= 0.0f ? r_dn : r;
+  r = res_up > 0.0f ? r_up : r;
+  return (int)r;
+}
+
 __device__ __forceinline__ u32 pop16(u32 v) { return (u32)__popc(v & 0xFFFFu); }
 
 // wave64 all-lanes reductions by butterfly shuffles

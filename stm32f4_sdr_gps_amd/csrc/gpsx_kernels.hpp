@@ -65,7 +65,8 @@ void launch_replica(hipStream_t s, const uint8_t *d_chips, unsigned offset_bits,
 void launch_corr_offsets(hipStream_t s, const uint8_t *d_rep, const uint8_t *d_i, const uint8_t *d_q,
                          const uint16_t *d_offsets, int first_offset, int n, uint16_t *d_cnt_i, uint16_t *d_cnt_q,
                          int16_t *d_corr8);
-void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q, int n, int16_t *d_out);
+void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q, int n, int16_t *d_out,
+                 uint32_t *d_disagree);
 void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int first_offset, gpsx_peak_t *d_peak);
 
 // K2+K3+K5 tracking correlators, one workgroup per channel

@@ -95,7 +95,8 @@ __device__ __forceinline__ void add_saturation_deficit(u32 (&acc)[4][G], const u
 
 // waves per SIMD the register allocator must leave room for: the byte-SAD single-block kernel fits 128 VGPRs (4 waves);
 // the dot-product and multi-block variants carry more live state and get 168 (3 waves) instead of spilling
-template <int G, bool MULTI, int ALGO>
+// DBG: the optional inspection outputs (raw counts, energy plane, per-block triplets) exist only in this instantiation
+template <int G, bool MULTI, int ALGO, bool DBG>
 __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                   const u32 *__restrict__ cw, const u32 *__restrict__ chipbits)
 {
@@ -339,12 +340,32 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
       }
 
       // ---- C: per-hypothesis corrections, magnitude, running search result -------------------------------------
-      // Odd offsets: replica word p1 = 1022 - q meets the buffer wrap.  The lane's four q need chips p1 - 1 and p1;
-      // they all lie within 26 chips of each other, so one 32-chip window read per PRN serves the four (chips < 0 = 0).
-      // (chip_base is the lowest chip the lane needs: p1 - 1 of its largest q)
+      // Wave-uniform pieces first.  The counts are affine in the accumulators: cnt = base + sign * acc.
+      const int base_i = DOT8 ? __builtin_amdgcn_readfirstlane((int)sh.ones[0]) + kHalf + 8 : 0;   // C0 = pop(D) + 8192 - 2 M
+      const int base_q = DOT8 ? __builtin_amdgcn_readfirstlane((int)sh.ones[1]) + kHalf + 8 : 0;
+      constexpr int kSign = DOT8 ? -2 : 1;
+      // Odd offsets skip replica word p1 = 1022 - q, which meets data bytes (2045, 0) = `wrap`.  That word's replica
+      // bits are (chip[p1 - 1] ? low : 0) | (chip[p1] ? high : 0): four possible popcounts per stream, precomputed.
+      u32 wrap_pop_i[4], wrap_pop_q[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 r = ((k & 1) ? low_mask : 0u) | ((k & 2) ? high_mask : 0u);
+        wrap_pop_i[k] = (u32)__builtin_amdgcn_readfirstlane((int)pop16(wrap_i ^ r));
+        wrap_pop_q[k] = (u32)__builtin_amdgcn_readfirstlane((int)pop16(wrap_q ^ r));
+      }
+      // One 32-chip window per PRN covers chips p1 - 1, p1 of the lane's four offsets (they lie within 26 chips).
       const int q_hi = chip_offset_of<ALGO>(tid, 3);
-      const int chip_base = kChips - 2 - q_hi;
+      const int chip_base = kChips - 2 - q_hi;   // lowest chip needed; bit k of chipwin = chip (chip_base + k)
       const int chip_lo = chip_base < 0 ? 0 : chip_base;
+      u32 chipwin[G];
+      if (half) {
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          const u64 two = (u64)sh.chipbits[p][chip_lo >> 5] | ((u64)sh.chipbits[p][(chip_lo >> 5) + 1] << 32);
+          const u32 w = (u32)(two >> (chip_lo & 31));
+          chipwin[p] = chip_base < 0 ? w << (chip_lo - chip_base) : w;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int q = chip_offset_of<ALGO>(tid, i);
@@ -352,54 +373,43 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
         const bool exists = q < kChips;
         const bool in_win = exists && o >= win_start && o < win_stop;
         const int oc = exists ? o : 0;
-        const u32 head_i = __popc(lds_byte(sh.d[0], oc) & low_mask);
-        const u32 head_q = __popc(lds_byte(sh.d[1], oc) & low_mask);
+        // quirk Q5 (replica shift not circular), applies when chip 1022 is set: + 2 pop(D[8o, 8o + b)) - b
+        const int adj_i = 2 * (int)__popc(lds_byte(sh.d[0], oc) & low_mask) - b;
+        const int adj_q = 2 * (int)__popc(lds_byte(sh.d[1], oc) & low_mask) - b;
+        // quirk Q3: odd offsets also skip the last replica word (1022) -- data bytes (o - 2, o - 1) -- unless it IS p1
+        const bool odd_tail = half && q > 0 && exists;
         u32 prev_i = 0, prev_q = 0;
-        const bool odd_tail = half && q > 0 && exists;  // the last replica word (1022) is skipped too, unless it IS p1
         if (odd_tail) {
           prev_i = lds_byte(sh.d[0], oc - 2) | (lds_byte(sh.d[0], oc - 1) << 8);
           prev_q = lds_byte(sh.d[1], oc - 2) | (lds_byte(sh.d[1], oc - 1) << 8);
         }
+        const int k0 = exists ? (kChips - 2 - q) - chip_base : 0;   // bit of chip p1 - 1 in chipwin (p1 = 1022 - q)
         const u32 key_lo = (u32)(2047 - o);
 #pragma unroll
         for (int p = 0; p < G; p++) {
           const u32 tail_bits = chipbits[(size_t)(slot0 + p) * 32 + 31];  // wave-uniform -> scalar load
-          const u32 c1022 = (tail_bits >> 30) & 1u, c1021 = (tail_bits >> 29) & 1u;
-          int ci, cq;
-          if (DOT8) {  // C0 = pop(D) + 8192 - 2 M
-            ci = (int)sh.ones[0] + kHalf + 8 - 2 * (int)acc_i[i][p];
-            cq = (int)sh.ones[1] + kHalf + 8 - 2 * (int)acc_q[i][p];
-          } else {
-            ci = (int)acc_i[i][p];
-            cq = (int)acc_q[i][p];
-          }
-          if (c1022) {  // replica shift is not circular (chip 1022's last b samples are lost, b zeros lead)
-            ci += 2 * (int)head_i - b;
-            cq += 2 * (int)head_q - b;
-          }
+          const bool c1022 = (tail_bits >> 30) & 1u, c1021 = (tail_bits >> 29) & 1u;
+          int ci = base_i + kSign * (int)acc_i[i][p] + (c1022 ? adj_i : 0);
+          int cq = base_q + kSign * (int)acc_q[i][p] + (c1022 ? adj_q : 0);
           if (half) {
-            const u64 two = (u64)sh.chipbits[p][chip_lo >> 5] | ((u64)sh.chipbits[p][(chip_lo >> 5) + 1] << 32);
-            u32 chipwin = (u32)(two >> (chip_lo & 31));                    // chips chip_lo .. chip_lo + 31
-            chipwin = chip_base < 0 ? chipwin << (chip_lo - chip_base) : chipwin;  // bit k = chip (chip_base + k)
-            const int k1 = exists ? (kChips - 1 - q) - chip_base : 1;       // p1 = 1022 - q
-            const u32 cp1 = (chipwin >> k1) & 1u, cp0 = (chipwin >> (k1 - 1)) & 1u;
-            const u32 r_wrap = (cp0 ? low_mask : 0u) | (cp1 ? high_mask : 0u);
-            ci -= (int)pop16(wrap_i ^ r_wrap);
-            cq -= (int)pop16(wrap_q ^ r_wrap);
-            if (odd_tail) {
-              const u32 r_last = (c1021 ? low_mask : 0u) | (c1022 ? high_mask : 0u);
-              ci -= (int)pop16(prev_i ^ r_last);
-              cq -= (int)pop16(prev_q ^ r_last);
+            const u32 sel = (chipwin[p] >> k0) & 3u;   // bit 0 = chip[p1 - 1], bit 1 = chip[p1]
+            const bool s0 = sel & 1u, s1 = sel & 2u;
+            ci -= (int)(s1 ? (s0 ? wrap_pop_i[3] : wrap_pop_i[2]) : (s0 ? wrap_pop_i[1] : wrap_pop_i[0]));
+            cq -= (int)(s1 ? (s0 ? wrap_pop_q[3] : wrap_pop_q[2]) : (s0 ? wrap_pop_q[1] : wrap_pop_q[0]));
+            const u32 r_last = (c1021 ? low_mask : 0u) | (c1022 ? high_mask : 0u);   // wave-uniform
+            ci -= odd_tail ? (int)__popc(prev_i ^ r_last) : 0;
+            cq -= odd_tail ? (int)__popc(prev_q ^ r_last) : 0;
+          }
+          u32 val = in_win ? (u32)mag8_fast(ci, cq) : 0u;
+          const int out_idx = out0 + p * out_pstride;
+          if (DBG) {
+            if (prm.cnt && last_ms && exists && p < n_valid) {
+              prm.cnt[((size_t)out_idx * kBytes + o) * 2 + 0] = (uint16_t)ci;
+              prm.cnt[((size_t)out_idx * kBytes + o) * 2 + 1] = (uint16_t)cq;
             }
           }
-          u32 val = in_win ? (u32)mag8(ci, cq) : 0u;
-          const int out_idx = out0 + p * out_pstride;
-          if (prm.cnt && last_ms && exists && p < n_valid) {
-            prm.cnt[((size_t)out_idx * kBytes + o) * 2 + 0] = (uint16_t)ci;
-            prm.cnt[((size_t)out_idx * kBytes + o) * 2 + 1] = (uint16_t)cq;
-          }
           if (MULTI) {
-            if (prm.per_ms) {  // single-block triplet of this ms (what correlation_search would have returned)
+            if (DBG && prm.per_ms) {  // single-block triplet of this ms (what correlation_search would have returned)
               const u32 key = in_win ? (val << 11) | key_lo : 0u;
               best[p] = key > best[p] ? key : best[p];
               total[p] += val;
@@ -416,15 +426,17 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
             best[p] = key > best[p] ? key : best[p];
             total[p] += val;
           }
-          if (prm.energy && last_ms && exists && p < n_valid)
-            prm.energy[(size_t)out_idx * kBytes + o] = val;
+          if (DBG) {
+            if (prm.energy && last_ms && exists && p < n_valid)
+              prm.energy[(size_t)out_idx * kBytes + o] = val;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the four q epilogues sequential: registers, not ILP, are scarce
       }
     }  // half
 
     // ---- D: workgroup reduction -> one triplet per PRN (per ms in MULTI mode only if asked) ----------------------
-    const bool reduce_now = MULTI ? (prm.per_ms != nullptr) : true;
+    const bool reduce_now = MULTI ? (DBG && prm.per_ms != nullptr) : true;
     if (reduce_now) {
 #pragma unroll
       for (int p = 0; p < G; p++) {
@@ -508,10 +520,18 @@ static void launch_acq_t(hipStream_t s, int n_workgroups, const AcqParams &prm, 
                          const uint32_t *d_chipbits)
 {
   const dim3 grid(n_workgroups), block(kThreads);
-  if (prm.n_ms > 1)
-    hipLaunchKernelGGL((k_acq<G, true, ALGO>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
-  else
-    hipLaunchKernelGGL((k_acq<G, false, ALGO>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  const bool dbg = prm.per_ms || prm.energy || prm.cnt;
+  if (prm.n_ms > 1) {
+    if (dbg)
+      hipLaunchKernelGGL((k_acq<G, true, ALGO, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    else
+      hipLaunchKernelGGL((k_acq<G, true, ALGO, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  } else {
+    if (dbg)
+      hipLaunchKernelGGL((k_acq<G, false, ALGO, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    else
+      hipLaunchKernelGGL((k_acq<G, false, ALGO, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  }
 }
 
 void launch_acq(hipStream_t s, int group, int algo, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,

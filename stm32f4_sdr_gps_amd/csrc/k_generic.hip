@@ -127,19 +127,26 @@ void launch_corr_offsets(hipStream_t s, const uint8_t *d_rep, const uint8_t *d_i
                      d_cnt_i, d_cnt_q, d_corr8);
 }
 
+// out = the generic magnitude; *disagree counts inputs where the grid kernel's trimmed variant (mag8_fast) differs
 __global__ void k_mag8(const uint16_t *__restrict__ cnt_i, const uint16_t *__restrict__ cnt_q, int n,
-                       int16_t *__restrict__ out)
+                       int16_t *__restrict__ out, u32 *__restrict__ disagree)
 {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < n)
-    out[idx] = (int16_t)mag8((int)cnt_i[idx], (int)cnt_q[idx]);
+  if (idx < n) {
+    const int a = mag8((int)cnt_i[idx], (int)cnt_q[idx]);
+    const int b = mag8_fast((int)cnt_i[idx], (int)cnt_q[idx]);
+    out[idx] = (int16_t)a;
+    if (a != b)
+      atomicAdd(disagree, 1u);
+  }
 }
 
-void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q, int n, int16_t *d_out)
+void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q, int n, int16_t *d_out,
+                 uint32_t *d_disagree)
 {
   if (n <= 0)
     return;
-  hipLaunchKernelGGL(k_mag8, dim3((n + 255) / 256), dim3(256), 0, s, d_cnt_i, d_cnt_q, n, d_out);
+  hipLaunchKernelGGL(k_mag8, dim3((n + 255) / 256), dim3(256), 0, s, d_cnt_i, d_cnt_q, n, d_out, d_disagree);
 }
 
 // max (strict: first maximum wins, nothing above 0 leaves phase 0), sum, sum / 2046 over n consecutive offsets
