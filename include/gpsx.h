@@ -31,6 +31,16 @@ extern "C" {
 #define GPSX_IF_HZ              4092000    /* PM/config.h:23                                               */
 #define GPSX_MAX_PRN            210        /* PM/GPS/gps_misc.c:319-341                                    */
 
+/* IF sample formats accepted wherever an entry point takes IF blocks (select with gpsx_set_if_format):
+ *   GPSX_IF_1BIT    the reference's format: MAX2769 I1 (sign) only, 8 samples per byte LSB first, 2046 bytes per ms
+ *   GPSX_IF_2BIT_SM MAX2769 I1/I0 sign + magnitude: 4 samples per byte LSB first, sample n in bits 2(n&3) (sign) and
+ *                   2(n&3)+1 (magnitude), 4092 bytes per ms.  The kernels unpack the pairs in LDS and correlate on the
+ *                   SIGN plane, i.e. exactly what the reference computes from the same front end (it wires I1 only,
+ *                   PM/config.h:16); the magnitude plane is available through gpsx_if_unpack2. */
+#define GPSX_IF_1BIT            0
+#define GPSX_IF_2BIT_SM         1
+#define GPSX_BYTES_PER_MS_2BIT  4092
+
 #define GPSX_OK       0
 #define GPSX_EIO     (-5)    /* a HIP runtime call failed (see gpsx_last_error)   */
 #define GPSX_ENOMEM  (-12)
@@ -59,6 +69,12 @@ const char *gpsx_strerror(int code);
 int         gpsx_version(void);
 /* name / CU count / clock of the device behind the context (for bench reports) */
 int         gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *compute_units, int *clock_khz);
+
+/* Sample format of the IF blocks passed to gpsx_acq_* and gpsx_track_* from now on (default GPSX_IF_1BIT). */
+int gpsx_set_if_format(gpsx_ctx *ctx, int if_format);
+/* Split n_blocks x 4092 bytes of GPSX_IF_2BIT_SM samples into the sign and magnitude bit planes, each n_blocks x 2046
+ * bytes in the 1-bit layout (either output may be NULL).  Host buffers. */
+int gpsx_if_unpack2(gpsx_ctx *ctx, const uint8_t *if_2bit, int n_blocks, uint8_t *sign_plane, uint8_t *magnitude_plane);
 
 /* device memory + HIP-event timing on the context's stream (so a C caller needs no HIP headers) */
 int gpsx_malloc(gpsx_ctx *ctx, void **dptr, size_t bytes);

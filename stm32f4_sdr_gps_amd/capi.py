@@ -18,6 +18,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libgpsx.so")
 
 BYTES_PER_MS = 2046
+BYTES_PER_MS_2BIT = 4092
+IF_1BIT, IF_2BIT_SM = 0, 1
 PHASES_BYTE = 2046
 PHASES_FINE = 16368
 IF_HZ = 4092000
@@ -74,6 +76,8 @@ def load_library() -> C.CDLL:
     lib.gpsx_replica.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
     lib.gpsx_corr_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gpsx_set_if_format.argtypes = [C.c_void_p, C.c_int]
+    lib.gpsx_if_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gpsx_mag8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
     # compat (reference names)
@@ -108,6 +112,7 @@ class Engine:
             raise GpsxError(f"gpsx_create(device={device}) -> {rc}: {self.lib.gpsx_strerror(rc).decode()} "
                             "(the correlator engine needs an MI355X; it has no CPU path)")
         self.h = h
+        self.block_bytes = BYTES_PER_MS
 
     def close(self):
         if getattr(self, "h", None):
@@ -164,6 +169,19 @@ class Engine:
         self._chk(self.lib.gpsx_event_elapsed_ms(self.h, ev0, ev1, C.byref(ms)), "gpsx_event_elapsed_ms")
         return ms.value
 
+    # -- IF sample format (N3 ingest) ---------------------------------------------------------------------------
+    def set_if_format(self, fmt: int):
+        self._chk(self.lib.gpsx_set_if_format(self.h, fmt), "gpsx_set_if_format")
+        self.block_bytes = BYTES_PER_MS_2BIT if fmt == IF_2BIT_SM else BYTES_PER_MS
+
+    def if_unpack2(self, if_2bit: np.ndarray):
+        blocks = np.ascontiguousarray(if_2bit, np.uint8).reshape(-1, BYTES_PER_MS_2BIT)
+        sign = np.zeros((len(blocks), BYTES_PER_MS), np.uint8)
+        mag = np.zeros((len(blocks), BYTES_PER_MS), np.uint8)
+        self._chk(self.lib.gpsx_if_unpack2(self.h, blocks.ctypes.data, len(blocks), sign.ctypes.data, mag.ctypes.data),
+                  "gpsx_if_unpack2")
+        return sign, mag
+
     # -- K1 ---------------------------------------------------------------------------------------------------
     def ca_codes(self, prns) -> np.ndarray:
         prns = np.ascontiguousarray(prns, np.uint8)
@@ -188,7 +206,7 @@ class Engine:
     def acq_grid(self, if_blocks: np.ndarray, prns, want_keys=True, **kw):
         """Host-buffer grid search.  Returns (peaks[n_search, n_prn, n_dopp, n_bits], keys[n_search, n_prn, n_dopp])."""
         prns = np.ascontiguousarray(prns, np.uint8)
-        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, BYTES_PER_MS)
+        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, self.block_bytes)
         g = self.grid_desc(prns, **kw)
         n_bits = 8 if g.phase_mode == PHASES_FINE else 1
         peaks = np.zeros((g.n_search, g.n_prn, g.n_dopp, n_bits), PEAK_DTYPE)
@@ -234,7 +252,7 @@ class Engine:
         return dict(peaks=peaks, keys=keys, per_ms=per_ms, energy=energy, cnt=cnt)
 
     def acq_jobs(self, if_blocks: np.ndarray, jobs: np.ndarray, want_energy=False):
-        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, BYTES_PER_MS)
+        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, self.block_bytes)
         jobs = np.ascontiguousarray(jobs, JOB_DTYPE)
         peaks = np.zeros(len(jobs), PEAK_DTYPE)
         energy = np.zeros((len(jobs), 2046), np.uint32) if want_energy else None

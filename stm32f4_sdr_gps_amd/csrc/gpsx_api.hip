@@ -26,6 +26,7 @@ struct gpsx_ctx {
   uint32_t *d_bits_all = nullptr;    // [211][32]
   uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
   uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
+  int if_format = GPSX_IF_1BIT;
   int algo = kAlgoDot8;              // $GPSX_ACQ_ALGO=sad selects the byte-SAD main loop (A/B measurements)
 
   // grouped tables for the PRN list of the last grid call
@@ -281,6 +282,37 @@ int gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *comp
   return GPSX_OK;
 }
 
+int gpsx_set_if_format(gpsx_ctx *ctx, int if_format)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  if (if_format != GPSX_IF_1BIT && if_format != GPSX_IF_2BIT_SM)
+    return fail(ctx, GPSX_EINVAL, "unknown IF sample format");
+  ctx->if_format = if_format;
+  return GPSX_OK;
+}
+
+int gpsx_if_unpack2(gpsx_ctx *ctx, const uint8_t *if_2bit, int n_blocks, uint8_t *sign_plane, uint8_t *magnitude_plane)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!if_2bit || n_blocks < 1 || (!sign_plane && !magnitude_plane))
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  const size_t in_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS_2BIT, out_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS;
+  if (int rc = arena_reset(ctx, arena_size(in_bytes) + 2 * arena_size(out_bytes))) return rc;
+  uint8_t *d_in = arena_take<uint8_t>(ctx, in_bytes);
+  uint8_t *d_sign = arena_take<uint8_t>(ctx, out_bytes);
+  uint8_t *d_mag = arena_take<uint8_t>(ctx, out_bytes);
+  HIPCHK(ctx, hipMemcpyAsync(d_in, if_2bit, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  launch_unpack2(ctx->stream, d_in, n_blocks, sign_plane ? d_sign : nullptr, magnitude_plane ? d_mag : nullptr);
+  LAUNCHCHK(ctx, "k_unpack2");
+  if (sign_plane)
+    HIPCHK(ctx, hipMemcpyAsync(sign_plane, d_sign, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (magnitude_plane)
+    HIPCHK(ctx, hipMemcpyAsync(magnitude_plane, d_mag, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
+}
+
 int gpsx_malloc(gpsx_ctx *ctx, void **dptr, size_t bytes)
 {
   if (int rc = use_device(ctx)) return rc;
@@ -414,6 +446,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.shard_count = shard_count;
   prm.win_start = g->win_start;
   prm.win_stop = g->win_stop;
+  prm.if_format = ctx->if_format;
   prm.jobs = nullptr;
   prm.peaks = d_peaks;
   prm.per_ms = d_per_ms;
@@ -439,7 +472,7 @@ int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blo
   if (!if_blocks || !peaks)
     return fail(ctx, GPSX_EINVAL, "null host pointer");
   const size_t n_peaks = gpsx_acq_peaks_count(g), n_keys = gpsx_acq_keys_count(g);
-  const size_t if_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS;
+  const size_t if_bytes = (size_t)n_blocks * (ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS);
   if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_peaks * sizeof(gpsx_peak_t)) +
                                     arena_size(n_keys * sizeof(int64_t))))
     return rc;
@@ -479,7 +512,7 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
       return fail(ctx, GPSX_EINVAL, "carrier frequency outside (0, fs)");
     recs[i] = AcqJobRec{j.block, j.prn, j.freq_hz, j.offset_bits, j.win_start, j.win_stop, i};
   }
-  const size_t if_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS;
+  const size_t if_bytes = (size_t)n_blocks * (ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS);
   const size_t e_count = energy_opt ? (size_t)n_jobs * GPSX_PHASES_BYTE : 0;
   if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_jobs * sizeof(AcqJobRec)) +
                                     arena_size(n_jobs * sizeof(gpsx_peak_t)) + arena_size(e_count * 4)))
@@ -495,6 +528,7 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
   AcqParams prm{};
   prm.n_ms = n_ms;
   prm.n_bits = 1;
+  prm.if_format = ctx->if_format;
   prm.jobs = d_jobs;
   prm.peaks = d_peaks;
   prm.energy = d_energy;
@@ -515,7 +549,7 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   if (int rc = use_device(ctx)) return rc;
   if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
-  launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), d_st, n_ch, ctx->d_chips_all, nullptr,
+  launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, d_st, n_ch, ctx->d_chips_all,
                    d_iq_out);
   LAUNCHCHK(ctx, "k_track_epl");
   return GPSX_OK;
@@ -529,13 +563,14 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   for (int i = 0; i < n_ch; i++)
     if (st[i].prn < 1 || st[i].prn > GPSX_MAX_PRN)
       return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
-  if (int rc = arena_reset(ctx, arena_size(GPSX_BYTES_PER_MS + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
+  const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
+  if (int rc = arena_reset(ctx, arena_size(blk_bytes + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
                                     arena_size((size_t)n_ch * 12)))
     return rc;
-  uint8_t *d_if = arena_take<uint8_t>(ctx, GPSX_BYTES_PER_MS + 2);
+  uint8_t *d_if = arena_take<uint8_t>(ctx, blk_bytes + 2);
   gpsx_trk_state_t *d_st = arena_take<gpsx_trk_state_t>(ctx, n_ch);
   int16_t *d_iq = arena_take<int16_t>(ctx, (size_t)n_ch * 6);
-  HIPCHK(ctx, hipMemcpyAsync(d_if, if_block, GPSX_BYTES_PER_MS, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_if, if_block, blk_bytes, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
   if (int rc = gpsx_track_epl_batch_dev(ctx, d_if, d_st, n_ch, d_iq)) return rc;
   HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));

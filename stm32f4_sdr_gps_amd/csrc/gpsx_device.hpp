@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/gpsx.h"
+
 namespace gpsx {
 
 constexpr int kChips = 1023;          // C/A code length
@@ -84,6 +86,28 @@ __device__ __forceinline__ int mag8_fast(int cnt_i, int cnt_q)
   r = res_dn <= 0.0f ? r_dn : r;
   r = res_up > 0.0f ? r_up : r;
   return (int)r;
+}
+
+// 16 even-position bits of a word gathered into the low half (bit 2k -> bit k): the sign plane of 16 two-bit samples
+__device__ __forceinline__ u32 even_bits16(u32 x)
+{
+  x &= 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+  x = (x | (x >> 4)) & 0x00FF00FFu;
+  x = (x | (x >> 8)) & 0x0000FFFFu;
+  return x;
+}
+
+// One 16-bit word (16 samples) of the sign plane of IF block `blk`: read straight from a 1-bit block, or unpacked from
+// sixteen sign/magnitude pairs of a 2-bit block.  `blk` is 2-byte aligned in either format.
+__device__ __forceinline__ uint16_t load_sign16(const uint8_t *blk, int word, int if_format)
+{
+  if (if_format == GPSX_IF_2BIT_SM) {
+    const uint16_t *p = reinterpret_cast<const uint16_t *>(blk) + 2 * word;
+    return (uint16_t)even_bits16((u32)p[0] | ((u32)p[1] << 16));
+  }
+  return reinterpret_cast<const uint16_t *>(blk)[word];
 }
 
 __device__ __forceinline__ u32 pop16(u32 v) { return (u32)__popc(v & 0xFFFFu); }

@@ -33,6 +33,7 @@ struct AcqParams {
   int32_t n_bits;
   int32_t shard_index, shard_count;
   int32_t win_start, win_stop;
+  int32_t if_format;        // GPSX_IF_1BIT / GPSX_IF_2BIT_SM
   // explicit job list (job mode)
   const AcqJobRec *jobs;
   // outputs (optional ones may be null)
@@ -70,8 +71,10 @@ void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q
 void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int first_offset, gpsx_peak_t *d_peak);
 
 // K2+K3+K5 tracking correlators, one workgroup per channel
-void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_chips,
-                      const int32_t *d_slot_of_channel, int16_t *d_iq);
+void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
+                      const uint8_t *d_chips, int16_t *d_iq);
+// N3: 2-bit sign/magnitude samples -> two 1-bit planes
+void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag);
 void launch_rewind(hipStream_t s, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps);
 
 }  // namespace gpsx

@@ -170,10 +170,11 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
   for (int ms = 0; ms < prm.n_ms; ms++) {
     const bool last_ms = ms == prm.n_ms - 1;
     // ---- A1: IF block -> LDS (coalesced 16-bit loads: a block starts on an even byte) -------------------------
-    const uint16_t *blk = reinterpret_cast<const uint16_t *>(if_blocks + (size_t)(first_block + ms) * kBytes);
+    const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
+    const uint8_t *blk = if_blocks + (size_t)(first_block + ms) * block_bytes;
     __syncthreads();  // previous iteration's readers of sh.* are done
-    for (int i = tid; i < 1024; i += kThreads)
-      sh.x[i] = i < kWords16 ? blk[i] : (uint16_t)0;
+    for (int i = tid; i < 1024; i += kThreads)   // 2-bit captures are unpacked to their sign plane on the way into LDS
+      sh.x[i] = i < kWords16 ? load_sign16(blk, i, prm.if_format) : (uint16_t)0;
     if (DOT8) {
       for (int i = tid; i < 4 * kFullWords; i += kThreads)
         (&sh.full[0][0][0])[i] = 0;

@@ -194,9 +194,9 @@ void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int firs
 //   (wraps to 2045), late = prompt + 1 (wraps to 0)                                   PM/GPS/tracking.c:115-130
 //   carrier NCO continues from if_freq_accum at (float)IF + if_freq_offset_hz and is stored back  gps_misc.c:244-274
 // Wave w < 3 computes offset E/P/L; the IF block is read once per channel with coalesced 16-bit loads.
-__global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ if_block, gpsx_trk_state_t *__restrict__ st,
-                                                   int n_ch, const uint8_t *__restrict__ chips_all,
-                                                   int16_t *__restrict__ iq_out)
+__global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ if_block, int if_format,
+                                                   gpsx_trk_state_t *__restrict__ st, int n_ch,
+                                                   const uint8_t *__restrict__ chips_all, int16_t *__restrict__ iq_out)
 {
   __shared__ __attribute__((aligned(4))) uint8_t s_i[2048];
   __shared__ __attribute__((aligned(4))) uint8_t s_q[2048];
@@ -216,9 +216,8 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
   const float freq_hz = (float)kIfHz + state.if_freq_offset_hz;
   const u32 step = nco_step_per_word(freq_hz);
 
-  const uint16_t *blk = reinterpret_cast<const uint16_t *>(if_block);
   for (int i = tid; i < 1024; i += 256) {
-    s_x[i] = i < kWords16 ? blk[i] : (uint16_t)0;
+    s_x[i] = i < kWords16 ? load_sign16(if_block, i, if_format) : (uint16_t)0;
     // replica word i (K2)
     const u32 prev = (i > 0 && i <= kWords16) ? chips[i - 1] : 0u;
     const u32 cur = i < kWords16 ? chips[i] : 0u;
@@ -256,12 +255,37 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
     st[ch].if_freq_accum = state.if_freq_accum + step * (u32)kWords32;
 }
 
-void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_chips,
-                      const int32_t *, int16_t *d_iq)
+void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
+                      const uint8_t *d_chips, int16_t *d_iq)
 {
   if (n_ch <= 0)
     return;
-  hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, d_st, n_ch, d_chips, d_iq);
+  hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips, d_iq);
+}
+
+// N3 ingest: MAX2769 sign/magnitude pairs -> sign plane and magnitude plane in the reference's 1-bit layout.
+// One thread per output 16-bit word (16 samples = 4 input bytes); loads and stores are coalesced.
+__global__ void k_unpack2(const uint8_t *__restrict__ in, int n_blocks, uint8_t *__restrict__ sign,
+                          uint8_t *__restrict__ mag)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_blocks * kWords16)
+    return;
+  const int blk = idx / kWords16, w = idx - blk * kWords16;
+  const uint16_t *p = reinterpret_cast<const uint16_t *>(in + (size_t)blk * GPSX_BYTES_PER_MS_2BIT) + 2 * w;
+  const u32 pairs = (u32)p[0] | ((u32)p[1] << 16);
+  if (sign)
+    reinterpret_cast<uint16_t *>(sign + (size_t)blk * kBytes)[w] = (uint16_t)even_bits16(pairs);
+  if (mag)
+    reinterpret_cast<uint16_t *>(mag + (size_t)blk * kBytes)[w] = (uint16_t)even_bits16(pairs >> 1);
+}
+
+void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag)
+{
+  const int n = n_blocks * kWords16;
+  if (n <= 0)
+    return;
+  hipLaunchKernelGGL(k_unpack2, dim3((n + 255) / 256), dim3(256), 0, s, d_in, n_blocks, d_sign, d_mag);
 }
 
 // gps_rewind_if_phase: accum += (uint32)((uint64)step_per_sample * 16368 * steps)

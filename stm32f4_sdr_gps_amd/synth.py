@@ -53,10 +53,32 @@ class Sat:
     nav_bits: np.ndarray | None = None  # +-1 per 20 ms, optional
 
 
-def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, start_ms: int = 0) -> np.ndarray:
-    """Return uint8 array [n_ms, 2046] of packed 1-bit samples."""
+def pack_2bit(sign_bits: np.ndarray, mag_bits: np.ndarray) -> np.ndarray:
+    """16368 sign bits + 16368 magnitude bits -> 4092 bytes of MAX2769-style pairs (GPSX_IF_2BIT_SM: sample n in bits
+    2(n & 3) (sign) and 2(n & 3) + 1 (magnitude) of byte n >> 2)."""
+    pairs = np.empty(2 * len(sign_bits), np.uint8)
+    pairs[0::2] = sign_bits
+    pairs[1::2] = mag_bits
+    return np.packbits(pairs, bitorder="little")
+
+
+def read_if_file(path: str, two_bit: bool = False, max_ms: int | None = None) -> np.ndarray:
+    """Raw IF capture file as the reference's replay tool streams it (PC_SpiLight/Readme.txt: `-i rec_file.bin`): a flat
+    byte stream, 2046 bytes (1-bit) or 4092 bytes (2-bit) per millisecond; a trailing partial block is dropped."""
+    per_ms = 4092 if two_bit else BYTES_PER_MS
+    raw = np.fromfile(path, dtype=np.uint8)
+    n = len(raw) // per_ms
+    if max_ms is not None:
+        n = min(n, max_ms)
+    return raw[:n * per_ms].reshape(n, per_ms)
+
+
+def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, start_ms: int = 0,
+            two_bit: bool = False, mag_threshold: float = 0.6) -> np.ndarray:
+    """Return uint8 array [n_ms, 2046] of packed 1-bit samples, or [n_ms, 4092] of sign/magnitude pairs if two_bit
+    (magnitude bit = |x| > mag_threshold)."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    out = np.zeros((n_ms, BYTES_PER_MS), np.uint8)
+    out = np.zeros((n_ms, 4092 if two_bit else BYTES_PER_MS), np.uint8)
     codes = {s.prn: (1.0 - 2.0 * ca_code(s.prn).astype(np.float64)) for s in sats}
     n0 = np.arange(SAMPLES_PER_MS, dtype=np.float64)
     for ms in range(n_ms):
@@ -71,7 +93,10 @@ def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, s
             ph = 2.0 * np.pi * ((IF_HZ + s.doppler_hz) / FS_HZ) * n + s.phase_rad
             x = x + s.amp * d * codes[s.prn][chip] * np.cos(ph)
         bits = (x >= 0).astype(np.uint8)
-        out[ms] = np.packbits(bits, bitorder="little")
+        if two_bit:
+            out[ms] = pack_2bit(bits, (np.abs(x) > mag_threshold).astype(np.uint8))
+        else:
+            out[ms] = np.packbits(bits, bitorder="little")
     return out
 
 

@@ -427,3 +427,52 @@ def test_track_epl_four_sv_default_table_locks_on_signal(eng, stream):
         power += np.stack([iq[:, 0] ** 2 + iq[:, 1] ** 2, iq[:, 2] ** 2 + iq[:, 3] ** 2, iq[:, 4] ** 2 + iq[:, 5] ** 2], 1)
     assert (power[:, 1] > power[:, 0]).all() and (power[:, 1] > power[:, 2]).all()
     assert (np.sqrt(power[:, 1] / 12) > 1500).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N3: 2-bit (MAX2769 sign + magnitude) ingest
+def test_two_bit_ingest_unpack_and_sign_plane_parity(oracle, tmp_path):
+    """2-bit captures are unpacked on the GPU (k_unpack2, and inside k_acq / k_track_epl on the way into LDS); the
+    correlation runs on the sign plane, so every result must equal the 1-bit path on the same samples."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    sats = [synth.Sat(5, 912.5, 1600.0, 0.6, 0.3), synth.Sat(30, 2018.0, 13000.0, 0.6, 4.0)]
+    one = synth.make_if(4, sats, seed=21)
+    two = synth.make_if(4, sats, seed=21, two_bit=True)
+    assert two.shape == (4, 4092)
+    eng = capi.Engine(0)
+    try:
+        sign, mag = eng.if_unpack2(two)
+        assert np.array_equal(sign, one)
+        pairs = np.unpackbits(two, axis=1, bitorder="little")
+        assert np.array_equal(mag, np.packbits(pairs[:, 1::2], axis=1, bitorder="little"))
+        # file round trip through the raw-stream reader (the replay tool's on-disk format)
+        path = tmp_path / "rec_file.bin"
+        two.tofile(path)
+        assert np.array_equal(synth.read_if_file(str(path), two_bit=True), two)
+
+        prns = np.array([5, 30, 7], np.uint8)
+        ref_peaks, ref_keys = eng.acq_grid(one, prns, n_search=2, n_ms=2, dopp_min_hz=500, dopp_step_hz=500, n_dopp=4)
+        st0 = np.zeros(2, capi.TRK_DTYPE)
+        st0["prn"], st0["code_phase_fine"], st0["if_freq_offset_hz"] = [5, 30], [1600.0, 13003.0], [912.5, 2018.0]
+        st_a = st0.copy()
+        iq_a = eng.track_epl(one[3], st_a)
+        eng.set_if_format(capi.IF_2BIT_SM)
+        peaks, keys = eng.acq_grid(two, prns, n_search=2, n_ms=2, dopp_min_hz=500, dopp_step_hz=500, n_dopp=4)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(peaks[f], ref_peaks[f])
+        assert np.array_equal(keys, ref_keys)
+        jobs = np.zeros(1, capi.JOB_DTYPE)
+        jobs[0] = (1, 1, 5, float(IF_HZ + 900), 2, 100, 400)
+        pk2, _ = eng.acq_jobs(two, jobs)
+        st_b = st0.copy()
+        iq_b = eng.track_epl(two[3], st_b)
+        assert np.array_equal(iq_a, iq_b) and np.array_equal(st_a, st_b)
+        eng.set_if_format(capi.IF_1BIT)
+        pk1, _ = eng.acq_jobs(one, jobs)
+        assert _peak_tuple(pk1[0]) == _peak_tuple(pk2[0])
+        want, _, _ = oracle.search_job(one[1:2], 1, oracle.ca_code(5), float(IF_HZ + 900), 2, 100, 400)
+        assert _peak_tuple(pk2[0]) == (want["max_val"], want["phase"], want["sum"], want["avr"])
+        with pytest.raises(capi.GpsxError):
+            eng.set_if_format(7)
+    finally:
+        eng.close()
