@@ -51,6 +51,7 @@ struct AcqShared {
   u32 ones[2];                   // ALGO_DOT8: pop(D) per stream
   u32 chipbits[G][34];           // 32 words of chips + zero pad for the 64-bit window reads
   u32 red[4][G][2];              // cross-wave reduction scratch
+  u32 carry[2 * G][kThreads];    // each lane's running (best key, sum) per PRN, parked here while the dot loop runs
 };
 
 __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
@@ -94,10 +95,11 @@ __device__ __forceinline__ void add_saturation_deficit(u32 (&acc)[4][G], const u
 }  // namespace
 
 // waves per SIMD the register allocator must leave room for: the byte-SAD single-block kernel fits 128 VGPRs (4 waves);
-// the dot-product and multi-block variants carry more live state and get 168 (3 waves) instead of spilling
+// the dot-product variant carries more live state and gets 168 (3 waves), the multi-block variants (64 extra energy
+// registers) 256 (2 waves), instead of spilling to scratch
 // DBG: the optional inspection outputs (raw counts, energy plane, per-block triplets) exist only in this instantiation
 template <int G, bool MULTI, int ALGO, bool DBG>
-__global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
+__global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                   const u32 *__restrict__ cw, const u32 *__restrict__ chipbits)
 {
   constexpr bool DOT8 = ALGO == kAlgoDot8;
@@ -300,9 +302,11 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
       } else {
         // lane's offsets q = 32 a + c + 8 i (a = tid / 8, c = tid % 8): nibble q + 8 j sits in dword 4 a + i + j at bit 4 c,
         // so step j uses windows W[j .. j + 3] of the lane's stream W[m] = alignbit(dw[m + 1], dw[m], 4 c)
-        const u32 *ni = sh.s[half][0] + 4 * (tid >> 3);
-        const u32 *nq = sh.s[half][1] + 4 * (tid >> 3);
-        const u32 shn = 4u * (u32)(tid & 7);
+        int tid_m = tid;
+        asm volatile("" : "+v"(tid_m));   // as in the epilogue: recompute the lane's addresses rather than keep them live
+        const u32 *ni = sh.s[half][0] + 4 * (tid_m >> 3);
+        const u32 *nq = sh.s[half][1] + 4 * (tid_m >> 3);
+        const u32 shn = 4u * (u32)(tid_m & 7);
         u32 wi[4], wq[4];
         u32 prev_i = ni[3], prev_q = nq[3];
 #pragma unroll
@@ -335,12 +339,26 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
         }
         // deficit of the saturated windows: E = sum_c chip[c] * F[q + c], only where such windows exist
         if (sh.any_full[half][0])
-          add_saturation_deficit<G>(acc_i, sh.full[half][0], chipbits + (size_t)slot0 * 32, tid);
+          add_saturation_deficit<G>(acc_i, sh.full[half][0], chipbits + (size_t)slot0 * 32, tid_m);
         if (sh.any_full[half][1])
-          add_saturation_deficit<G>(acc_q, sh.full[half][1], chipbits + (size_t)slot0 * 32, tid);
+          add_saturation_deficit<G>(acc_q, sh.full[half][1], chipbits + (size_t)slot0 * 32, tid_m);
       }
 
       // ---- C: per-hypothesis corrections, magnitude, running search result -------------------------------------
+      // The running (best, total) of the even offsets were parked in LDS so that they do not occupy registers during
+      // the dot loop of the odd offsets (lane-private columns: conflict-free).
+      if (half == 1) {
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          best[p] = sh.carry[2 * p][tid];
+          total[p] = sh.carry[2 * p + 1][tid];
+        }
+      }
+      // (tid laundered through an empty asm: everything derived from it below -- offsets, window tests, LDS addresses --
+      //  is then recomputed here, a handful of ALU ops, instead of being hoisted out of the millisecond loop and held
+      //  in ~25 registers across the dot loop, which is what pushed the kernel into scratch spills)
+      int tid_e = tid;
+      asm volatile("" : "+v"(tid_e));
       // Wave-uniform pieces first.  The counts are affine in the accumulators: cnt = base + sign * acc.
       const int base_i = DOT8 ? __builtin_amdgcn_readfirstlane((int)sh.ones[0]) + kHalf + 8 : 0;   // C0 = pop(D) + 8192 - 2 M
       const int base_q = DOT8 ? __builtin_amdgcn_readfirstlane((int)sh.ones[1]) + kHalf + 8 : 0;
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
         wrap_pop_q[k] = (u32)__builtin_amdgcn_readfirstlane((int)pop16(wrap_q ^ r));
       }
       // One 32-chip window per PRN covers chips p1 - 1, p1 of the lane's four offsets (they lie within 26 chips).
-      const int q_hi = chip_offset_of<ALGO>(tid, 3);
+      const int q_hi = chip_offset_of<ALGO>(tid_e, 3);
       const int chip_base = kChips - 2 - q_hi;   // lowest chip needed; bit k of chipwin = chip (chip_base + k)
       const int chip_lo = chip_base < 0 ? 0 : chip_base;
       u32 chipwin[G];
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int q = chip_offset_of<ALGO>(tid, i);
+        const int q = chip_offset_of<ALGO>(tid_e, i);
         const int o = 2 * q + half;
         const bool exists = q < kChips;
         const bool in_win = exists && o >= win_start && o < win_stop;
@@ -433,6 +451,13 @@ __global__ __launch_bounds__(kThreads, (ALGO == kAlgoDot8 || MULTI) ? 3 : 4) voi
           }
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the four q epilogues sequential: registers, not ILP, are scarce
+      }
+      if (half == 0) {
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          sh.carry[2 * p][tid] = best[p];
+          sh.carry[2 * p + 1][tid] = total[p];
+        }
       }
     }  // half
 
