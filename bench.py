@@ -15,7 +15,7 @@ units are dealt round-robin to the ranks (per-GPU work is constant: weak scaling
 Prints one JSON line on rank 0.  `roofline` is priced the way SURVEY.md 8(d) prescribes for a bytes-based roofline
 (6138 operand bytes per hypothesis as the reference streams them); the kernel itself keeps its operands in LDS and is
 bound by integer VALU issue, which `roofline_valu` prices (2048 lane-ops per hypothesis in the reference's XOR/popcount
-formulation; the SAD formulation issues ~4x fewer).  `cpu_baseline` times the reference's own C (oracle/_ref, built in
+formulation; the dot8 kernel issues ~6x fewer).  `cpu_baseline` times the reference's own C (oracle/_ref, built in
 place from the reference tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.
 """
 import argparse
@@ -263,7 +263,7 @@ def main():
                 "unit": "Tlane-op/s",
                 "frac": ach_tops / VALU_INT_PEAK_TOPS,
                 "note": "algorithmic lane-ops = 2048/hypothesis (reference XOR+popcount formulation); the SAD kernel "
-                        "issues ~560/hypothesis, so frac > 1 is possible; issued-op efficiency is in profiles/",
+                        "issues ~350/hypothesis, so frac > 1 is possible; issued-op efficiency is in profiles/",
             },
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }
