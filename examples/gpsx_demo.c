@@ -1,0 +1,124 @@
+/* examples/gpsx_demo.c -- a plain C host driving the MI355X correlator engine through the reference's own interface.
+ *
+ * This is the shape of the firmware's main loop (Firmware/project_main/main.c:45-168 of iliasam/STM32F4_SDR_GPS) on
+ * a hosted system: the 4-satellite channel table with PRN + Doppler-hint inputs, acquisition steps on captured
+ * milliseconds until every channel is acquired, then 17-slot multiplexed tracking steps -- with libgpsx.so in place of
+ * gps_misc.c / acquisition.c / tracking.c.  The capture driver is replaced by a raw IF file (1 bit per sample, LSB
+ * first, 2046 bytes per millisecond: the format PC_SpiLight replays), and the small channel sequencer below restates
+ * what gps_master_handling() does for acquisition (gps_master.c:68-129).
+ *
+ *   gcc -O2 -I include examples/gpsx_demo.c -L stm32f4_sdr_gps_amd/lib -lgpsx \
+ *       -Wl,-rpath,$PWD/stm32f4_sdr_gps_amd/lib -lm -o gpsx_demo
+ *   ./gpsx_demo capture.bin [max_ms]
+ *
+ * Prints one line per channel: acquisition result and the tracking loop state after the last millisecond.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpsx_compat.h"
+
+#define BLOCK_BYTES (PRN_SPI_WORDS_CNT * 2)
+
+static gps_ch_t gps_channels[GPS_SAT_CNT];
+static int gps_start_flag = 1;
+
+/* channel sequencing during acquisition; returns non-zero while any channel still needs acquisition */
+static int master_handling(gps_ch_t *ch)
+{
+  int need_acq = 0, need_freq = 0, stage3_ready = 0;
+  if (gps_start_flag) {
+    gps_start_flag = 0;
+    acquisition_start_channel(&ch[0]);
+  }
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    if (ch[i].acq_data.state != GPS_ACQ_DONE) need_acq = 1;
+    if (ch[i].acq_data.state < GPS_ACQ_FREQ_SEARCH_DONE) need_freq = 1;
+    if (ch[i].acq_data.state == GPS_ACQ_CODE_PHASE_SEARCH2_DONE) stage3_ready++;
+  }
+  if (need_acq) {
+    for (int i = 0; i < GPS_SAT_CNT - 1; i++) {
+      if (ch[i].acq_data.state == GPS_ACQ_FREQ_SEARCH_DONE && ch[i + 1].acq_data.state == GPS_ACQ_NEED_FREQ_SEARCH) {
+        acquisition_start_channel(&ch[i + 1]);   /* frequency search (or hint) one channel at a time */
+        return need_acq;
+      }
+    }
+  }
+  if (!need_freq && need_acq) {
+    for (int i = 0; i < GPS_SAT_CNT; i++) {
+      if (ch[i].acq_data.state == GPS_ACQ_FREQ_SEARCH_DONE)
+        acquisition_start_code_search_channel(&ch[i]);
+      if (stage3_ready == GPS_SAT_CNT)
+        acquisition_start_code_search3_channel(&ch[i]);
+    }
+  }
+  if (!need_acq) {
+    for (int i = 0; i < GPS_SAT_CNT; i++)
+      if (ch[i].tracking_data.state == GPS_TRACKNG_IDLE)
+        ch[i].tracking_data.state = GPS_NEED_PRE_TRACK;
+  }
+  return need_acq;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 2) {
+    fprintf(stderr, "usage: %s capture.bin [max_ms]\n", argv[0]);
+    return 2;
+  }
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) {
+    perror(argv[1]);
+    return 2;
+  }
+  const long max_ms = argc > 2 ? atol(argv[2]) : 0x7fffffffL;
+
+  /* PM/main.c:54-73: the firmware's default table */
+  static const uint8_t prn[GPS_SAT_CNT] = {5, 14, 20, 30};
+  static const int16_t hint_hz[GPS_SAT_CNT] = {900, 4000, -1000, 2000};
+  gps_fill_summ_table();                    /* opens the GPU context; aborts loudly if there is none */
+  memset(gps_channels, 0, sizeof gps_channels);
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    gps_channels[i].prn = prn[i];
+    gps_channels[i].acq_data.given_freq_offset_hz = hint_hz[i];
+    gps_channell_prepare(&gps_channels[i]);
+  }
+
+  uint8_t block[BLOCK_BYTES];
+  long t = 0, acquired_at = -1;
+  gpsx_compat_set_packet_cnt(0);
+  int need_acq = master_handling(gps_channels);
+  for (; t < max_ms && fread(block, 1, BLOCK_BYTES, f) == BLOCK_BYTES; t++) {
+    gpsx_compat_set_packet_cnt((uint32_t)t);           /* the capture driver's 1 ms tick */
+    if (need_acq) {
+      acquisition_process(gps_channels, block);         /* main_process_acq_data, PM/main.c:163-168 */
+      need_acq = master_handling(gps_channels);
+      if (!need_acq)
+        acquired_at = t;
+    } else {
+      const long slot = t % (TRACKING_CH_LENGTH * GPS_SAT_CNT + 1);   /* main_fast_data_proc, PM/main.c:134-158 */
+      long sat = slot / TRACKING_CH_LENGTH;
+      if (sat >= GPS_SAT_CNT) sat = 0;
+      const uint8_t index = slot == TRACKING_CH_LENGTH * GPS_SAT_CNT ? 0xFF : (uint8_t)(slot % TRACKING_CH_LENGTH);
+      gps_tracking_process(&gps_channels[sat], block, index);
+      need_acq = master_handling(gps_channels);
+    }
+  }
+  fclose(f);
+
+  printf("processed_ms=%ld acquired_at_ms=%ld\n", t, acquired_at);
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    const gps_ch_t *c = &gps_channels[i];
+    uint32_t fine_bits, freq_bits;
+    memcpy(&fine_bits, &c->tracking_data.code_phase_fine, 4);
+    memcpy(&freq_bits, &c->tracking_data.if_freq_offset_hz, 4);
+    printf("PRN=%u acq_state=%d code_phase=%u doppler_hz=%d trk_state=%d code_phase_fine=%.3f(0x%08x) "
+           "if_freq_offset_hz=%.3f(0x%08x) nco=0x%08x snr_db=%.2f bit_sync=%u\n",
+           c->prn, (int)c->acq_data.state, c->acq_data.found_code_phase, c->acq_data.found_freq_offset_hz,
+           (int)c->tracking_data.state, c->tracking_data.code_phase_fine, fine_bits, c->tracking_data.if_freq_offset_hz,
+           freq_bits, c->tracking_data.if_freq_accum, c->tracking_data.snr_value, c->nav_data.period_sync_ok_flag);
+  }
+  gpsx_compat_shutdown();
+  return 0;
+}

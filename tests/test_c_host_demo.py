@@ -1,0 +1,61 @@
+"""The plain-C host (examples/gpsx_demo.c) built with gcc against libgpsx.so: "host code stays in C".
+CPU: it compiles and links with nothing but include/gpsx_compat.h, and refuses to run without a GPU (abort + message).
+GPU: it drives acquisition -> pre-track -> tracking over 3000 ms of IF read from a raw capture file and must end in
+exactly the channel state the reference's own C reaches on that stream (tests/golden/f7_steps_hints.npz)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from golden_util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def demo_exe():
+    from stm32f4_sdr_gps_amd import build
+    build.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "gpsx_demo"], stdout=subprocess.DEVNULL)
+    return os.path.join(ROOT, "examples", "gpsx_demo")
+
+
+def _have_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_have_gpu(), reason="a GPU is present")
+def test_c_host_builds_and_fails_loudly_without_gpu(demo_exe, tmp_path):
+    cap = tmp_path / "cap.bin"
+    np.zeros(2046 * 4, np.uint8).tofile(cap)
+    res = subprocess.run([demo_exe, str(cap)], capture_output=True, text=True)
+    assert res.returncode != 0                     # abort(), no silent CPU path
+    assert "no CPU path" in res.stderr and "gpsx_create" in res.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_reaches_the_reference_end_state(demo_exe, tmp_path):
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_hints.npz")
+    n_ms = int(g["n_ms"])
+    cap = tmp_path / "rec_file.bin"
+    synth.four_sv_with_nav(n_ms, seed=7).tofile(cap)
+    out = subprocess.run([demo_exe, str(cap)], capture_output=True, text=True, check=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("PRN=")]
+    assert len(lines) == 4 and f"processed_ms={n_ms}" in out
+    last = g["snaps"][-1]
+    for i, line in enumerate(lines):
+        m = re.search(r"acq_state=(\d+) code_phase=(\d+) doppler_hz=(-?\d+) trk_state=(\d+) code_phase_fine=\S+\(0x(\w+)\) "
+                      r"if_freq_offset_hz=\S+\(0x(\w+)\) nco=0x(\w+)", line)
+        acq_state, code_phase, dopp, trk_state = (int(m.group(k)) for k in range(1, 5))
+        fine_bits, freq_bits, nco = (int(m.group(k), 16) for k in (5, 6, 7))
+        a = last[i]
+        assert acq_state == int(a[16:20].view("<i4")[0]) == 9
+        assert code_phase == int(a[6:8].view("<u2")[0])
+        assert dopp == int(a[2:4].view("<i2")[0])
+        assert trk_state == int(a[60 + 148:60 + 152].view("<i4")[0]) == 4
+        assert fine_bits == int(a[60 + 80:60 + 84].view("<u4")[0])        # float loop state, bit for bit
+        assert freq_bits == int(a[60 + 4:60 + 8].view("<u4")[0])
+        assert nco == int(a[60 + 8:60 + 12].view("<u4")[0])
