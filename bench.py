@@ -127,18 +127,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hooks (tests/test_gpu_bench_dist.py, one-GPU boxes): GPSX_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and
+    # GPSX_BENCH_BACKEND=gloo swaps RCCL for gloo (RCCL refuses two ranks on one device); the sharded data path is unchanged.
+    dev_index = 0 if os.environ.get("GPSX_BENCH_SHARE_DEVICE") == "1" else local_rank
+    backend = os.environ.get("GPSX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("GPSX_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL at world 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from stm32f4_sdr_gps_amd import capi, synth  # after torch: one HIP runtime per process
 
     stream = torch.cuda.Stream(device=dev)
-    eng = capi.Engine(local_rank, stream=stream.cuda_stream)
+    eng = capi.Engine(dev_index, stream=stream.cuda_stream)
     dev_name, cus, clk_khz = eng.device_info()
 
     n_search = args.searches * world
@@ -207,6 +214,20 @@ def main():
     keys = d_keys.cpu().numpy()
     energy = keys >> 14
     assert (energy > 0).all() and energy.max() > 1500 * min(1.0, args.amp_scale), "acquisition grid produced no peaks"
+
+    if use_dist and os.environ.get("GPSX_BENCH_VERIFY") == "1":
+        # the merged table must equal what one GPU computes for the whole grid (checked outside the timed region)
+        g_all = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+                              dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
+        with torch.cuda.stream(stream):
+            d_keys_all = torch.zeros_like(d_keys)
+            rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_all), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
+                                           d_keys_all.data_ptr(), None, None, None)
+            assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_keys_all.cpu(), torch.from_numpy(keys)), "sharded sweep + all-reduce != unsharded sweep"
+        if rank == 0:
+            print("VERIFY sharded == unsharded", flush=True)
 
     if rank == 0:
         total_hyp = float(args.steps) * n_search * HYP_PER_SEARCH
