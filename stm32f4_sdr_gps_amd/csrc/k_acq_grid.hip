@@ -232,27 +232,60 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) 
         sh.s[arr >> 1][arr & 1][dw] = packed;
       }
     } else {
-      // 4-bit sums min(S, 15), eight per dword; windows with S == 16 are flagged in the bit plane `full`
-      for (int m = tid; m < 4 * kNibDwords; m += kThreads) {
-        const int arr = m / kNibDwords;
-        const int dw = m - arr * kNibDwords;
-        const int t0 = b + 8 * (arr >> 1);
-        const u32 *dd = sh.d[arr & 1];
-        u32 packed = 0;
+      // 4-bit sums min(S, 15), eight per dword; windows with S == 16 are flagged in the bit plane `full`.
+      // One task = one dword of BOTH t0 arrays of one stream: the sixteen windows D[16 k + b, +16) and D[16 k + b + 8, +16),
+      // k = k0 .. k0 + 7, are cut from five funnel-shifted words (consecutive windows are consecutive 16-bit fields).
+      for (int m = tid; m < 2 * kNibDwords; m += kThreads) {
+        const int iq = m / kNibDwords;
+        const int dw = m - iq * kNibDwords;
+        const u32 *dd = sh.d[iq];
+        const int kd0 = dw * 8;   // index in the doubled array
+        const int k0 = kd0 >= 2 * kChips ? kd0 - 2 * kChips : (kd0 >= kChips ? kd0 - kChips : kd0);
+        u32 sum0[8], sum1[8];
+        if (k0 + 7 < kChips) {
+          const int w = k0 >> 1;
+          const u32 sft = 16u * (u32)(k0 & 1) + (u32)b;
+          u32 x[5];
+#pragma unroll
+          for (int j = 0; j < 5; j++)
+            x[j] = __builtin_amdgcn_alignbit(dd[w + j + 1], dd[w + j], sft);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            sum0[2 * j] = pop16(x[j]);
+            sum0[2 * j + 1] = (u32)__popc(x[j] >> 16);
+            sum1[2 * j] = pop16(x[j] >> 8);
+            sum1[2 * j + 1] = pop16(__builtin_amdgcn_alignbit(x[j + 1], x[j], 24u));
+          }
+        } else {  // the two dwords per array where k wraps around 1023
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const int kd = kd0 + e;
+            const int k = kd >= 2 * kChips ? kd - 2 * kChips : (kd >= kChips ? kd - kChips : kd);
+            const int pos = 16 * k + b;
+            const u32 lo = dd[pos >> 5], mid = dd[(pos >> 5) + 1];
+            sum0[e] = pop16(__builtin_amdgcn_alignbit(mid, lo, (u32)(pos & 31)));
+            const int pos1 = pos + 8;
+            sum1[e] = pop16(__builtin_amdgcn_alignbit(dd[(pos1 >> 5) + 1], dd[pos1 >> 5], (u32)(pos1 & 31)));
+          }
+        }
+        u32 packed0 = 0, packed1 = 0, full0 = 0, full1 = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          const int kd = dw * 8 + e;   // index in the doubled array
-          const int k = kd >= 2 * kChips ? kd - 2 * kChips : (kd >= kChips ? kd - kChips : kd);
-          const int pos = 16 * k + t0;
-          const u32 win = __builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31));
-          const u32 sum = pop16(win);
-          if (sum == 16u) {
-            atomicOr(&sh.full[arr >> 1][arr & 1][kd >> 5], 1u << (kd & 31));
-            sh.any_full[arr >> 1][arr & 1] = 1u;
-          }
-          packed |= (sum > 15u ? 15u : sum) << (4 * e);
+          packed0 |= (sum0[e] - (sum0[e] >> 4)) << (4 * e);   // 16 -> 15, everything else unchanged
+          packed1 |= (sum1[e] - (sum1[e] >> 4)) << (4 * e);
+          full0 |= (sum0[e] >> 4) << e;
+          full1 |= (sum1[e] >> 4) << e;
         }
-        sh.s[arr >> 1][arr & 1][dw] = packed;
+        sh.s[0][iq][dw] = packed0;
+        sh.s[1][iq][dw] = packed1;
+        if (full0) {   // rare on noise-like data
+          atomicOr(&sh.full[0][iq][kd0 >> 5], full0 << (kd0 & 31));
+          sh.any_full[0][iq] = 1u;
+        }
+        if (full1) {
+          atomicOr(&sh.full[1][iq][kd0 >> 5], full1 << (kd0 & 31));
+          sh.any_full[1][iq] = 1u;
+        }
       }
     }
     __syncthreads();
