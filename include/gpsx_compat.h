@@ -180,6 +180,13 @@ void      acquisition_start_code_search3_channel(gps_ch_t *channel);
 /* One tracking step (pre-tracking or E/P/L + DLL/PLL/FLL) of one channel; index = 0..3, or 0xFF for the idle slot. */
 void      gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index);
 
+/* NOT in the reference: one tracking step of n_ch channels on the same millisecond, each channel served every
+ * millisecond as in the single-satellite firmware's schedule (project_single_sat/main.c:96-109; index cycles 0..3).
+ * All channels' pre-tracking searches and E/P/L correlators go out as one launch each, which is what keeps hundreds of
+ * channels inside the 1 ms budget; per channel the result is what gps_tracking_process would give a receiver that had
+ * only that channel.  Nav-bit synchronisation uses the built-in default (not the overridable hook). */
+void      gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint8_t index);
+
 /* Link-time dependencies of the step logic, as in the reference.  libgpsx provides WEAK defaults that a host program
  * overrides simply by defining the symbol:
  *   signal_capture_get_packet_cnt  1 ms tick (PM/signal_capture.c:35); default: a counter set by gpsx_compat_set_packet_cnt

@@ -42,5 +42,42 @@ def main():
         del lib
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def gen_continuous():
+    """Golden for the batched step: the reference's gps_tracking_process run on ONE channel per library instance (so the
+    file-static slot buffers of tracking.c / nav_data.c are private to the channel), every millisecond served, index =
+    t & 3; acquisition results are preset from the known delays / hints."""
+    import shutil
+    import tempfile
+    pyoracle.build_ref()
+    n_ms = 2500
+    prns, found_freq, found_phase = [5, 14, 20, 30], [900, 4000, -1000, 2000], [200, 500, 1124, 1624]
+    stream = synth.four_sv_with_nav(n_ms, seed=7)
+    snaps = np.zeros((n_ms, 4, sd.SNAP), np.uint8)
+    src = os.path.join(ROOT, "oracle", "_ref", "libref_steps.so")
+    with tempfile.TemporaryDirectory() as td:
+        for c in range(4):
+            path = os.path.join(td, f"ref_copy_{c}.so")
+            shutil.copy(src, path)
+            steps = sd.StepsLib(C.CDLL(path), True)
+            C.CDLL("libc.so.6").srand(1)
+            table = sd.preset_channel(steps, prns[c], found_freq[c], found_phase[c])
+            for t in range(n_ms):
+                steps.set_time(t)
+                blk = np.ascontiguousarray(stream[t])
+                steps.lib.gps_tracking_process(table.ctypes.data, blk.ctypes.data, t & 3)
+                snaps[t, c] = sd.snapshot(table[None, :])[0]
+    path = os.path.join(ROOT, "tests", "golden", "f7_steps_continuous.npz")
+    np.savez_compressed(path, snaps=snaps, prns=np.array(prns), found_freq=np.array(found_freq),
+                        found_phase=np.array(found_phase), n_ms=np.int32(n_ms),
+                        stream_fnv=np.uint32(fnv1a32(stream[::97])))
+    print("continuous", os.path.getsize(path), "bytes")
+    for r in sd.summarize(snaps):
+        print("  ", r)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "continuous":
+    gen_continuous()

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/gpsx_compat.h"
 #include "gpsx_compat_internal.hpp"
@@ -38,9 +39,18 @@ uint32_t g_freq_votes[ACQ_COUNT];
 uint16_t g_bin_phases[kBinCapacity];
 uint8_t g_bin_count = 0;
 
-// pre-tracking running best of the current channel time slot (tracking.c:33-34)
-uint16_t g_slot_best_value = 0;
-uint16_t g_slot_best_phase = 0;
+// State the reference keeps in file/function statics because only ONE channel is served per 4 ms time slot:
+// pre-tracking's running best of the slot (tracking.c:33-34) and the nav-bit hook's slot buffers (nav_data.c:27,48-51).
+// The reference-named entry points share one instance, exactly like the reference; the batched step
+// (gps_tracking_process_batch, every channel served every millisecond) gives each channel its own.
+struct SlotState {
+  uint16_t best_value = 0;
+  uint16_t best_phase = 0;
+  uint32_t start_ticks = 0;
+  int16_t ip[TRACKING_CH_LENGTH] = {0, 0, 0, 0};
+  uint8_t bits[TRACKING_CH_LENGTH] = {0, 0, 0, 0};
+};
+SlotState g_shared_slot;
 
 void reset_search_buffers()
 {
@@ -351,36 +361,40 @@ void settle_pre_track(gps_ch_t &ch, uint8_t count)
   }
 }
 
-void pre_track_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
+// window of this millisecond's 7 correlations; false if it is empty
+bool pre_track_window(const gps_ch_t &ch, uint8_t index, uint16_t &first, uint16_t &last)
 {
-  gps_tracking_t &t = ch.tracking_data;
-  if (index >= TRACKING_CH_LENGTH)
-    return;
-  const uint16_t first = (uint16_t)(t.code_search_start + index * kPreTrackStep);
-  uint16_t last = (uint16_t)(first + kPreTrackStep);
+  const gps_tracking_t &t = ch.tracking_data;
+  first = (uint16_t)(t.code_search_start + index * kPreTrackStep);
+  last = (uint16_t)(first + kPreTrackStep);
   if (last > kFullRange)
     last = kFullRange;
-  if (first < last) {
-    // K2 + K3 + 7 x gps_correlation8 in one launch; the window's first maximum competes with the slot's running best
-    gpsx_acq_job_t job;
-    job.block = 0;
-    job.n_ms = 1;
-    job.prn = ch.prn;
-    job.freq_hz = (float)IF_FREQ_HZ + t.if_freq_offset_hz;
-    job.offset_bits = 0;
-    job.win_start = first;
-    job.win_stop = last;
-    gpsx_peak_t pk;
-    const int rc = gpsx_acq_jobs(gpsx_compat_ctx(), &job, 1, data, 1, &pk, nullptr);
-    if (rc != GPSX_OK)
-      gpsx_compat_die("gps_tracking_process(pre-track)", rc);
-    if ((int16_t)pk.max_val > (int)g_slot_best_value) {
-      g_slot_best_value = (uint16_t)pk.max_val;
-      g_slot_best_phase = (uint16_t)pk.phase;
-    }
+  return first < last;
+}
+
+gpsx_acq_job_t pre_track_job(const gps_ch_t &ch, uint16_t first, uint16_t last)
+{
+  // K2 + K3 + 7 x gps_correlation8 in one search; the window's first maximum competes with the slot's running best
+  gpsx_acq_job_t job;
+  job.block = 0;
+  job.n_ms = 1;
+  job.prn = ch.prn;
+  job.freq_hz = (float)IF_FREQ_HZ + ch.tracking_data.if_freq_offset_hz;
+  job.offset_bits = 0;
+  job.win_start = first;
+  job.win_stop = last;
+  return job;
+}
+
+void pre_track_apply(gps_ch_t &ch, uint8_t index, const gpsx_peak_t *pk, SlotState &slot)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  if (pk && (int16_t)pk->max_val > (int)slot.best_value) {
+    slot.best_value = (uint16_t)pk->max_val;
+    slot.best_phase = (uint16_t)pk->phase;
   }
   if (index == TRACKING_CH_LENGTH - 1) {   // end of this channel's time slot
-    t.pre_track_phases[t.pre_track_count] = g_slot_best_phase;
+    t.pre_track_phases[t.pre_track_count] = slot.best_phase;
     t.pre_track_count++;
     if (t.pre_track_count > PRE_TRACK_POINTS_MAX_CNT - 10)
       settle_pre_track(ch, t.pre_track_count);
@@ -388,40 +402,55 @@ void pre_track_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
       t.pre_track_count = 0;
       std::memset(t.pre_track_phases, 0, PRE_TRACK_POINTS_MAX_CNT * 2);
     }
-    g_slot_best_value = 0;
+    slot.best_value = 0;
   }
 }
 
+void pre_track_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
+{
+  if (index >= TRACKING_CH_LENGTH)
+    return;
+  uint16_t first, last;
+  gpsx_peak_t pk;
+  const bool has_job = pre_track_window(ch, index, first, last);
+  if (has_job) {
+    const gpsx_acq_job_t job = pre_track_job(ch, first, last);
+    const int rc = gpsx_acq_jobs(gpsx_compat_ctx(), &job, 1, data, 1, &pk, nullptr);
+    if (rc != GPSX_OK)
+      gpsx_compat_die("gps_tracking_process(pre-track)", rc);
+  }
+  pre_track_apply(ch, index, has_job ? &pk : nullptr, g_shared_slot);
+}
+
 // ---- tracking step (tracking.c:92-170) ------------------------------------------------------------------------------
-void tracking_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
+void nav_bit_sync(gps_ch_t *channel, uint8_t index, int16_t new_i, SlotState &slot);
+
+// Bookkeeping before the correlators: elapsed milliseconds since this channel was last served -> how many skipped
+// milliseconds the carrier NCO must be advanced by (0 when served every millisecond).
+uint8_t tracking_skipped_ms(gps_ch_t &ch)
 {
   gps_tracking_t &t = ch.tracking_data;
   const uint32_t now = signal_capture_get_packet_cnt();
-  if (index >= TRACKING_CH_LENGTH)
-    return;
   uint32_t elapsed = now - t.prev_track_timestamp;
   t.prev_track_timestamp = now;
   if (elapsed > 50)
     elapsed = 1;
-  if (elapsed != 1)
-    gps_rewind_if_phase(&t, (uint8_t)(elapsed - 1));   // the carrier NCO kept running while other channels were served
+  return elapsed != 1 ? (uint8_t)(elapsed - 1) : (uint8_t)0;
+}
 
-  gpsx_trk_state_t st;
-  st.prn = ch.prn;
-  st.code_phase_fine = t.code_phase_fine;
-  st.if_freq_offset_hz = t.if_freq_offset_hz;
-  st.if_freq_accum = t.if_freq_accum;
-  int16_t iq[6];
-  const int rc = gpsx_track_epl_batch(gpsx_compat_ctx(), data, &st, 1, iq);   // K2 + K3 + K5
-  if (rc != GPSX_OK)
-    gpsx_compat_die("gps_tracking_process", rc);
-  t.if_freq_accum = st.if_freq_accum;
+// Everything after the correlators: DLL / PLL / FLL, nav-bit hook, SNR.  slot == nullptr: call the overridable
+// gps_nav_data_analyse_new_code (reference linkage); otherwise the built-in bit synchroniser on the given slot state.
+void tracking_apply(gps_ch_t &ch, uint8_t index, const int16_t iq[6], SlotState *slot)
+{
+  gps_tracking_t &t = ch.tracking_data;
   const int16_t IE = iq[0], QE = iq[1], IP = iq[2], QP = iq[3], IL = iq[4], QL = iq[5];
-
   dll_update(ch, IE, QE, IL, QL);
   pll_update(ch, index, IP, QP);
   fll_update(ch, index, IP, QP);
-  gps_nav_data_analyse_new_code(&ch, index, IP);
+  if (slot)
+    nav_bit_sync(&ch, index, IP, *slot);
+  else
+    gps_nav_data_analyse_new_code(&ch, index, IP);
 
   t.i_part_summ += (uint32_t)std::abs((int)IP);
   t.q_part_summ += (uint32_t)std::abs((int)QP);
@@ -439,6 +468,48 @@ void tracking_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
   }
 }
 
+// ---- tracking step (tracking.c:92-170) ------------------------------------------------------------------------------
+void tracking_step(gps_ch_t &ch, uint8_t *data, uint8_t index)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  (void)signal_capture_get_packet_cnt();   // the reference reads the tick before the index test (tracking.c:94-99)
+  if (index >= TRACKING_CH_LENGTH)
+    return;
+  const uint8_t skipped = tracking_skipped_ms(ch);
+  if (skipped)
+    gps_rewind_if_phase(&t, skipped);   // the carrier NCO kept running while other channels were served
+
+  gpsx_trk_state_t st;
+  st.prn = ch.prn;
+  st.code_phase_fine = t.code_phase_fine;
+  st.if_freq_offset_hz = t.if_freq_offset_hz;
+  st.if_freq_accum = t.if_freq_accum;
+  int16_t iq[6];
+  const int rc = gpsx_track_epl_batch(gpsx_compat_ctx(), data, &st, 1, iq);   // K2 + K3 + K5
+  if (rc != GPSX_OK)
+    gpsx_compat_die("gps_tracking_process", rc);
+  t.if_freq_accum = st.if_freq_accum;
+  tracking_apply(ch, index, iq, nullptr);
+}
+
+// shared by gps_tracking_process and the batched step: state transitions around pre-tracking (tracking.c:52-87)
+void enter_pre_track_if_needed(gps_ch_t &ch)
+{
+  gps_tracking_t &t = ch.tracking_data;
+  if (t.state != GPS_NEED_PRE_TRACK)
+    return;
+  t.code_search_start = (uint16_t)(ch.acq_data.found_code_phase - kPreTrackZone / 2);
+  t.code_search_stop = (uint16_t)(ch.acq_data.found_code_phase + kPreTrackZone / 2);
+  if (t.code_search_start > kFullRange)
+    t.code_search_start = 0;
+  if (t.code_search_stop > kFullRange)
+    t.code_search_stop = kFullRange;
+  t.if_freq_offset_hz = (float)ch.acq_data.found_freq_offset_hz;
+  t.pre_track_count = 0;
+  std::memset(t.pre_track_phases, 0, PRE_TRACK_POINTS_MAX_CNT * 2);
+  t.state = GPS_PRE_TRACK_RUN;
+}
+
 }  // namespace
 
 extern "C" {
@@ -453,11 +524,8 @@ __attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *, uint8_t) {}
 // Default prompt-I hook: 20 ms bit-period synchronisation and bit integration (PM/GPS/nav_data.c:46-250), without the
 // word / subframe layer.  A host that links the reference's nav_data.c overrides it.
 namespace {
-uint32_t g_slot_start_ticks = 0;
-int16_t g_slot_ip[TRACKING_CH_LENGTH];
-uint8_t g_slot_bits[TRACKING_CH_LENGTH];
 
-void refine_bit_edge(gps_ch_t *ch, const int16_t *ip)   // nav_data.c:145-218
+void refine_bit_edge(gps_ch_t *ch, const int16_t *ip, uint32_t slot_start_ticks)   // nav_data.c:145-218
 {
   uint8_t edge = 0;
   if (std::abs((int)ip[1]) > std::abs((int)ip[0]))
@@ -496,7 +564,7 @@ void refine_bit_edge(gps_ch_t *ch, const int16_t *ip)   // nav_data.c:145-218
   }
   if (edge == 0)
     return;
-  ch->nav_data.accurate_swap_time = (uint8_t)((g_slot_start_ticks + edge) % 20);
+  ch->nav_data.accurate_swap_time = (uint8_t)((slot_start_ticks + edge) % 20);
   ch->nav_data.accurate_swap_ok = 1;
 }
 
@@ -519,7 +587,8 @@ void integrate_bit(gps_ch_t *ch, uint8_t ms_bit, uint32_t now)   // nav_data.c:2
 }
 }  // namespace
 
-__attribute__((weak)) void gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t new_i)
+namespace {
+void nav_bit_sync(gps_ch_t *channel, uint8_t index, int16_t new_i, SlotState &slot)
 {
   if (index >= TRACKING_CH_LENGTH)
     return;
@@ -527,27 +596,27 @@ __attribute__((weak)) void gps_nav_data_analyse_new_code(gps_ch_t *channel, uint
   uint8_t bit = new_i > 0 ? 1 : 0;
   if (n.inv_polarity_flag)
     bit ^= 1;
-  g_slot_bits[index] = bit;
-  g_slot_ip[index] = new_i;
+  slot.bits[index] = bit;
+  slot.ip[index] = new_i;
   const uint32_t now = signal_capture_get_packet_cnt();
   if (index == 0)
-    g_slot_start_ticks = now;
+    slot.start_ticks = now;
   if (n.period_sync_ok_flag == 1)
     integrate_bit(channel, bit, now);
   if (index < TRACKING_CH_LENGTH - 1)
     return;
 
-  uint8_t flips = 0, flip_at = 0, prev = g_slot_bits[0];
+  uint8_t flips = 0, flip_at = 0, prev = slot.bits[0];
   for (uint8_t i = 1; i < TRACKING_CH_LENGTH; i++) {
-    if (g_slot_bits[i] != prev) {
+    if (slot.bits[i] != prev) {
       flips++;
       flip_at = i;
     }
-    prev = g_slot_bits[i];
+    prev = slot.bits[i];
   }
   if (flips != 1)
     return;
-  const uint32_t edge_time = g_slot_start_ticks + flip_at;
+  const uint32_t edge_time = slot.start_ticks + flip_at;
   const uint8_t rem = (uint8_t)((edge_time - n.old_swap_time) % 20);
   if (rem < 2 || rem == 19) {
     if (n.right_period_cnt < 10)
@@ -562,7 +631,13 @@ __attribute__((weak)) void gps_nav_data_analyse_new_code(gps_ch_t *channel, uint
   }
   n.old_swap_time = edge_time;
   if (n.period_sync_ok_flag && flip_at == 2)
-    refine_bit_edge(channel, g_slot_ip);
+    refine_bit_edge(channel, slot.ip, slot.start_ticks);
+}
+}  // namespace
+
+__attribute__((weak)) void gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t new_i)
+{
+  nav_bit_sync(channel, index, new_i, g_shared_slot);
 }
 
 // ---- acquisition.h ----------------------------------------------------------------------------------------------------
@@ -679,24 +754,100 @@ void acquisition_process(gps_ch_t *channel, uint8_t *data)
 void gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index)
 {
   gps_tracking_t &t = channel->tracking_data;
-  if (t.state == GPS_NEED_PRE_TRACK) {   // load the acquisition result (tracking.c:52-72)
-    t.code_search_start = (uint16_t)(channel->acq_data.found_code_phase - kPreTrackZone / 2);
-    t.code_search_stop = (uint16_t)(channel->acq_data.found_code_phase + kPreTrackZone / 2);
-    if (t.code_search_start > kFullRange)
-      t.code_search_start = 0;
-    if (t.code_search_stop > kFullRange)
-      t.code_search_stop = kFullRange;
-    t.if_freq_offset_hz = (float)channel->acq_data.found_freq_offset_hz;
-    t.pre_track_count = 0;
-    std::memset(t.pre_track_phases, 0, PRE_TRACK_POINTS_MAX_CNT * 2);
-    t.state = GPS_PRE_TRACK_RUN;
-  }
+  enter_pre_track_if_needed(*channel);
   if (t.state == GPS_PRE_TRACK_RUN)
     pre_track_step(*channel, data, index);
   else if (t.state == GPS_PRE_TRACK_DONE)
     t.state = GPS_TRACKING_RUN;
   if (t.state == GPS_TRACKING_RUN)
     tracking_step(*channel, data, index);
+}
+
+// ---- batched step (not in the reference) --------------------------------------------------------------------------------
+// gps_tracking_process for n_ch channels on the SAME millisecond, each channel treated as the single channel of its own
+// receiver (the schedule of project_single_sat/main.c:96-109: every channel is served every millisecond, `index`
+// cycles 0..3 or is 0xFF for an idle slot).  All pre-tracking searches go out as ONE job list and all E/P/L correlators
+// as ONE launch; the per-channel loop logic is the same code gps_tracking_process runs.
+void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint8_t index)
+{
+  static std::vector<SlotState> slots;
+  static std::vector<gpsx_acq_job_t> jobs;
+  static std::vector<gpsx_peak_t> peaks;
+  static std::vector<int> job_of, trk_of;
+  static std::vector<gpsx_trk_state_t> st;
+  static std::vector<uint8_t> skipped;
+  static std::vector<int16_t> iq;
+  if (n_ch <= 0)
+    return;
+  if ((int)slots.size() < n_ch)
+    slots.resize(n_ch);
+  jobs.clear();
+  st.clear();
+  skipped.clear();
+  job_of.assign(n_ch, -1);
+  trk_of.assign(n_ch, -1);
+  bool any_skipped = false;
+
+  // pass 1: state transitions that precede the correlators, and the work lists
+  for (int c = 0; c < n_ch; c++) {
+    gps_ch_t &ch = channel[c];
+    gps_tracking_t &t = ch.tracking_data;
+    enter_pre_track_if_needed(ch);
+    if (t.state == GPS_PRE_TRACK_RUN) {
+      uint16_t first, last;
+      if (index < TRACKING_CH_LENGTH && pre_track_window(ch, index, first, last)) {
+        job_of[c] = (int)jobs.size();
+        jobs.push_back(pre_track_job(ch, first, last));
+      }
+    } else {
+      if (t.state == GPS_PRE_TRACK_DONE)
+        t.state = GPS_TRACKING_RUN;
+      if (t.state == GPS_TRACKING_RUN && index < TRACKING_CH_LENGTH) {
+        gpsx_trk_state_t s1;
+        s1.prn = ch.prn;
+        s1.code_phase_fine = t.code_phase_fine;
+        s1.if_freq_offset_hz = t.if_freq_offset_hz;
+        s1.if_freq_accum = t.if_freq_accum;
+        trk_of[c] = (int)st.size();
+        st.push_back(s1);
+        skipped.push_back(tracking_skipped_ms(ch));
+        any_skipped |= skipped.back() != 0;
+      }
+    }
+  }
+  // pass 2: the GPU work of this millisecond
+  gpsx_ctx *gx = gpsx_compat_ctx();
+  if (!jobs.empty()) {
+    peaks.resize(jobs.size());
+    const int rc = gpsx_acq_jobs(gx, jobs.data(), (int)jobs.size(), data, 1, peaks.data(), nullptr);
+    if (rc != GPSX_OK)
+      gpsx_compat_die("gps_tracking_process_batch(pre-track)", rc);
+  }
+  if (!st.empty()) {
+    if (any_skipped) {
+      const int rc = gpsx_rewind(gx, st.data(), (int)st.size(), skipped.data());
+      if (rc != GPSX_OK)
+        gpsx_compat_die("gps_tracking_process_batch(rewind)", rc);
+    }
+    iq.resize(st.size() * 6);
+    const int rc = gpsx_track_epl_batch(gx, data, st.data(), (int)st.size(), iq.data());
+    if (rc != GPSX_OK)
+      gpsx_compat_die("gps_tracking_process_batch", rc);
+  }
+  // pass 3: per-channel serial logic, in channel order
+  for (int c = 0; c < n_ch; c++) {
+    gps_ch_t &ch = channel[c];
+    gps_tracking_t &t = ch.tracking_data;
+    if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
+      if (index < TRACKING_CH_LENGTH)
+        pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[job_of[c]] : nullptr, slots[c]);
+      // a channel whose pre-tracking just settled starts tracking on the NEXT millisecond (its correlators were not
+      // part of this launch); the reference's single-channel call does the same one call later
+    } else if (trk_of[c] >= 0) {
+      t.if_freq_accum = st[trk_of[c]].if_freq_accum;
+      tracking_apply(ch, index, &iq[(size_t)trk_of[c] * 6], &slots[c]);
+    }
+  }
 }
 
 }  // extern "C"

@@ -66,10 +66,23 @@ def _trk_set(table, i, name, value):
 
 
 def snapshot(table):
-    out = np.zeros((N_CH, SNAP), np.uint8)
+    out = np.zeros((len(table), SNAP), np.uint8)
     out[:, :212] = table[:, :212]
     out[:, 212:226] = table[:, 212:226]
     return out
+
+
+def preset_channel(steps: "StepsLib", prn: int, found_freq_hz: int, found_code_phase: int) -> np.ndarray:
+    """One gps_ch_t whose acquisition is already done (state GPS_ACQ_DONE with the given result) and whose tracking
+    is about to start (GPS_NEED_PRE_TRACK) -- what gps_master_handling leaves behind (gps_master.c:118-127)."""
+    ch = np.zeros(CH_SIZE, np.uint8)
+    ch[664] = prn
+    steps.lib.gps_channell_prepare(ch.ctypes.data)
+    ch[2:4] = np.frombuffer(np.int16(found_freq_hz).tobytes(), np.uint8)      # found_freq_offset_hz
+    ch[6:8] = np.frombuffer(np.uint16(found_code_phase).tobytes(), np.uint8)  # found_code_phase
+    ch[16:20] = np.frombuffer(np.int32(ACQ_DONE).tobytes(), np.uint8)         # acq state
+    ch[60 + 148:60 + 152] = np.frombuffer(np.int32(TRK_NEED_PRE).tobytes(), np.uint8)
+    return ch
 
 
 def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int):
