@@ -159,18 +159,34 @@ def main():
     with torch.cuda.stream(stream):
         d_if = torch.from_numpy(np.concatenate([blocks.reshape(-1), np.zeros(2, np.uint8)])).to(dev)
         d_peaks = torch.zeros((n_search, N_PRN, N_DOPP, 8, 4), dtype=torch.int32, device=dev)
-        d_keys = torch.zeros((n_search, N_PRN, N_DOPP), dtype=torch.int64, device=dev)
+        # two key tables: the all-reduce of step k (RCCL's own stream) overlaps the grid kernel of step k + 1
+        key_bufs = [torch.zeros((n_search, N_PRN, N_DOPP), dtype=torch.int64, device=dev) for _ in range(2)]
+        pending = [None, None]
+        step_no = [0]
 
         def step():
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            if pending[slot] is not None:      # the table is about to be overwritten: its exchange must have finished
+                pending[slot].wait()
+                pending[slot] = None
+            keys_t = key_bufs[slot]
             rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
-                                           d_keys.data_ptr(), None, None, None)
+                                           keys_t.data_ptr(), None, None, None)
             if rc != 0:
                 raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
-            if use_dist:
-                dist.all_reduce(d_keys, op=dist.ReduceOp.MAX)
+            if use_dist:   # the ONE collective of the path: max-merge of the packed (energy, phase) keys
+                pending[slot] = dist.all_reduce(keys_t, op=dist.ReduceOp.MAX, async_op=True)
+
+        def drain():
+            for i in range(2):
+                if pending[i] is not None:
+                    pending[i].wait()
+                    pending[i] = None
 
         for _ in range(args.warmup):
             step()
+        drain()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -181,6 +197,7 @@ def main():
         for _ in range(args.steps):
             step()
         eng.record(ev1)
+        drain()                                  # every step's exchange is complete inside the timed region
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -211,6 +228,7 @@ def main():
         pcie = reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
 
     # sanity outside the timed region: the merged key table must hold the six synthetic satellites' peaks
+    d_keys = key_bufs[(step_no[0] - 1) & 1]
     keys = d_keys.cpu().numpy()
     energy = keys >> 14
     assert (energy > 0).all() and energy.max() > 1500 * min(1.0, args.amp_scale), "acquisition grid produced no peaks"
