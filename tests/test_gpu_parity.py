@@ -476,3 +476,48 @@ def test_two_bit_ingest_unpack_and_sign_plane_parity(oracle, tmp_path):
             eng.set_if_format(7)
     finally:
         eng.close()
+
+
+def test_acq_grid_randomised_descriptors_vs_oracle(eng, oracle, stream):
+    """Seeded sweep over the descriptor space: PRN lists of any length (1..210, repeats allowed), arbitrary Doppler
+    grids, windows, 1..5 ms integration, both phase modes, several searches with overlapping strides, shards."""
+    from stm32f4_sdr_gps_amd.capi import PHASES_BYTE, PHASES_FINE
+    rng = np.random.default_rng(2024)
+    for trial in range(14):
+        n_prn = int(rng.integers(1, 12))
+        prns = rng.integers(1, 211, n_prn).astype(np.uint8)
+        n_dopp = int(rng.integers(1, 5))
+        dmin = int(rng.integers(-7000, 6000))
+        dstep = int(rng.integers(1, 900))
+        n_ms = int(rng.integers(1, 6))
+        n_search = int(rng.integers(1, 4))
+        stride = int(rng.integers(0, 3))
+        if (n_search - 1) * stride + n_ms > len(stream):
+            n_search, stride = 1, 1
+        a, b = sorted(int(x) for x in rng.integers(0, 2047, 2))
+        mode = PHASES_FINE if trial % 3 else PHASES_BYTE
+        n_bits = 8 if mode == PHASES_FINE else 1
+        world = int(rng.integers(1, 4))
+        merged = None
+        for r in range(world):
+            peaks, keys = eng.acq_grid(stream, prns, n_search=n_search, n_ms=n_ms, search_stride_blocks=stride,
+                                       dopp_min_hz=dmin, dopp_step_hz=dstep, n_dopp=n_dopp, phase_mode=mode, win=(a, b),
+                                       shard=(r, world))
+            merged = _merge_owned(np.zeros_like(peaks) if merged is None else merged, peaks, keys)
+        for s in range(n_search):
+            blk = stream[s * stride:s * stride + n_ms]
+            for p in range(n_prn):
+                for d in range(n_dopp):
+                    for bit in range(n_bits):
+                        pk, _, _ = oracle.search_job(blk, n_ms, oracle.ca_code(int(prns[p])), float(IF_HZ + dmin + d * dstep),
+                                                     bit, a, b)
+                        assert _peak_tuple(merged[s, p, d, bit]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), \
+                            (trial, s, p, d, bit)
+
+
+def _merge_owned(acc, peaks, keys):
+    """Shards write zeros for units they do not own; owned units are those with a non-zero key."""
+    out = acc.copy()
+    mine = keys != 0
+    out[mine] = peaks[mine]
+    return out
