@@ -424,9 +424,10 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   const int shard_index = g->shard_count > 0 ? g->shard_index : 0;
   const int n_bits = gpsx_acq_bits(g->phase_mode);
   const int n_groups = (g->n_prn + kAcqGroup - 1) / kAcqGroup;
-  const long n_units = (long)g->n_search * n_groups * g->n_dopp;
+  const int n_super = (n_groups + kSuperGroups - 1) / kSuperGroups;
+  const long n_units = (long)g->n_search * n_super * g->n_dopp;
   const long local_units = n_units > shard_index ? (n_units - shard_index + shard_count - 1) / shard_count : 0;
-  if (local_units * n_bits > 0x7FFFFFFFL)
+  if (local_units * n_bits * kSuperGroups > 0x7FFFFFFFL)
     return fail(ctx, GPSX_EINVAL, "grid too large for one launch");
 
   if (shard_count > 1) {
@@ -452,7 +453,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.per_ms = d_per_ms;
   prm.energy = d_energy;
   prm.cnt = d_cnt;
-  launch_acq(ctx->stream, kAcqGroup, ctx->algo, (int)(local_units * n_bits), prm,
+  launch_acq(ctx->stream, kAcqGroup, ctx->algo, local_units, prm,
              static_cast<const uint8_t *>(d_if_blocks), ctx->algo == kAlgoDot8 ? ctx->d_grid_cw8 : ctx->d_grid_cw,
              ctx->d_grid_bits);
   LAUNCHCHK(ctx, "k_acq");

@@ -8,7 +8,8 @@
 
 namespace gpsx {
 
-constexpr int kAcqGroup = 8;      // PRNs sharing one workgroup's wiped data in the grid kernel
+constexpr int kAcqGroup = 8;      // PRNs per accumulator set (one main-loop pass) in the grid kernel
+constexpr int kSuperGroups = 2;   // groups per sharding unit: a unit is (search, 16 PRNs, Doppler bin)
 constexpr int kCodeWords = 256;   // 4-chip code words per PRN (1023 chips + 1 masked pad)
 constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window sum inside 32 bits
 constexpr int kAlgoSad = 0;       // main loop: v_msad_u8 on 8-bit block sums, 4 chips per instruction
@@ -51,9 +52,9 @@ struct AcqParams {
 void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int group, uint8_t *d_chips,
                         uint32_t *d_chipbits, uint32_t *d_cw, uint32_t *d_cw8);
 
-// K2+K3+K4 fused acquisition search.  group = kAcqGroup (grid) or 1 (job list).
-// d_cw is the table matching `algo` (cw for kAlgoSad, cw8 for kAlgoDot8).
-void launch_acq(hipStream_t s, int group, int algo, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
+// K2+K3+K4 fused acquisition search.  group = kAcqGroup (grid; local_units = sharding units of this rank) or 1 (job
+// list; local_units = jobs).  d_cw is the table matching `algo` (cw for kAlgoSad, cw8 for kAlgoDot8).
+void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits);
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,

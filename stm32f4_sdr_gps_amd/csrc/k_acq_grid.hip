@@ -29,6 +29,8 @@
 //   by E = sum_c chip[c] * F[q + c] over the bit plane F of saturated windows -- an AND + popcount pass that only runs
 //   for the (t0, I/Q) arrays that contain such a window at all (2^-16 per window on noise-like data; dense on clean
 //   synthetic carriers, where the pass costs about half of the dot loop).
+#include <cstdlib>
+
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
 
@@ -41,7 +43,7 @@ constexpr int kSDwords = 520;  // S' arrays: 2046 + pad bytes, doubled circular 
 constexpr int kNibDwords = 264;  // 4-bit block sums: 2046 + pad nibbles, doubled circular copy, as dwords
 constexpr int kFullWords = 68;   // bit plane of saturated windows, doubled circular copy
 
-template <int G>
+template <int G, int GPW>
 struct AcqShared {
   uint16_t x[1024];              // raw IF block
   u32 d[2][514];                 // wiped I / Q streams: 511 words, word 511 = wrap-around copy, zero pad
@@ -49,9 +51,9 @@ struct AcqShared {
   u32 full[2][2][kFullWords];    // ALGO_DOT8: windows whose sum is 16
   u32 any_full[2][2];            // ALGO_DOT8: does the array hold any such window
   u32 ones[2];                   // ALGO_DOT8: pop(D) per stream
-  u32 chipbits[G][34];           // 32 words of chips + zero pad for the 64-bit window reads
+  u32 chipbits[GPW * G][34];     // 32 words of chips + zero pad for the 64-bit window reads
   u32 red[4][G][2];              // cross-wave reduction scratch
-  u32 carry[2 * G][kThreads];    // each lane's running (best key, sum) per PRN, parked here while the dot loop runs
+  u32 carry[GPW][2 * G][kThreads];  // each lane's running (best key, sum) per PRN, parked here while the dot loops run
 };
 
 __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
@@ -98,67 +100,67 @@ __device__ __forceinline__ void add_saturation_deficit(u32 (&acc)[4][G], const u
 // the dot-product variant carries more live state and gets 168 (3 waves), the multi-block variants (64 extra energy
 // registers) 256 (2 waves), instead of spilling to scratch
 // DBG: the optional inspection outputs (raw counts, energy plane, per-block triplets) exist only in this instantiation
-template <int G, bool MULTI, int ALGO, bool DBG>
-__global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
+// GPW: PRN groups of G handled per workgroup, one after the other, on the SAME wiped data and block sums -- the
+//      per-millisecond preamble (capture load, wipe-off, block sums, barriers) is paid once for GPW * G PRNs
+template <int G, bool MULTI, int ALGO, bool DBG, int GPW>
+__global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 1) ? 3 : 4)) void k_acq(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                   const u32 *__restrict__ cw, const u32 *__restrict__ chipbits)
 {
   constexpr bool DOT8 = ALGO == kAlgoDot8;
   constexpr int kSteps = DOT8 ? kCodeWords / 2 : kCodeWords;   // 8 or 4 chips per main-loop step
-  __shared__ AcqShared<G> sh;
+  __shared__ AcqShared<G, GPW> sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
   // ---- decode this workgroup's search ------------------------------------------------------------------------
-  int first_block, slot0, b, win_start, win_stop, out0, out_pstride, n_valid;
+  // Grid mode: the sharding unit is (search, 16-PRN super group, Doppler); a super group is two G-PRN groups, handled
+  // by one workgroup (GPW = 2) or two (GPW = 1), times the replica bit shifts.
+  int first_block, group0, n_groups_here, b, win_start, win_stop, dopp = 0, search = 0;
   float freq_hz;
+  AcqJobRec jr{};
   if (prm.jobs) {
-    const AcqJobRec jr = prm.jobs[blockIdx.x];
+    jr = prm.jobs[blockIdx.x];
     first_block = jr.block;
-    slot0 = jr.slot;
+    group0 = jr.slot / G;   // G == 1 in job mode
+    n_groups_here = 1;
     freq_hz = jr.freq_hz;
     b = jr.offset_bits & 15;
     win_start = jr.win_start;
     win_stop = jr.win_stop;
-    out0 = jr.out_index;
-    out_pstride = 1;
-    n_valid = 1;
   } else {
-    const int unit_local = blockIdx.x / prm.n_bits;
-    b = blockIdx.x - unit_local * prm.n_bits;
+    constexpr int kParts = kSuperGroups / GPW;   // workgroups per (super unit, bit shift)
+    int id = blockIdx.x;
+    const int part = id % kParts;
+    id /= kParts;
+    b = id % prm.n_bits;
+    const int unit_local = id / prm.n_bits;
     const int unit = prm.shard_index + unit_local * prm.shard_count;
-    const int dopp = unit % prm.n_dopp;
+    dopp = unit % prm.n_dopp;
     const int t = unit / prm.n_dopp;
-    const int group = t % prm.n_groups;
-    const int search = t / prm.n_groups;
+    const int n_super = (prm.n_groups + kSuperGroups - 1) / kSuperGroups;
+    const int super = t % n_super;
+    search = t / n_super;
     first_block = search * prm.search_stride_blocks;
-    slot0 = group * G;
+    group0 = super * kSuperGroups + part * GPW;
+    n_groups_here = prm.n_groups - group0 < GPW ? prm.n_groups - group0 : GPW;
+    if (n_groups_here <= 0)
+      return;   // odd number of groups: the last super group has one
     // int arithmetic, then one conversion: PM/GPS/acquisition.c:285-289
     freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);
     win_start = prm.win_start;
     win_stop = prm.win_stop;
-    out_pstride = prm.n_dopp * prm.n_bits;
-    out0 = ((search * prm.n_prn + slot0) * prm.n_dopp + dopp) * prm.n_bits + b;
-    n_valid = prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G;
   }
   const u32 step_word = nco_step_per_word(freq_hz);
   const u32 low_mask = (1u << b) - 1u;                 // replica bits of word i that still belong to chip i-1
   const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;      // ... and to chip i
-  const u32 *cw_group = cw + (size_t)(slot0 / G) * kSteps * G;
 
-  for (int i = tid; i < G * 34; i += kThreads) {
+  for (int i = tid; i < GPW * G * 34; i += kThreads) {
     const int p = i / 34, w = i - p * 34;
-    sh.chipbits[p][w] = w < 32 ? chipbits[(size_t)(slot0 + p) * 32 + w] : 0u;
+    sh.chipbits[p][w] = (w < 32 && p < n_groups_here * G) ? chipbits[(size_t)(group0 * G + p) * 32 + w] : 0u;
   }
 
-  // running result per PRN: packed (value << 11 | 2047 - offset) maximum and the window sum
-  u32 best[G], total[G];
-  u32 energy[MULTI ? 2 : 1][MULTI ? 4 : 1][MULTI ? G : 1];
-#pragma unroll
-  for (int p = 0; p < G; p++) {
-    best[p] = 0;
-    total[p] = 0;
-  }
+  u32 energy[MULTI ? 2 : 1][MULTI ? 4 : 1][MULTI ? G : 1];   // MULTI implies GPW == 1
   if (MULTI) {
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -296,6 +298,20 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) 
     // ---- B: the SAD loops, t0 = b (even byte offsets) then t0 = b + 8 (odd byte offsets) ------------------------
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
+#pragma unroll 1
+     for (int gi = 0; gi < n_groups_here; gi++) {
+      // per-group addressing (wave-uniform scalars)
+      const int slot0 = (group0 + gi) * G;
+      const u32 *cw_group = cw + (size_t)(group0 + gi) * kSteps * G;
+      const int out_pstride = prm.jobs ? 1 : prm.n_dopp * prm.n_bits;
+      const int out0 = prm.jobs ? jr.out_index : ((search * prm.n_prn + slot0) * prm.n_dopp + dopp) * prm.n_bits + b;
+      const int n_valid = prm.jobs ? 1 : (prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G);
+      u32 best[G], total[G];   // running result per PRN: packed (value << 11 | 2047 - offset) maximum, window sum
+#pragma unroll
+      for (int p = 0; p < G; p++) {
+        best[p] = 0;
+        total[p] = 0;
+      }
       u32 acc_i[4][G], acc_q[4][G];
 #pragma unroll
       for (int i = 0; i < 4; i++)
@@ -383,8 +399,8 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) 
       if (half == 1) {
 #pragma unroll
         for (int p = 0; p < G; p++) {
-          best[p] = sh.carry[2 * p][tid];
-          total[p] = sh.carry[2 * p + 1][tid];
+          best[p] = sh.carry[gi][2 * p][tid];
+          total[p] = sh.carry[gi][2 * p + 1][tid];
         }
       }
       // (tid laundered through an empty asm: everything derived from it below -- offsets, window tests, LDS addresses --
@@ -413,7 +429,8 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) 
       if (half) {
 #pragma unroll
         for (int p = 0; p < G; p++) {
-          const u64 two = (u64)sh.chipbits[p][chip_lo >> 5] | ((u64)sh.chipbits[p][(chip_lo >> 5) + 1] << 32);
+          const u32 *cb = sh.chipbits[gi * G + p];
+          const u64 two = (u64)cb[chip_lo >> 5] | ((u64)cb[(chip_lo >> 5) + 1] << 32);
           const u32 w = (u32)(two >> (chip_lo & 31));
           chipwin[p] = chip_base < 0 ? w << (chip_lo - chip_base) : w;
         }
@@ -488,52 +505,53 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) 
       if (half == 0) {
 #pragma unroll
         for (int p = 0; p < G; p++) {
-          sh.carry[2 * p][tid] = best[p];
-          sh.carry[2 * p + 1][tid] = total[p];
+          sh.carry[gi][2 * p][tid] = best[p];
+          sh.carry[gi][2 * p + 1][tid] = total[p];
         }
       }
-    }  // half
 
-    // ---- D: workgroup reduction -> one triplet per PRN (per ms in MULTI mode only if asked) ----------------------
-    const bool reduce_now = MULTI ? (DBG && prm.per_ms != nullptr) : true;
-    if (reduce_now) {
+      // ---- D: workgroup reduction -> one triplet per PRN (per ms in MULTI mode only if asked) --------------------
+      const bool reduce_now = half == 1 && (MULTI ? (DBG && prm.per_ms != nullptr) : true);
+      if (reduce_now) {
 #pragma unroll
-      for (int p = 0; p < G; p++) {
-        const u32 k = wave_max_u32(best[p]);
-        const u32 t = wave_sum_u32(total[p]);
-        if (lane == 0) {
-          sh.red[wave][p][0] = k;
-          sh.red[wave][p][1] = t;
+        for (int p = 0; p < G; p++) {
+          const u32 k = wave_max_u32(best[p]);
+          const u32 t = wave_sum_u32(total[p]);
+          if (lane == 0) {
+            sh.red[wave][p][0] = k;
+            sh.red[wave][p][1] = t;
+          }
         }
-      }
-      __syncthreads();
-      if (tid < n_valid) {
-        u32 k = 0, t = 0;
-        for (int w = 0; w < 4; w++) {
-          k = sh.red[w][tid][0] > k ? sh.red[w][tid][0] : k;
-          t += sh.red[w][tid][1];
+        __syncthreads();
+        if (tid < n_valid) {
+          u32 k = 0, t = 0;
+          for (int w = 0; w < 4; w++) {
+            k = sh.red[w][tid][0] > k ? sh.red[w][tid][0] : k;
+            t += sh.red[w][tid][1];
+          }
+          gpsx_peak_t pk;
+          pk.max_val = k >> 11;
+          pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+          pk.sum = t;
+          pk.avr = t / (2u * kChips);
+          const int out_idx = out0 + tid * out_pstride;
+          if (MULTI)
+            prm.per_ms[(size_t)out_idx * prm.n_ms + ms] = pk;
+          else
+            prm.peaks[out_idx] = pk;
         }
-        gpsx_peak_t pk;
-        pk.max_val = k >> 11;
-        pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
-        pk.sum = t;
-        pk.avr = t / (2u * kChips);
-        const int out_idx = out0 + tid * out_pstride;
-        if (MULTI)
-          prm.per_ms[(size_t)out_idx * prm.n_ms + ms] = pk;
-        else
-          prm.peaks[out_idx] = pk;
+        __syncthreads();   // sh.red is reused by the next group
       }
-#pragma unroll
-      for (int p = 0; p < G; p++) {
-        best[p] = 0;
-        total[p] = 0;
-      }
-    }
+     }  // gi
+    }  // half
   }  // ms
 
   if (MULTI) {
-    // search over the accumulated energies
+    // search over the accumulated energies (GPW == 1: the one group of this workgroup)
+    const int slot0 = group0 * G;
+    const int out_pstride = prm.jobs ? 1 : prm.n_dopp * prm.n_bits;
+    const int out0 = prm.jobs ? jr.out_index : ((search * prm.n_prn + slot0) * prm.n_dopp + dopp) * prm.n_bits + b;
+    const int n_valid = prm.jobs ? 1 : (prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G);
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < G; p++) {
@@ -574,40 +592,65 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : (ALGO == kAlgoDot8 ? 3 : 4)) 
   }
 }
 
-template <int G, int ALGO>
+template <int G, int ALGO, int GPW>
 static void launch_acq_t(hipStream_t s, int n_workgroups, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw,
                          const uint32_t *d_chipbits)
 {
   const dim3 grid(n_workgroups), block(kThreads);
   const bool dbg = prm.per_ms || prm.energy || prm.cnt;
-  if (prm.n_ms > 1) {
-    if (dbg)
-      hipLaunchKernelGGL((k_acq<G, true, ALGO, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
-    else
-      hipLaunchKernelGGL((k_acq<G, true, ALGO, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+  if constexpr (GPW == 1) {
+    if (prm.n_ms > 1) {
+      if (dbg)
+        hipLaunchKernelGGL((k_acq<G, true, ALGO, true, 1>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+      else
+        hipLaunchKernelGGL((k_acq<G, true, ALGO, false, 1>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    } else {
+      if (dbg)
+        hipLaunchKernelGGL((k_acq<G, false, ALGO, true, 1>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+      else
+        hipLaunchKernelGGL((k_acq<G, false, ALGO, false, 1>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    }
   } else {
-    if (dbg)
-      hipLaunchKernelGGL((k_acq<G, false, ALGO, true>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
-    else
-      hipLaunchKernelGGL((k_acq<G, false, ALGO, false>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
+    hipLaunchKernelGGL((k_acq<G, false, ALGO, false, GPW>), grid, block, 0, s, prm, d_if, d_cw, d_chipbits);
   }
 }
 
-void launch_acq(hipStream_t s, int group, int algo, int n_workgroups, const AcqParams &prm, const uint8_t *d_if,
+int acq_groups_per_workgroup(int group, const AcqParams &prm, long local_units)
+{
+  // Two PRN groups per workgroup halve the per-block preamble; worth it while the launch still has several waves of
+  // workgroups per CU slot (256 CUs x 3 resident) and only in the plain single-block production instantiation.
+  const bool plain = group == kAcqGroup && prm.n_ms == 1 && !prm.per_ms && !prm.energy && !prm.cnt && !prm.jobs;
+  const long wgs_if_two = local_units * prm.n_bits;
+  static const char *force = std::getenv("GPSX_ACQ_GPW");   // "1" / "2": A/B measurements
+  if (force && plain && prm.n_groups >= 2)
+    return force[0] == '2' ? 2 : 1;
+  return (plain && prm.n_groups >= 2 && wgs_if_two >= 4 * 768) ? 2 : 1;
+}
+
+void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits)
 {
-  if (n_workgroups <= 0)
+  if (local_units <= 0)
     return;
   if (group == kAcqGroup) {
+    const int gpw = acq_groups_per_workgroup(group, prm, local_units);
+    const int n_wg = (int)(local_units * prm.n_bits * (kSuperGroups / gpw));
+    if (algo == kAlgoDot8) {
+      if (gpw == 2)
+        launch_acq_t<kAcqGroup, kAlgoDot8, 2>(s, n_wg, prm, d_if, d_cw, d_chipbits);
+      else
+        launch_acq_t<kAcqGroup, kAlgoDot8, 1>(s, n_wg, prm, d_if, d_cw, d_chipbits);
+    } else {
+      if (gpw == 2)
+        launch_acq_t<kAcqGroup, kAlgoSad, 2>(s, n_wg, prm, d_if, d_cw, d_chipbits);
+      else
+        launch_acq_t<kAcqGroup, kAlgoSad, 1>(s, n_wg, prm, d_if, d_cw, d_chipbits);
+    }
+  } else {   // job list: one PRN, one workgroup per job
     if (algo == kAlgoDot8)
-      launch_acq_t<kAcqGroup, kAlgoDot8>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
+      launch_acq_t<1, kAlgoDot8, 1>(s, (int)local_units, prm, d_if, d_cw, d_chipbits);
     else
-      launch_acq_t<kAcqGroup, kAlgoSad>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
-  } else {
-    if (algo == kAlgoDot8)
-      launch_acq_t<1, kAlgoDot8>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
-    else
-      launch_acq_t<1, kAlgoSad>(s, n_workgroups, prm, d_if, d_cw, d_chipbits);
+      launch_acq_t<1, kAlgoSad, 1>(s, (int)local_units, prm, d_if, d_cw, d_chipbits);
   }
 }
 
@@ -622,7 +665,8 @@ __global__ void k_acq_keys(const gpsx_peak_t *__restrict__ peaks, int64_t *__res
   const int dopp = idx % n_dopp;
   const int prn = (idx / n_dopp) % n_prn;
   const int search = idx / (n_dopp * n_prn);
-  const int unit = (search * n_groups + prn / kAcqGroup) * n_dopp + dopp;
+  const int n_super = (n_groups + kSuperGroups - 1) / kSuperGroups;
+  const int unit = (search * n_super + prn / (kAcqGroup * kSuperGroups)) * n_dopp + dopp;
   int64_t best = 0;
   if (unit % shard_count == shard_index) {
     for (int b = 0; b < n_bits; b++) {

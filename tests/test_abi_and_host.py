@@ -113,5 +113,5 @@ def test_sharding_partition_and_key_packing():
     assert int(e[0]) == 9 and int(f[0]) == 8 * 4 + 3
     # weak-scaling balance of the bench default (16 searches per GPU): every rank gets the same number of units
     for world in (1, 2, 4, 8):
-        counts = [int(sharding.owned_mask(16 * world, 32, 21, r, world)[:, ::8, :].sum()) for r in range(world)]
-        assert len(set(counts)) == 1 and counts[0] == 16 * 4 * 21
+        counts = [int(sharding.owned_mask(16 * world, 32, 21, r, world)[:, ::16, :].sum()) for r in range(world)]
+        assert len(set(counts)) == 1 and counts[0] == 16 * 2 * 21
