@@ -414,13 +414,16 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
       constexpr int kSign = DOT8 ? -2 : 1;
       // Odd offsets skip replica word p1 = 1022 - q, which meets data bytes (2045, 0) = `wrap`.  That word's replica
       // bits are (chip[p1 - 1] ? low : 0) | (chip[p1] ? high : 0): four possible popcounts per stream, precomputed.
-      u32 wrap_pop_i[4], wrap_pop_q[4];
+      // (packed one byte each into a scalar; the lane's two chip bits then select a byte with one v_bfe_u32)
+      u32 wrap_tab_i = 0, wrap_tab_q = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const u32 r = ((k & 1) ? low_mask : 0u) | ((k & 2) ? high_mask : 0u);
-        wrap_pop_i[k] = (u32)__builtin_amdgcn_readfirstlane((int)pop16(wrap_i ^ r));
-        wrap_pop_q[k] = (u32)__builtin_amdgcn_readfirstlane((int)pop16(wrap_q ^ r));
+        wrap_tab_i |= pop16(wrap_i ^ r) << (8 * k);
+        wrap_tab_q |= pop16(wrap_q ^ r) << (8 * k);
       }
+      wrap_tab_i = (u32)__builtin_amdgcn_readfirstlane((int)wrap_tab_i);
+      wrap_tab_q = (u32)__builtin_amdgcn_readfirstlane((int)wrap_tab_q);
       // One 32-chip window per PRN covers chips p1 - 1, p1 of the lane's four offsets (they lie within 26 chips).
       const int q_hi = chip_offset_of<ALGO>(tid_e, 3);
       const int chip_base = kChips - 2 - q_hi;   // lowest chip needed; bit k of chipwin = chip (chip_base + k)
@@ -461,10 +464,9 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
           int ci = base_i + kSign * (int)acc_i[i][p] + (c1022 ? adj_i : 0);
           int cq = base_q + kSign * (int)acc_q[i][p] + (c1022 ? adj_q : 0);
           if (half) {
-            const u32 sel = (chipwin[p] >> k0) & 3u;   // bit 0 = chip[p1 - 1], bit 1 = chip[p1]
-            const bool s0 = sel & 1u, s1 = sel & 2u;
-            ci -= (int)(s1 ? (s0 ? wrap_pop_i[3] : wrap_pop_i[2]) : (s0 ? wrap_pop_i[1] : wrap_pop_i[0]));
-            cq -= (int)(s1 ? (s0 ? wrap_pop_q[3] : wrap_pop_q[2]) : (s0 ? wrap_pop_q[1] : wrap_pop_q[0]));
+            const u32 sel8 = ((chipwin[p] >> k0) & 3u) * 8u;   // bit 0 = chip[p1 - 1], bit 1 = chip[p1]
+            ci -= (int)__builtin_amdgcn_ubfe(wrap_tab_i, sel8, 8u);
+            cq -= (int)__builtin_amdgcn_ubfe(wrap_tab_q, sel8, 8u);
             const u32 r_last = (c1021 ? low_mask : 0u) | (c1022 ? high_mask : 0u);   // wave-uniform
             ci -= odd_tail ? (int)__popc(prev_i ^ r_last) : 0;
             cq -= odd_tail ? (int)__popc(prev_q ^ r_last) : 0;
