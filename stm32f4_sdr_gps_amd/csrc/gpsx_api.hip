@@ -27,7 +27,9 @@ struct gpsx_ctx {
   uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
   uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
   int if_format = GPSX_IF_1BIT;
-  int algo = kAlgoDot8;              // $GPSX_ACQ_ALGO=sad selects the byte-SAD main loop (A/B measurements)
+  int algo = kAlgoPoly;              // $GPSX_ACQ_ALGO = poly (default) | dot8 | sad, for A/B measurements
+  uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
+  size_t acc_entries = 0;
 
   // grouped tables for the PRN list of the last grid call
   std::vector<uint8_t> grid_prns;
@@ -209,7 +211,7 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     return GPSX_ENODEV;
   }
   if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
-    ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad : kAlgoDot8;
+    ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad : (std::strcmp(a, "dot8") == 0 ? kAlgoDot8 : kAlgoPoly);
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -254,7 +256,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
-                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena};
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
@@ -453,10 +455,28 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.per_ms = d_per_ms;
   prm.energy = d_energy;
   prm.cnt = d_cnt;
-  launch_acq(ctx->stream, kAcqGroup, ctx->algo, local_units, prm,
-             static_cast<const uint8_t *>(d_if_blocks), ctx->algo == kAlgoDot8 ? ctx->d_grid_cw8 : ctx->d_grid_cw,
-             ctx->d_grid_bits);
-  LAUNCHCHK(ctx, "k_acq");
+  const bool inspect = d_per_ms || d_energy || d_cnt;
+  if (ctx->algo == kAlgoPoly && n_bits == 8 && g->n_ms == 1 && !inspect) {
+    const size_t n_peaks = gpsx_acq_peaks_count(g);
+    if (n_peaks > ctx->acc_entries) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_acc)
+        (void)hipFree(ctx->d_acc);
+      ctx->d_acc = nullptr;
+      ctx->acc_entries = 0;
+      HIPCHK(ctx, hipMalloc((void **)&ctx->d_acc, 2 * n_peaks * sizeof(uint32_t)));
+      ctx->acc_entries = n_peaks;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_acc, 0, 2 * n_peaks * sizeof(uint32_t), ctx->stream));
+    launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
+                    ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks);
+    LAUNCHCHK(ctx, "k_acq_poly");
+  } else {
+    const int algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;
+    launch_acq(ctx->stream, kAcqGroup, algo, local_units, prm, static_cast<const uint8_t *>(d_if_blocks),
+               algo == kAlgoDot8 ? ctx->d_grid_cw8 : ctx->d_grid_cw, ctx->d_grid_bits);
+    LAUNCHCHK(ctx, "k_acq");
+  }
   if (d_keys) {
     launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
                     shard_count);
@@ -533,7 +553,8 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
   prm.jobs = d_jobs;
   prm.peaks = d_peaks;
   prm.energy = d_energy;
-  launch_acq(ctx->stream, 1, ctx->algo, n_jobs, prm, d_if, ctx->algo == kAlgoDot8 ? ctx->d_cw8_all : ctx->d_cw_all,
+  const int job_algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;
+  launch_acq(ctx->stream, 1, job_algo, n_jobs, prm, d_if, job_algo == kAlgoDot8 ? ctx->d_cw8_all : ctx->d_cw_all,
              ctx->d_bits_all);
   LAUNCHCHK(ctx, "k_acq(jobs)");
   HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_jobs * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -13,7 +13,8 @@ constexpr int kSuperGroups = 2;   // groups per sharding unit: a unit is (search
 constexpr int kCodeWords = 256;   // 4-chip code words per PRN (1023 chips + 1 masked pad)
 constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window sum inside 32 bits
 constexpr int kAlgoSad = 0;       // main loop: v_msad_u8 on 8-bit block sums, 4 chips per instruction
-constexpr int kAlgoDot8 = 1;      // main loop: v_dot8_u32_u4 on 4-bit block sums, 8 chips per instruction (default)
+constexpr int kAlgoDot8 = 1;      // main loop: v_dot8_u32_u4 on 4-bit block sums, 8 chips per instruction
+constexpr int kAlgoPoly = 2;      // fine grid only: polyphase recurrence across the 16 sample offsets, AND + popcount (default)
 
 // One search = one workgroup pass: `count` (<= group size) consecutive code-table slots, one carrier frequency,
 // one replica bit shift, n_ms consecutive blocks.
@@ -56,6 +57,11 @@ void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int g
 // list; local_units = jobs).  d_cw is the table matching `algo` (cw for kAlgoSad, cw8 for kAlgoDot8).
 void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits);
+// Polyphase variant for phase_mode FINE, n_ms == 1, no inspection outputs (k_acq_poly.hip).  d_keyacc / d_sumacc: two
+// zeroed u32 planes of n_peaks entries; the trailing finalize kernel converts them into d_peaks.
+void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
+                     const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
+                     gpsx_peak_t *d_peaks);
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
                      int n_dopp, int n_bits, int shard_index, int shard_count);

@@ -1,0 +1,452 @@
+// k_acq_poly.hip -- the acquisition grid kernel for the fine (16368-phase) cold-start sweep, polyphase formulation.
+//
+// Same contract as k_acq (k_acq_grid.hip): per (search, PRN, Doppler, replica bit shift) the triplet correlation_search
+// (PM/GPS/gps_misc.c:155-191) returns, bit for bit; same preamble (capture -> LDS, carrier wipe-off K3), same
+// per-hypothesis corrections and magnitude.  What changes is how the 2 x 16368 sample-granular correlations
+//      M_t0(q) = sum_c chip[c] * S_t0[q + c],   S_t0[k] = pop(D[16 k + t0, +16)),   s = 16 q + t0
+// are obtained for the sixteen sample offsets t0 inside a chip.  Moving the windows by ONE sample changes each block sum
+// by one sample leaving and one entering:  S_{t0+1}[k] = S_t0[k] - d_t0[k] + d_t0[k + 1],  d_t0[k] = D(16 k + t0), so
+//      M_{t0+1}(q) = M_t0(q) - X_t0(q) + X_t0(q + 1),          X_t0(q) = sum_c chip[c] * d_t0[q + c]
+// and X is a correlation of two BIT vectors of length 1023: 32 words of v_and_b32 + v_bcnt_u32_b32 (accumulating) per
+// hypothesis and stream -- 64 instructions against the 128 v_dot8_u32_u4 of the direct form (and 2046 XOR/popcount
+// pairs in the reference).  d_t0 is the t0-th polyphase component of the wiped stream (every 16th sample).
+// A workgroup owns 1024 chip offsets q x G PRNs x I,Q for a SEGMENT of eight consecutive t0: the first is computed
+// directly (4-bit block sums, v_dot8_u32_u4, exact saturation pass -- as in k_acq), the next seven by the recurrence.
+// Per-(PRN, bit shift) search results are merged across the two segments (even / odd byte offsets) and the waves with
+// atomicMax / atomicAdd on two u32 planes; k_acq_finalize turns them into gpsx_peak_t.
+//
+// Lane l owns q = 4 l .. 4 l + 3; X_t0(4 l + 4) is lane l + 1's first value, exchanged through LDS.
+#include "gpsx_device.hpp"
+#include "gpsx_kernels.hpp"
+
+namespace gpsx {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kNibDwords = 264;   // 4-bit block sums, 2046 + pad nibbles (circular copy appended)
+constexpr int kFullWords = 68;    // bit plane of saturated windows
+constexpr int kPlaneWords = 66;   // one polyphase bit plane: 1023 bits + circular copy
+constexpr int kSegment = 8;       // sample offsets per workgroup
+constexpr int kPH = 4;            // PRNs per X pass (bounds the live X registers)
+
+template <int G>
+struct PolyShared {
+  uint16_t x[1024];                        // raw IF block
+  u32 d[2][514];                           // wiped I / Q streams (word 511 = wrap-around copy, then zero pad)
+  u32 s[2][kNibDwords];                    // 4-bit block sums of the segment's first offset, I / Q
+  u32 full[2][kFullWords];                 // their saturated windows
+  u32 any_full[2];
+  u32 ones[2];                             // pop(D) per stream
+  u32 plane[2][kSegment - 1][kPlaneWords]; // d_t0 for the seven recurrence steps, I / Q
+  u32 chipbits[G][34];
+  u32 xch[2 * kPH][kThreads];              // first X value of every lane, for its left neighbour
+};
+
+__device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
+{
+  return (words[byte_index >> 2] >> ((byte_index & 3) * 8)) & 0xFFu;
+}
+
+// Corrections of the reference's quirks, magnitude, windowed max / sum, merge into the global planes.
+// m_i / m_q: M_t0(q) for the lane's four q and G PRNs.
+template <int G>
+__device__ __forceinline__ void poly_finish_offset(const PolyShared<G> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
+                                                   const u32 (&m_q)[4][G], int win_start, int win_stop,
+                                                   const u32 *__restrict__ chipbits_g, int n_valid, size_t out0,
+                                                   size_t out_pstride, u32 *__restrict__ keyacc, u32 *__restrict__ sumacc)
+{
+  const int b = t0 & 7, half = t0 >> 3;
+  const u32 low_mask = (1u << b) - 1u;
+  const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));   // recompute lane-derived values here instead of keeping them live across the loops
+  const int base_i = __builtin_amdgcn_readfirstlane((int)sh.ones[0]) + kHalf + 8;   // C0 = pop(D) + 8192 - 2 M
+  const int base_q = __builtin_amdgcn_readfirstlane((int)sh.ones[1]) + kHalf + 8;
+  const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8;   // data bytes (2045, 0): the word odd offsets skip at the wrap
+  const u32 wrap_q = (sh.d[1][0] & 0xFFu) << 8;
+  u32 wrap_tab_i = 0, wrap_tab_q = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u32 r = ((k & 1) ? low_mask : 0u) | ((k & 2) ? high_mask : 0u);
+    wrap_tab_i |= pop16(wrap_i ^ r) << (8 * k);
+    wrap_tab_q |= pop16(wrap_q ^ r) << (8 * k);
+  }
+  wrap_tab_i = (u32)__builtin_amdgcn_readfirstlane((int)wrap_tab_i);
+  wrap_tab_q = (u32)__builtin_amdgcn_readfirstlane((int)wrap_tab_q);
+  const int q_hi = 4 * tid_e + 3;
+  const int chip_base = kChips - 2 - q_hi;   // lowest chip needed; bit k of chipwin = chip (chip_base + k)
+  const int chip_lo = chip_base < 0 ? 0 : chip_base;
+  u32 chipwin[G];
+  if (half) {
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      const u32 *cb = sh.chipbits[p];
+      const u64 two = (u64)cb[chip_lo >> 5] | ((u64)cb[(chip_lo >> 5) + 1] << 32);
+      const u32 w = (u32)(two >> (chip_lo & 31));
+      chipwin[p] = chip_base < 0 ? w << (chip_lo - chip_base) : w;
+    }
+  }
+  u32 best[G], total[G];
+#pragma unroll
+  for (int p = 0; p < G; p++) {
+    best[p] = 0;
+    total[p] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int q = 4 * tid_e + i;
+    const int o = 2 * q + half;
+    const bool exists = q < kChips;
+    const bool in_win = exists && o >= win_start && o < win_stop;
+    const int oc = exists ? o : 0;
+    const int adj_i = 2 * (int)__popc(lds_byte(sh.d[0], oc) & low_mask) - b;   // quirk Q5
+    const int adj_q = 2 * (int)__popc(lds_byte(sh.d[1], oc) & low_mask) - b;
+    const bool odd_tail = half && q > 0 && exists;                             // quirk Q3, replica word 1022
+    u32 prev_i = 0, prev_q = 0;
+    if (odd_tail) {
+      prev_i = lds_byte(sh.d[0], oc - 2) | (lds_byte(sh.d[0], oc - 1) << 8);
+      prev_q = lds_byte(sh.d[1], oc - 2) | (lds_byte(sh.d[1], oc - 1) << 8);
+    }
+    const int k0 = exists ? (kChips - 2 - q) - chip_base : 0;
+    const u32 key_lo = (u32)(2047 - o);
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      const u32 tail_bits = chipbits_g[p * 32 + 31];   // wave-uniform -> scalar load
+      const bool c1022 = (tail_bits >> 30) & 1u, c1021 = (tail_bits >> 29) & 1u;
+      int ci = base_i - 2 * (int)m_i[i][p] + (c1022 ? adj_i : 0);
+      int cq = base_q - 2 * (int)m_q[i][p] + (c1022 ? adj_q : 0);
+      if (half) {
+        const u32 sel8 = ((chipwin[p] >> k0) & 3u) * 8u;   // bit 0 = chip[p1 - 1], bit 1 = chip[p1], p1 = 1022 - q
+        ci -= (int)__builtin_amdgcn_ubfe(wrap_tab_i, sel8, 8u);
+        cq -= (int)__builtin_amdgcn_ubfe(wrap_tab_q, sel8, 8u);
+        const u32 r_last = (c1021 ? low_mask : 0u) | (c1022 ? high_mask : 0u);
+        ci -= odd_tail ? (int)__popc(prev_i ^ r_last) : 0;
+        cq -= odd_tail ? (int)__popc(prev_q ^ r_last) : 0;
+      }
+      const u32 val = in_win ? (u32)mag8_fast(ci, cq) : 0u;
+      const u32 key = in_win ? (val << 11) | key_lo : 0u;
+      best[p] = key > best[p] ? key : best[p];
+      total[p] += val;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // wave reduction, then one atomic pair per wave and PRN into the (PRN, bit shift) slot shared with the other segment
+#pragma unroll
+  for (int p = 0; p < G; p++) {
+    const u32 k = wave_max_u32(best[p]);
+    const u32 t = wave_sum_u32(total[p]);
+    if (lane == 0 && p < n_valid) {
+      const size_t idx = out0 + (size_t)p * out_pstride + (size_t)b;
+      atomicMax(&keyacc[idx], k);
+      atomicAdd(&sumacc[idx], t);
+    }
+  }
+}
+
+}  // namespace
+
+template <int G>
+__global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
+                                                          const u32 *__restrict__ cw8, const u32 *__restrict__ chipbits,
+                                                          u32 *__restrict__ keyacc, u32 *__restrict__ sumacc)
+{
+  __shared__ PolyShared<G> sh;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+
+  // ---- decode: (sharding unit = search x 16-PRN super group x Doppler) x group x segment ---------------------------
+  int id = blockIdx.x;
+  const int seg = id & 1;
+  id >>= 1;
+  const int gsel = id % kSuperGroups;
+  const int unit_local = id / kSuperGroups;
+  const int unit = prm.shard_index + unit_local * prm.shard_count;
+  const int dopp = unit % prm.n_dopp;
+  const int t = unit / prm.n_dopp;
+  const int n_super = (prm.n_groups + kSuperGroups - 1) / kSuperGroups;
+  const int super = t % n_super;
+  const int search = t / n_super;
+  const int group = super * kSuperGroups + gsel;
+  if (group >= prm.n_groups)
+    return;
+  const int slot0 = group * G;
+  const int n_valid = prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G;
+  const int t0_first = seg * kSegment;
+  const float freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
+  const u32 step_word = nco_step_per_word(freq_hz);
+  const u32 *cw_group = cw8 + (size_t)group * (kCodeWords / 2) * G;
+  const u32 *chipbits_g = chipbits + (size_t)slot0 * 32;
+  const size_t out_pstride = (size_t)prm.n_dopp * 8;
+  const size_t out0 = ((size_t)(search * prm.n_prn + slot0) * prm.n_dopp + dopp) * 8;
+
+  for (int i = tid; i < G * 34; i += kThreads) {
+    const int p = i / 34, w = i - p * 34;
+    sh.chipbits[p][w] = w < 32 ? chipbits_g[p * 32 + w] : 0u;
+  }
+
+  // ---- A1 / A2: capture -> LDS, carrier wipe-off (as k_acq) ---------------------------------------------------------
+  const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
+  const uint8_t *blk = if_blocks + (size_t)(search * prm.search_stride_blocks) * block_bytes;
+  for (int i = tid; i < 1024; i += kThreads)
+    sh.x[i] = i < kWords16 ? load_sign16(blk, i, prm.if_format) : (uint16_t)0;
+  for (int i = tid; i < 2 * kFullWords; i += kThreads)
+    (&sh.full[0][0])[i] = 0;
+  if (tid < 2) {
+    sh.any_full[tid] = 0;
+    sh.ones[tid] = 0;
+  }
+  __syncthreads();
+  {
+    const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
+    u32 ones_i = 0, ones_q = 0;
+    for (int w = tid; w < 514; w += kThreads) {
+      u32 vi = 0, vq = 0;
+      if (w < kWords32) {
+        const u32 quad = (step_word * (u32)w) >> 30;
+        vi = carrier_i(quad) ^ x32[w];
+        vq = carrier_q(quad) ^ x32[w];
+      }
+      sh.d[0][w] = vi;
+      sh.d[1][w] = vq;
+      ones_i += __popc(vi);
+      ones_q += __popc(vq);
+    }
+    ones_i = wave_sum_u32(ones_i);
+    ones_q = wave_sum_u32(ones_q);
+    if (lane == 0) {
+      atomicAdd(&sh.ones[0], ones_i);
+      atomicAdd(&sh.ones[1], ones_q);
+    }
+  }
+  __syncthreads();
+  if (tid < 2)
+    sh.d[tid][511] = sh.d[tid][0] << 16;   // samples 16352..16367 are zero, then the stream wraps to sample 0
+  __syncthreads();
+
+  // ---- A3: block sums of the segment's first offset (nibbles + saturated-window plane) --------------------------------
+  for (int m = tid; m < 2 * kNibDwords; m += kThreads) {
+    const int iq = m / kNibDwords;
+    const int dw = m - iq * kNibDwords;
+    const u32 *dd = sh.d[iq];
+    const int kd0 = dw * 8;
+    u32 packed = 0, fullbits = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int kd = kd0 + e;
+      const int k = kd >= 2 * kChips ? kd - 2 * kChips : (kd >= kChips ? kd - kChips : kd);
+      const int pos = 16 * k + t0_first;
+      const u32 sum = pop16(__builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31)));
+      packed |= (sum - (sum >> 4)) << (4 * e);
+      fullbits |= (sum >> 4) << e;
+    }
+    sh.s[iq][dw] = packed;
+    if (fullbits) {
+      atomicOr(&sh.full[iq][kd0 >> 5], fullbits << (kd0 & 31));
+      sh.any_full[iq] = 1u;
+    }
+  }
+  // ---- A4: polyphase bit planes d_t0[k] = D(16 k + t0) for the seven recurrence steps, circular copy appended ------------
+  for (int m = tid; m < 2 * (kSegment - 1) * kPlaneWords; m += kThreads) {
+    const int iq = m / ((kSegment - 1) * kPlaneWords);
+    const int r = m - iq * (kSegment - 1) * kPlaneWords;
+    const int st = r / kPlaneWords;
+    const int w = r - st * kPlaneWords;
+    const int t0 = t0_first + st;
+    const u32 *dd = sh.d[iq];
+    u32 bits = 0;
+#pragma unroll 8
+    for (int e = 0; e < 32; e++) {
+      const int kd = 32 * w + e;
+      const int k = kd >= 2 * kChips ? kd - 2 * kChips : (kd >= kChips ? kd - kChips : kd);
+      const int pos = 16 * k + t0;   // < 16368: the stream's own samples (the last 16 are zero)
+      bits |= ((dd[pos >> 5] >> (pos & 31)) & 1u) << e;
+    }
+    sh.plane[iq][st][w] = bits;
+  }
+  __syncthreads();
+
+  // ---- B0: M for the first offset, directly: v_dot8_u32_u4 on the 4-bit sums, then the exact saturation deficit ------
+  u32 m_i[4][G], m_q[4][G];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int p = 0; p < G; p++) {
+      m_i[i][p] = 0;
+      m_q[i][p] = 0;
+    }
+  {
+    // nibble 4 tid + i + 8 j lives in dword tid / 2 + j at bit 16 (tid & 1) + 4 i
+    const u32 *ni = sh.s[0] + (tid >> 1);
+    const u32 *nq = sh.s[1] + (tid >> 1);
+    const u32 sh0 = 16u * (u32)(tid & 1);
+    u32 cur_i = ni[0], cur_q = nq[0];
+#pragma unroll 2
+    for (int j = 0; j < kCodeWords / 2; j++) {
+      const u32 nxt_i = ni[j + 1];
+      const u32 nxt_q = nq[j + 1];
+      u32 wi[4], wq[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        wi[i] = __builtin_amdgcn_alignbit(nxt_i, cur_i, sh0 + 4u * (u32)i);
+        wq[i] = __builtin_amdgcn_alignbit(nxt_q, cur_q, sh0 + 4u * (u32)i);
+      }
+#pragma unroll
+      for (int p = 0; p < G; p++) {
+        const u32 code = cw_group[j * G + p];   // eight 0/1 chip nibbles, wave-uniform -> scalar load
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          m_i[i][p] = __builtin_amdgcn_udot8(wi[i], code, m_i[i][p], false);
+          m_q[i][p] = __builtin_amdgcn_udot8(wq[i], code, m_q[i][p], false);
+        }
+      }
+      cur_i = nxt_i;
+      cur_q = nxt_q;
+    }
+#pragma unroll 1
+    for (int iq = 0; iq < 2; iq++) {
+      if (!sh.any_full[iq])
+        continue;
+      const u32 *fw = sh.full[iq];
+#pragma unroll 1
+      for (int w = 0; w < 32; w++) {
+        u32 fwin[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int bit = 4 * tid + i + 32 * w;
+          fwin[i] = __builtin_amdgcn_alignbit(fw[(bit >> 5) + 1], fw[bit >> 5], (u32)(bit & 31));
+        }
+#pragma unroll
+        for (int p = 0; p < G; p++) {
+          const u32 chips32 = chipbits_g[p * 32 + w];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 add = (u32)__popc(fwin[i] & chips32);
+            if (iq == 0)
+              m_i[i][p] += add;
+            else
+              m_q[i][p] += add;
+          }
+        }
+      }
+    }
+  }
+  poly_finish_offset<G>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid, out0,
+                        out_pstride, keyacc, sumacc);
+
+  // ---- B1..B7: one sample further each: M += X(q + 1) - X(q), X = AND + popcount against the polyphase plane ----------
+#pragma unroll 1
+  for (int st = 0; st < kSegment - 1; st++) {
+    int tid_m = tid;
+    asm volatile("" : "+v"(tid_m));
+    const int wbase = tid_m >> 3;                    // bit 4 tid + i + 32 w  ->  word tid / 8 + w, bit 4 (tid % 8) + i
+    const u32 shb = 4u * (u32)(tid_m & 7);
+#pragma unroll
+    for (int ph = 0; ph < G / kPH; ph++) {   // unrolled: ph indexes the M registers
+      u32 x_i[4][kPH], x_q[4][kPH];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int p = 0; p < kPH; p++) {
+          x_i[i][p] = 0;
+          x_q[i][p] = 0;
+        }
+      const u32 *pi = sh.plane[0][st] + wbase;
+      const u32 *pq = sh.plane[1][st] + wbase;
+      u32 cur_i = pi[0], cur_q = pq[0];
+      // Four words per trip: the 16 chip words of a trip arrive by four s_load_dwordx4 (the loop is NOT unrolled further:
+      // hoisting all 128 chip words into SGPRs makes the compiler spill them through v_readlane, which costs more VALU
+      // issue slots than the correlation itself).  The popcount accumulates in the instruction (v_bcnt_u32_b32 d, s, d);
+      // written as asm because the optimiser otherwise reassociates the sums into bcnt + v_add3 chains.
+#pragma unroll 1
+      for (int w4 = 0; w4 < 8; w4++) {
+        u32 c32[kPH][4];
+#pragma unroll
+        for (int p = 0; p < kPH; p++) {
+          const uint4 c = *reinterpret_cast<const uint4 *>(chipbits_g + (ph * kPH + p) * 32 + 4 * w4);   // wave-uniform
+          c32[p][0] = c.x;
+          c32[p][1] = c.y;
+          c32[p][2] = c.z;
+          c32[p][3] = c.w;
+        }
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) {
+          const int w = 4 * w4 + ww;
+          const u32 nxt_i = pi[w + 1];
+          const u32 nxt_q = pq[w + 1];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const u32 wi = __builtin_amdgcn_alignbit(nxt_i, cur_i, shb + (u32)i);
+            const u32 wq = __builtin_amdgcn_alignbit(nxt_q, cur_q, shb + (u32)i);
+#pragma unroll
+            for (int p = 0; p < kPH; p++) {
+              const u32 ai = wi & c32[p][ww];
+              const u32 aq = wq & c32[p][ww];
+              asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x_i[i][p]) : "v"(ai));
+              asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x_q[i][p]) : "v"(aq));
+            }
+          }
+          cur_i = nxt_i;
+          cur_q = nxt_q;
+        }
+      }
+      // X(4 tid + 4) is the right neighbour's first value; lane 255's is X(1024) = X(1) = lane 0's second... not needed:
+      // lane 255 owns q = 1020..1023 and only q <= 1022 exist, so its i = 3 result is never used.
+      __syncthreads();   // previous readers of xch are done
+#pragma unroll
+      for (int p = 0; p < kPH; p++) {
+        sh.xch[2 * p][tid] = x_i[0][p];
+        sh.xch[2 * p + 1][tid] = x_q[0][p];
+      }
+      __syncthreads();
+      const int nb = tid < kThreads - 1 ? tid + 1 : tid;
+#pragma unroll
+      for (int p = 0; p < kPH; p++) {
+        const u32 right_i = sh.xch[2 * p][nb];
+        const u32 right_q = sh.xch[2 * p + 1][nb];
+        const int pp = ph * kPH + p;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          m_i[i][pp] += x_i[i + 1][p] - x_i[i][p];
+          m_q[i][pp] += x_q[i + 1][p] - x_q[i][p];
+        }
+        m_i[3][pp] += right_i - x_i[3][p];
+        m_q[3][pp] += right_q - x_q[3][p];
+      }
+    }
+    poly_finish_offset<G>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
+                          out0, out_pstride, keyacc, sumacc);
+  }
+}
+
+// (packed key, sum) planes -> gpsx_peak_t
+__global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__restrict__ sumacc, size_t n,
+                               gpsx_peak_t *__restrict__ peaks)
+{
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n)
+    return;
+  const u32 k = keyacc[idx], t = sumacc[idx];
+  gpsx_peak_t pk;
+  pk.max_val = k >> 11;
+  pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+  pk.sum = t;
+  pk.avr = t / (2u * kChips);
+  peaks[idx] = pk;
+}
+
+void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
+                     const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
+                     gpsx_peak_t *d_peaks)
+{
+  if (local_units > 0) {
+    const int n_wg = (int)(local_units * kSuperGroups * 2);
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup>), dim3(n_wg), dim3(kThreads), 0, s, prm, d_if, d_cw8, d_chipbits, d_keyacc,
+                       d_sumacc);
+  }
+  if (n_peaks > 0)
+    hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
+                       n_peaks, d_peaks);
+}
+
+}  // namespace gpsx
