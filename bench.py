@@ -15,7 +15,7 @@ units are dealt round-robin to the ranks (per-GPU work is constant: weak scaling
 Prints one JSON line on rank 0.  `roofline` is priced the way SURVEY.md 8(d) prescribes for a bytes-based roofline
 (6138 operand bytes per hypothesis as the reference streams them); the kernel itself keeps its operands in LDS and is
 bound by integer VALU issue, which `roofline_valu` prices (2048 lane-ops per hypothesis in the reference's XOR/popcount
-formulation; the dot8 kernel issues ~6x fewer).  `cpu_baseline` times the reference's own C (oracle/_ref, built in
+formulation; the polyphase kernel issues ~9x fewer).  `cpu_baseline` times the reference's own C (oracle/_ref, built in
 place from the reference tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.
 """
 import argparse
@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--searches", type=int, default=16, help="1 ms captures per GPU per step")
+    ap.add_argument("--searches", type=int, default=64, help="1 ms captures per GPU per step")
     ap.add_argument("--amp-scale", type=float, default=0.25,
                     help="scale of the six synthetic satellites' amplitudes: 0.25 (default) puts each satellite below the "
                          "noise like a live antenna; 1.0 is the strong test signal, whose long runs of saturated block sums "
@@ -289,7 +289,7 @@ def main():
                 "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "gpsx::k_acq<8,false,dot8>" if os.environ.get("GPSX_ACQ_ALGO", "dot8") != "sad" else "gpsx::k_acq<8,false,sad>",
+                "kernel": {"poly": "gpsx::k_acq_poly<8,16>", "dot8": "gpsx::k_acq<8,false,dot8>", "sad": "gpsx::k_acq<8,false,sad>"}.get(os.environ.get("GPSX_ACQ_ALGO", "poly"), "gpsx::k_acq_poly<8,16>"),
                 "kernel_ms": launch_ms,
                 "note": "algorithmic bytes = 6138 B/hypothesis as the reference streams its operands (SURVEY.md 8(d)); "
                         "the kernel stages the 2 KB capture in LDS, so real HBM traffic is ~0 and frac may exceed 1; "
@@ -302,7 +302,7 @@ def main():
                 "unit": "Tlane-op/s",
                 "frac": ach_tops / VALU_INT_PEAK_TOPS,
                 "note": "algorithmic lane-ops = 2048/hypothesis (reference XOR+popcount formulation); the SAD kernel "
-                        "issues ~350/hypothesis, so frac > 1 is possible; issued-op efficiency is in profiles/",
+                        "issues ~230/hypothesis, so frac > 1 is possible; issued-op efficiency is in profiles/",
             },
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }

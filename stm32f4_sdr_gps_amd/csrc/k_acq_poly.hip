@@ -10,12 +10,14 @@
 // and X is a correlation of two BIT vectors of length 1023: 32 words of v_and_b32 + v_bcnt_u32_b32 (accumulating) per
 // hypothesis and stream -- 64 instructions against the 128 v_dot8_u32_u4 of the direct form (and 2046 XOR/popcount
 // pairs in the reference).  d_t0 is the t0-th polyphase component of the wiped stream (every 16th sample).
-// A workgroup owns 1024 chip offsets q x G PRNs x I,Q for a SEGMENT of eight consecutive t0: the first is computed
-// directly (4-bit block sums, v_dot8_u32_u4, exact saturation pass -- as in k_acq), the next seven by the recurrence.
-// Per-(PRN, bit shift) search results are merged across the two segments (even / odd byte offsets) and the waves with
-// atomicMax / atomicAdd on two u32 planes; k_acq_finalize turns them into gpsx_peak_t.
+// A workgroup owns 1024 chip offsets q x G PRNs x I,Q for a SEGMENT of 8 or 16 consecutive t0: the first is computed
+// directly (4-bit block sums, v_dot8_u32_u4, exact saturation pass -- as in k_acq), the others by the recurrence.
+// Per-(PRN, bit shift) search results are merged across even / odd byte offsets (t0 = b and b + 8), segments and
+// waves with atomicMax / atomicAdd on two u32 planes; k_acq_finalize turns them into gpsx_peak_t.
 //
 // Lane l owns q = 4 l .. 4 l + 3; X_t0(4 l + 4) is lane l + 1's first value, exchanged through LDS.
+#include <cstdlib>
+
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
 
@@ -27,10 +29,10 @@ constexpr int kThreads = 256;
 constexpr int kNibDwords = 264;   // 4-bit block sums, 2046 + pad nibbles (circular copy appended)
 constexpr int kFullWords = 68;    // bit plane of saturated windows
 constexpr int kPlaneWords = 66;   // one polyphase bit plane: 1023 bits + circular copy
-constexpr int kSegment = 8;       // sample offsets per workgroup
-constexpr int kPH = 4;            // PRNs per X pass (bounds the live X registers)
+constexpr int kMaxSegment = 16;   // sample offsets per workgroup: 8 (two workgroups per chip) or 16 (one)
+constexpr int kPH = 8;            // PRNs per X pass (all of the group: X and M registers together still fit 168 VGPRs)
 
-template <int G>
+template <int G, int SEG>
 struct PolyShared {
   uint16_t x[1024];                        // raw IF block
   u32 d[2][514];                           // wiped I / Q streams (word 511 = wrap-around copy, then zero pad)
@@ -38,7 +40,7 @@ struct PolyShared {
   u32 full[2][kFullWords];                 // their saturated windows
   u32 any_full[2];
   u32 ones[2];                             // pop(D) per stream
-  u32 plane[2][kSegment - 1][kPlaneWords]; // d_t0 for the seven recurrence steps, I / Q
+  u32 plane[2][SEG - 1][kPlaneWords];      // d_t0 for the SEG - 1 recurrence steps, I / Q
   u32 chipbits[G][34];
   u32 xch[2 * kPH][kThreads];              // first X value of every lane, for its left neighbour
 };
@@ -50,8 +52,8 @@ __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
 
 // Corrections of the reference's quirks, magnitude, windowed max / sum, merge into the global planes.
 // m_i / m_q: M_t0(q) for the lane's four q and G PRNs.
-template <int G>
-__device__ __forceinline__ void poly_finish_offset(const PolyShared<G> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
+template <int G, int SEG>
+__device__ __forceinline__ void poly_finish_offset(const PolyShared<G, SEG> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
                                                    const u32 (&m_q)[4][G], int win_start, int win_stop,
                                                    const u32 *__restrict__ chipbits_g, int n_valid, size_t out0,
                                                    size_t out_pstride, u32 *__restrict__ keyacc, u32 *__restrict__ sumacc)
@@ -146,19 +148,20 @@ __device__ __forceinline__ void poly_finish_offset(const PolyShared<G> &sh, int 
 
 }  // namespace
 
-template <int G>
+template <int G, int SEG>
 __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ cw8, const u32 *__restrict__ chipbits,
                                                           u32 *__restrict__ keyacc, u32 *__restrict__ sumacc)
 {
-  __shared__ PolyShared<G> sh;
+  __shared__ PolyShared<G, SEG> sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
 
   // ---- decode: (sharding unit = search x 16-PRN super group x Doppler) x group x segment ---------------------------
+  constexpr int kSegs = kMaxSegment / SEG;   // workgroups per chip
   int id = blockIdx.x;
-  const int seg = id & 1;
-  id >>= 1;
+  const int seg = id % kSegs;
+  id /= kSegs;
   const int gsel = id % kSuperGroups;
   const int unit_local = id / kSuperGroups;
   const int unit = prm.shard_index + unit_local * prm.shard_count;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     return;
   const int slot0 = group * G;
   const int n_valid = prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G;
-  const int t0_first = seg * kSegment;
+  const int t0_first = seg * SEG;
   const float freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
   const u32 step_word = nco_step_per_word(freq_hz);
   const u32 *cw_group = cw8 + (size_t)group * (kCodeWords / 2) * G;
@@ -247,9 +250,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     }
   }
   // ---- A4: polyphase bit planes d_t0[k] = D(16 k + t0) for the seven recurrence steps, circular copy appended ------------
-  for (int m = tid; m < 2 * (kSegment - 1) * kPlaneWords; m += kThreads) {
-    const int iq = m / ((kSegment - 1) * kPlaneWords);
-    const int r = m - iq * (kSegment - 1) * kPlaneWords;
+  for (int m = tid; m < 2 * (SEG - 1) * kPlaneWords; m += kThreads) {
+    const int iq = m / ((SEG - 1) * kPlaneWords);
+    const int r = m - iq * (SEG - 1) * kPlaneWords;
     const int st = r / kPlaneWords;
     const int w = r - st * kPlaneWords;
     const int t0 = t0_first + st;
@@ -331,12 +334,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
       }
     }
   }
-  poly_finish_offset<G>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid, out0,
+  poly_finish_offset<G, SEG>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid, out0,
                         out_pstride, keyacc, sumacc);
 
   // ---- B1..B7: one sample further each: M += X(q + 1) - X(q), X = AND + popcount against the polyphase plane ----------
 #pragma unroll 1
-  for (int st = 0; st < kSegment - 1; st++) {
+  for (int st = 0; st < SEG - 1; st++) {
     int tid_m = tid;
     asm volatile("" : "+v"(tid_m));
     const int wbase = tid_m >> 3;                    // bit 4 tid + i + 32 w  ->  word tid / 8 + w, bit 4 (tid % 8) + i
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
         m_q[3][pp] += right_q - x_q[3][p];
       }
     }
-    poly_finish_offset<G>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
+    poly_finish_offset<G, SEG>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
                           out0, out_pstride, keyacc, sumacc);
   }
 }
@@ -440,9 +443,17 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
                      gpsx_peak_t *d_peaks)
 {
   if (local_units > 0) {
-    const int n_wg = (int)(local_units * kSuperGroups * 2);
-    hipLaunchKernelGGL((k_acq_poly<kAcqGroup>), dim3(n_wg), dim3(kThreads), 0, s, prm, d_if, d_cw8, d_chipbits, d_keyacc,
-                       d_sumacc);
+    // One workgroup per chip (16 offsets: one direct step + 15 recurrence steps) when that still leaves several waves
+    // of workgroups per CU slot; otherwise two (8 offsets each) for balance.
+    static const char *force = std::getenv("GPSX_ACQ_SEG");   // "8" / "16": A/B measurements
+    const long wg16 = local_units * kSuperGroups;
+    const bool seg16 = force ? force[0] == '1' : wg16 >= 6 * 768;
+    if (seg16)
+      hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                         d_chipbits, d_keyacc, d_sumacc);
+    else
+      hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                         d_chipbits, d_keyacc, d_sumacc);
   }
   if (n_peaks > 0)
     hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,

@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag="r01", searches=16):
+def main(tag="r01", searches=64):
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -28,7 +28,7 @@ def main(tag="r01", searches=16):
         agg = collections.defaultdict(list)
         meta = {}
         for r in csv.DictReader(open(path)):
-            if "k_acq<" in r["Kernel_Name"]:
+            if "k_acq<" in r["Kernel_Name"] or "k_acq_poly<" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
                                           "Accum_VGPR_Count", "SGPR_Count")}
@@ -38,7 +38,7 @@ def main(tag="r01", searches=16):
     c = summary["counters_avg_per_launch"]
     with open(os.path.join(src, "trace", "trace_kernel_stats.csv")) as f:
         for r in csv.DictReader(f):
-            if "k_acq<" in r["Name"]:
+            if "k_acq<" in r["Name"] or "k_acq_poly<" in r["Name"]:
                 summary["kernel_trace_avg_ns"] = float(r["AverageNs"])
                 summary["kernel_trace_calls"] = int(r["Calls"])
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
