@@ -467,9 +467,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
       HIPCHK(ctx, hipMalloc((void **)&ctx->d_acc, 2 * n_peaks * sizeof(uint32_t)));
       ctx->acc_entries = n_peaks;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_acc, 0, 2 * n_peaks * sizeof(uint32_t), ctx->stream));
     launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
-                    ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks);
+                    ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1);
     LAUNCHCHK(ctx, "k_acq_poly");
   } else {
     const int algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;

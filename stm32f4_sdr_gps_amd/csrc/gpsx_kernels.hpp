@@ -58,10 +58,11 @@ void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int g
 void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits);
 // Polyphase variant for phase_mode FINE, n_ms == 1, no inspection outputs (k_acq_poly.hip).  d_keyacc / d_sumacc: two
-// zeroed u32 planes of n_peaks entries; the trailing finalize kernel converts them into d_peaks.
+// u32 scratch planes of n_peaks entries, used (zeroed, merged with atomics, converted into d_peaks) only when the launch
+// is split into two 8-offset workgroups per chip; the one-workgroup-per-chip form writes d_peaks directly.
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks);
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero);
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
                      int n_dopp, int n_bits, int shard_index, int shard_count);

@@ -43,6 +43,8 @@ struct PolyShared {
   u32 plane[2][SEG - 1][kPlaneWords];      // d_t0 for the SEG - 1 recurrence steps, I / Q
   u32 chipbits[G][34];
   u32 xch[2 * kPH][kThreads];              // first X value of every lane, for its left neighbour
+  u32 part[8][G][2];                       // SEG == 16: (packed best key, sum) per bit shift and PRN, merged over the
+                                           // four waves and the two offsets (t0 = b: even byte offsets, b + 8: odd)
 };
 
 __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
@@ -53,10 +55,11 @@ __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
 // Corrections of the reference's quirks, magnitude, windowed max / sum, merge into the global planes.
 // m_i / m_q: M_t0(q) for the lane's four q and G PRNs.
 template <int G, int SEG>
-__device__ __forceinline__ void poly_finish_offset(const PolyShared<G, SEG> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
+__device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
                                                    const u32 (&m_q)[4][G], int win_start, int win_stop,
                                                    const u32 *__restrict__ chipbits_g, int n_valid, size_t out0,
-                                                   size_t out_pstride, u32 *__restrict__ keyacc, u32 *__restrict__ sumacc)
+                                                   size_t out_pstride, u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
+                                                   gpsx_peak_t *__restrict__ peaks)
 {
   const int b = t0 & 7, half = t0 >> 3;
   const u32 low_mask = (1u << b) - 1u;
@@ -133,15 +136,34 @@ __device__ __forceinline__ void poly_finish_offset(const PolyShared<G, SEG> &sh,
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // wave reduction, then one atomic pair per wave and PRN into the (PRN, bit shift) slot shared with the other segment
+  // Wave reduction, then merge.  SEG == 16: the workgroup sees both offsets of every bit shift, so the merge stays in
+  // LDS and the finished triplet is written once; SEG == 8: the other offset belongs to another workgroup, merge through
+  // global atomics (k_acq_finalize converts the planes afterwards).
 #pragma unroll
   for (int p = 0; p < G; p++) {
     const u32 k = wave_max_u32(best[p]);
     const u32 t = wave_sum_u32(total[p]);
     if (lane == 0 && p < n_valid) {
-      const size_t idx = out0 + (size_t)p * out_pstride + (size_t)b;
-      atomicMax(&keyacc[idx], k);
-      atomicAdd(&sumacc[idx], t);
+      if (SEG == 16) {
+        atomicMax(&sh.part[b][p][0], k);
+        atomicAdd(&sh.part[b][p][1], t);
+      } else {
+        const size_t idx = out0 + (size_t)p * out_pstride + (size_t)b;
+        atomicMax(&keyacc[idx], k);
+        atomicAdd(&sumacc[idx], t);
+      }
+    }
+  }
+  if (SEG == 16 && half) {
+    __syncthreads();
+    if (tid < n_valid) {
+      const u32 k = sh.part[b][tid][0], t = sh.part[b][tid][1];
+      gpsx_peak_t pk;
+      pk.max_val = k >> 11;
+      pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+      pk.sum = t;
+      pk.avr = t / (2u * kChips);
+      peaks[out0 + (size_t)tid * out_pstride + (size_t)b] = pk;
     }
   }
 }
@@ -151,7 +173,8 @@ __device__ __forceinline__ void poly_finish_offset(const PolyShared<G, SEG> &sh,
 template <int G, int SEG>
 __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ cw8, const u32 *__restrict__ chipbits,
-                                                          u32 *__restrict__ keyacc, u32 *__restrict__ sumacc)
+                                                          u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
+                                                          gpsx_peak_t *__restrict__ peaks)
 {
   __shared__ PolyShared<G, SEG> sh;
   const int tid = threadIdx.x;
@@ -199,6 +222,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     sh.any_full[tid] = 0;
     sh.ones[tid] = 0;
   }
+  for (int i = tid; i < 8 * G * 2; i += kThreads)
+    (&sh.part[0][0][0])[i] = 0;
   __syncthreads();
   {
     const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     }
   }
   poly_finish_offset<G, SEG>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid, out0,
-                        out_pstride, keyacc, sumacc);
+                        out_pstride, keyacc, sumacc, peaks);
 
   // ---- B1..B7: one sample further each: M += X(q + 1) - X(q), X = AND + popcount against the polyphase plane ----------
 #pragma unroll 1
@@ -418,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
       }
     }
     poly_finish_offset<G, SEG>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
-                          out0, out_pstride, keyacc, sumacc);
+                          out0, out_pstride, keyacc, sumacc, peaks);
   }
 }
 
@@ -440,24 +465,27 @@ __global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__rest
 
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks)
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero)
 {
-  if (local_units > 0) {
-    // One workgroup per chip (16 offsets: one direct step + 15 recurrence steps) when that still leaves several waves
-    // of workgroups per CU slot; otherwise two (8 offsets each) for balance.
-    static const char *force = std::getenv("GPSX_ACQ_SEG");   // "8" / "16": A/B measurements
-    const long wg16 = local_units * kSuperGroups;
-    const bool seg16 = force ? force[0] == '1' : wg16 >= 6 * 768;
-    if (seg16)
-      hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
-                         d_chipbits, d_keyacc, d_sumacc);
-    else
-      hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
-                         d_chipbits, d_keyacc, d_sumacc);
-  }
-  if (n_peaks > 0)
+  if (local_units <= 0 || n_peaks == 0)
+    return;
+  // One workgroup per chip (16 offsets: one direct step + 15 recurrence steps; results merged in LDS and written once)
+  // when that still leaves several waves of workgroups per CU slot; otherwise two (8 offsets each, merged through
+  // global atomics on two scratch planes and converted by k_acq_finalize) for balance.
+  static const char *force = std::getenv("GPSX_ACQ_SEG");   // "8" / "16": A/B measurements
+  const long wg16 = local_units * kSuperGroups;
+  const bool seg16 = force ? force[0] == '1' : wg16 >= 6 * 768;
+  if (seg16) {
+    (void)peaks_are_zero;   // units of other shards keep whatever the caller zeroed
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                       d_chipbits, d_keyacc, d_sumacc, d_peaks);
+  } else {
+    (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                       d_chipbits, d_keyacc, d_sumacc, d_peaks);
     hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
                        n_peaks, d_peaks);
+  }
 }
 
 }  // namespace gpsx
