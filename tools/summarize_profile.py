@@ -62,10 +62,14 @@ def main(tag="r01", searches=64):
             # main-loop instructions the formulation needs: workgroups x 4 waves x 2 halves x steps x 64
             "main_loop_wave_instructions_sad": searches * 672 * 4 * 2 * 256 * 64,
             "main_loop_wave_instructions_dot8": searches * 672 * 4 * 2 * 128 * 64,
+            # polyphase kernel: per (search, Doppler, PRN group) 4 waves x (one direct offset of 128 x 64 dots
+            # + 15 recurrence offsets of 32 words x 64 (and + bcnt) pairs)
+            "main_loop_wave_instructions_poly": searches * 21 * 4 * 4 * (128 * 64 + 15 * 32 * 128),
         }
         d = summary["derived"]
         d["sad_share_of_valu"] = d["main_loop_wave_instructions_sad"] / c["SQ_INSTS_VALU"]
         d["dot8_share_of_valu"] = d["main_loop_wave_instructions_dot8"] / c["SQ_INSTS_VALU"]
+        d["poly_share_of_valu"] = d["main_loop_wave_instructions_poly"] / c["SQ_INSTS_VALU"]
     with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
