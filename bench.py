@@ -110,6 +110,9 @@ def main():
                     help="scale of the six synthetic satellites' amplitudes: 0.25 (default) puts each satellite below the "
                          "noise like a live antenna; 1.0 is the strong test signal, whose long runs of saturated block sums "
                          "take the kernel's exact-correction pass far more often (reported in profiles/ as the slow case)")
+    ap.add_argument("--n-ms", type=int, default=1,
+                    help="blocks integrated non-coherently per search (BASELINE.json configs[3] uses 10); hypotheses are "
+                         "then counted per block, as SURVEY.md 8(d) config 4 does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -150,9 +153,10 @@ def main():
 
     n_search = args.searches * world
     # synthetic captures: consecutive milliseconds of one stream; identical on every rank (each rank reads all of it)
-    blocks = synth.cold_start_block(n_search, seed=11, amp_scale=args.amp_scale)
+    n_ms = args.n_ms
+    blocks = synth.cold_start_block(n_search * n_ms, seed=11, amp_scale=args.amp_scale)
     prns = np.arange(1, N_PRN + 1, dtype=np.uint8)
-    g = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+    g = eng.grid_desc(prns, n_search=n_search, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=DOPP_MIN,
                       dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046),
                       shard=(rank, world))
     import ctypes as C
@@ -171,7 +175,7 @@ def main():
                 pending[slot].wait()
                 pending[slot] = None
             keys_t = key_bufs[slot]
-            rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
+            rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
                                            keys_t.data_ptr(), None, None, None)
             if rc != 0:
                 raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
@@ -213,7 +217,7 @@ def main():
     # PCIe-inclusive rate of the host-buffer entry point (H2D of the captures + launch + D2H of peaks and keys); reported
     # as an extra, never as `value`
     pcie = None
-    if world == 1:
+    if world == 1 and n_ms == 1:
         g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
                            dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
         h_peaks = np.zeros((n_search, N_PRN, N_DOPP, 8), capi.PEAK_DTYPE)
@@ -235,11 +239,11 @@ def main():
 
     if use_dist and os.environ.get("GPSX_BENCH_VERIFY") == "1":
         # the merged table must equal what one GPU computes for the whole grid (checked outside the timed region)
-        g_all = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+        g_all = eng.grid_desc(prns, n_search=n_search, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=DOPP_MIN,
                               dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
         with torch.cuda.stream(stream):
             d_keys_all = torch.zeros_like(d_keys)
-            rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_all), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
+            rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_all), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
                                            d_keys_all.data_ptr(), None, None, None)
             assert rc == 0
         torch.cuda.synchronize()
@@ -248,10 +252,10 @@ def main():
             print("VERIFY sharded == unsharded", flush=True)
 
     if rank == 0:
-        total_hyp = float(args.steps) * n_search * HYP_PER_SEARCH
+        total_hyp = float(args.steps) * n_search * n_ms * HYP_PER_SEARCH
         value = total_hyp / elapsed_s
         launch_ms = gpu_ms / args.steps                   # HIP events on the engine's stream around the K launches
-        hyp_per_launch = args.searches * HYP_PER_SEARCH   # per GPU
+        hyp_per_launch = args.searches * n_ms * HYP_PER_SEARCH   # per GPU
         ach_gbs = hyp_per_launch * BYTES_PER_HYP / (launch_ms * 1e-3) / 1e9
         ach_tops = hyp_per_launch * LANE_OPS_PER_HYP / (launch_ms * 1e-3) / 1e12
         traffic = None
@@ -259,7 +263,7 @@ def main():
         if os.path.exists(tr_file):
             with open(tr_file) as f:
                 tr = json.load(f)
-            if tr.get("searches_per_launch") == args.searches:
+            if tr.get("searches_per_launch") == args.searches and n_ms == 1:
                 traffic = tr.get("hbm_bytes_per_launch")
         line = {
             "metric": "acquisition hypotheses/sec (PRN x Doppler x phase)",
@@ -275,10 +279,13 @@ def main():
             "dtype": "u8",
             "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11)",
             "config": {
-                "workload": "cold-start acquisition grid: 32 PRN x 21 Doppler (+-5 kHz @ 500 Hz) x 16368 code phases, "
-                            "1 ms coherent, 16.368 Msps 1-bit IF (BASELINE.json configs[2])",
+                "workload": ("cold-start acquisition grid: 32 PRN x 21 Doppler (+-5 kHz @ 500 Hz) x 16368 code phases, "
+                             "1 ms coherent, 16.368 Msps 1-bit IF (BASELINE.json configs[2])") if n_ms == 1 else
+                            (f"32-PRN acquisition grid (21 Doppler x 16368 phases) with {n_ms} ms non-coherent integration "
+                             "(BASELINE.json configs[3]); hypotheses counted per 1 ms block"),
                 "searches_per_gpu_per_step": args.searches,
-                "hypotheses_per_step": n_search * HYP_PER_SEARCH,
+                "hypotheses_per_step": n_search * n_ms * HYP_PER_SEARCH,
+                "blocks_per_search": n_ms,
                 "parallelism": f"grid units dealt round-robin to {world} rank(s); one all-reduce(MAX) of packed peak keys"
                                if world > 1 else "single GPU",
             },
