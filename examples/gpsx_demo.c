@@ -4,8 +4,8 @@
  * a hosted system: the 4-satellite channel table with PRN + Doppler-hint inputs, acquisition steps on captured
  * milliseconds until every channel is acquired, then 17-slot multiplexed tracking steps -- with libgpsx.so in place of
  * gps_misc.c / acquisition.c / tracking.c.  The capture driver is replaced by a raw IF file (1 bit per sample, LSB
- * first, 2046 bytes per millisecond: the format PC_SpiLight replays), and the small channel sequencer below restates
- * what gps_master_handling() does for acquisition (gps_master.c:68-129).
+ * first, 2046 bytes per millisecond: the format PC_SpiLight replays); gps_master_handling() / gps_master_need_acq()
+ * (gps_master.h) sequence the channels exactly as in the firmware.
  *
  *   gcc -O2 -I include examples/gpsx_demo.c -L stm32f4_sdr_gps_amd/lib -lgpsx \
  *       -Wl,-rpath,$PWD/stm32f4_sdr_gps_amd/lib -lm -o gpsx_demo
@@ -22,44 +22,6 @@
 #define BLOCK_BYTES (PRN_SPI_WORDS_CNT * 2)
 
 static gps_ch_t gps_channels[GPS_SAT_CNT];
-static int gps_start_flag = 1;
-
-/* channel sequencing during acquisition; returns non-zero while any channel still needs acquisition */
-static int master_handling(gps_ch_t *ch)
-{
-  int need_acq = 0, need_freq = 0, stage3_ready = 0;
-  if (gps_start_flag) {
-    gps_start_flag = 0;
-    acquisition_start_channel(&ch[0]);
-  }
-  for (int i = 0; i < GPS_SAT_CNT; i++) {
-    if (ch[i].acq_data.state != GPS_ACQ_DONE) need_acq = 1;
-    if (ch[i].acq_data.state < GPS_ACQ_FREQ_SEARCH_DONE) need_freq = 1;
-    if (ch[i].acq_data.state == GPS_ACQ_CODE_PHASE_SEARCH2_DONE) stage3_ready++;
-  }
-  if (need_acq) {
-    for (int i = 0; i < GPS_SAT_CNT - 1; i++) {
-      if (ch[i].acq_data.state == GPS_ACQ_FREQ_SEARCH_DONE && ch[i + 1].acq_data.state == GPS_ACQ_NEED_FREQ_SEARCH) {
-        acquisition_start_channel(&ch[i + 1]);   /* frequency search (or hint) one channel at a time */
-        return need_acq;
-      }
-    }
-  }
-  if (!need_freq && need_acq) {
-    for (int i = 0; i < GPS_SAT_CNT; i++) {
-      if (ch[i].acq_data.state == GPS_ACQ_FREQ_SEARCH_DONE)
-        acquisition_start_code_search_channel(&ch[i]);
-      if (stage3_ready == GPS_SAT_CNT)
-        acquisition_start_code_search3_channel(&ch[i]);
-    }
-  }
-  if (!need_acq) {
-    for (int i = 0; i < GPS_SAT_CNT; i++)
-      if (ch[i].tracking_data.state == GPS_TRACKNG_IDLE)
-        ch[i].tracking_data.state = GPS_NEED_PRE_TRACK;
-  }
-  return need_acq;
-}
 
 int main(int argc, char **argv)
 {
@@ -88,13 +50,13 @@ int main(int argc, char **argv)
   uint8_t block[BLOCK_BYTES];
   long t = 0, acquired_at = -1;
   gpsx_compat_set_packet_cnt(0);
-  int need_acq = master_handling(gps_channels);
+  gps_master_handling(gps_channels, 0);
   for (; t < max_ms && fread(block, 1, BLOCK_BYTES, f) == BLOCK_BYTES; t++) {
     gpsx_compat_set_packet_cnt((uint32_t)t);           /* the capture driver's 1 ms tick */
-    if (need_acq) {
+    if (gps_master_need_acq()) {
       acquisition_process(gps_channels, block);         /* main_process_acq_data, PM/main.c:163-168 */
-      need_acq = master_handling(gps_channels);
-      if (!need_acq)
+      gps_master_handling(gps_channels, 0);
+      if (!gps_master_need_acq())
         acquired_at = t;
     } else {
       const long slot = t % (TRACKING_CH_LENGTH * GPS_SAT_CNT + 1);   /* main_fast_data_proc, PM/main.c:134-158 */
@@ -102,7 +64,7 @@ int main(int argc, char **argv)
       if (sat >= GPS_SAT_CNT) sat = 0;
       const uint8_t index = slot == TRACKING_CH_LENGTH * GPS_SAT_CNT ? 0xFF : (uint8_t)(slot % TRACKING_CH_LENGTH);
       gps_tracking_process(&gps_channels[sat], block, index);
-      need_acq = master_handling(gps_channels);
+      gps_master_handling(gps_channels, index);
     }
   }
   fclose(f);

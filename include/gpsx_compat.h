@@ -180,6 +180,19 @@ void      acquisition_start_code_search3_channel(gps_ch_t *channel);
 /* One tracking step (pre-tracking or E/P/L + DLL/PLL/FLL) of one channel; index = 0..3, or 0xFF for the idle slot. */
 void      gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index);
 
+/* --- channel sequencing (PM/GPS/gps_master.h:7-14; gps_master.c:68-129,458-510) ------------------------------------- */
+/* Starts acquisition channel by channel, opens the code-phase searches together, hands finished channels to tracking
+ * (GPS_NEED_PRE_TRACK).  Call it after every acquisition_process / gps_tracking_process, as PM/main.c:157,167 does.
+ * The reference's navigation / pseudorange / PVT / UI duties are not reproduced: gps_master_nav_handling is a weak
+ * no-op hook (called in the idle slot, index 0xFF), key_up_presed a weak variable a host may set. */
+void    gps_master_handling(gps_ch_t *channels /* [GPS_SAT_CNT] */, uint8_t index);
+uint8_t gps_master_need_acq(void);
+uint8_t gps_master_need_freq_search(gps_ch_t *channels);
+uint8_t gps_master_is_code_search3(gps_ch_t *channels);
+void    gps_master_reset_to_aqc_start(gps_ch_t *channels);
+void    gps_master_nav_handling(gps_ch_t *channels);
+extern uint8_t key_up_presed;
+
 /* NOT in the reference: one tracking step of n_ch channels on the same millisecond, each channel served every
  * millisecond as in the single-satellite firmware's schedule (project_single_sat/main.c:96-109; index cycles 0..3).
  * All channels' pre-tracking searches and E/P/L correlators go out as one launch each, which is what keeps hundreds of

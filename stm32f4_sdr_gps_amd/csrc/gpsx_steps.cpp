@@ -750,6 +750,100 @@ void acquisition_process(gps_ch_t *channel, uint8_t *data)
   }
 }
 
+// ---- gps_master.h: channel sequencing (PM/GPS/gps_master.c:68-129, 458-510) -------------------------------------------------
+// The part of the reference's "GPS master" that drives the step calls above: start acquisition channel by channel,
+// open the code-phase searches together, hand finished channels to tracking.  Its navigation / pseudorange / PVT /
+// UI duties are out of scope: gps_master_nav_handling is a weak no-op hook, key_up_presed a weak variable.
+namespace {
+uint8_t g_need_acq = 1;     // gps_common_need_acq
+uint8_t g_start_flag = 1;   // gps_start_flag
+}  // namespace
+
+__attribute__((weak)) uint8_t key_up_presed = 0;
+__attribute__((weak)) void gps_master_nav_handling(gps_ch_t *) {}
+
+uint8_t gps_master_need_acq(void) { return g_need_acq; }
+
+uint8_t gps_master_need_freq_search(gps_ch_t *channels)
+{
+  uint8_t need = 0;
+  for (int i = 0; i < GPS_SAT_CNT; i++)
+    if (channels[i].acq_data.state < GPS_ACQ_FREQ_SEARCH_DONE)
+      need = 1;
+  return need;
+}
+
+uint8_t gps_master_is_code_search3(gps_ch_t *channels)
+{
+  int n = 0;
+  for (int i = 0; i < GPS_SAT_CNT; i++)
+    if (channels[i].acq_data.state > GPS_ACQ_CODE_PHASE_SEARCH2)
+      n++;
+  return n == GPS_SAT_CNT;
+}
+
+void gps_master_reset_to_aqc_start(gps_ch_t *channels)
+{
+  for (int i = 0; i < GPS_SAT_CNT; i++)
+    if (channels[i].acq_data.state < GPS_ACQ_FREQ_SEARCH_DONE)
+      return;
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    uint32_t good_words;   // gps_nav_data_t.word_cnt_test, byte 56 of the reference's struct (inside the opaque part)
+    std::memcpy(&good_words, reinterpret_cast<const uint8_t *>(&channels[i].nav_data) + 56, 4);
+    if (good_words > 1)
+      channels[i].acq_data.found_freq_offset_hz = (int16_t)channels[i].tracking_data.if_freq_offset_hz;
+    channels[i].acq_data.state = GPS_ACQ_FREQ_SEARCH_DONE;
+    std::memset(&channels[i].tracking_data, 0, sizeof(gps_tracking_t));
+    std::memset(&channels[i].nav_data, 0, sizeof(gps_nav_data_t));
+  }
+}
+
+void gps_master_handling(gps_ch_t *channels, uint8_t index)
+{
+  if (g_start_flag) {
+    g_start_flag = 0;
+    acquisition_start_channel(&channels[0]);
+  }
+  g_need_acq = 0;
+  uint8_t need_freq = 0, stage3_ready = 0;
+  for (int i = 0; i < GPS_SAT_CNT; i++) {
+    if (channels[i].acq_data.state != GPS_ACQ_DONE)
+      g_need_acq = 1;
+    if (channels[i].acq_data.state < GPS_ACQ_FREQ_SEARCH_DONE)
+      need_freq = 1;
+    if (channels[i].acq_data.state == GPS_ACQ_CODE_PHASE_SEARCH2_DONE)
+      stage3_ready++;
+  }
+  if (g_need_acq == 1) {   // frequency searches (or hints) one channel at a time
+    for (int i = 0; i < GPS_SAT_CNT - 1; i++) {
+      if (channels[i].acq_data.state == GPS_ACQ_FREQ_SEARCH_DONE &&
+          channels[i + 1].acq_data.state == GPS_ACQ_NEED_FREQ_SEARCH) {
+        acquisition_start_channel(&channels[i + 1]);
+        return;
+      }
+    }
+  }
+  if (need_freq == 0 && g_need_acq == 1) {   // code-phase searches for all channels together
+    for (int i = 0; i < GPS_SAT_CNT; i++) {
+      if (channels[i].acq_data.state == GPS_ACQ_FREQ_SEARCH_DONE)
+        acquisition_start_code_search_channel(&channels[i]);
+      if (stage3_ready == GPS_SAT_CNT)
+        acquisition_start_code_search3_channel(&channels[i]);
+    }
+  }
+  if (g_need_acq == 0) {   // everything acquired: start tracking
+    for (int i = 0; i < GPS_SAT_CNT; i++)
+      if (channels[i].tracking_data.state == GPS_TRACKNG_IDLE)
+        channels[i].tracking_data.state = GPS_NEED_PRE_TRACK;
+  }
+  if (key_up_presed) {
+    key_up_presed = 0;
+    gps_master_reset_to_aqc_start(channels);
+  }
+  if (index == 0xFF)   // the idle slot of the 17 ms cycle: navigation / pseudoranges / PVT in the reference
+    gps_master_nav_handling(channels);
+}
+
 // ---- tracking.h ---------------------------------------------------------------------------------------------------------
 void gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index)
 {
