@@ -521,3 +521,60 @@ def _merge_owned(acc, peaks, keys):
     mine = keys != 0
     out[mine] = peaks[mine]
     return out
+
+
+def test_kernels_do_not_write_outside_their_outputs(eng, stream):
+    """Out-of-bounds canaries (no sanitizer exists for the device side): every device output is placed
+    between guard regions filled with a pattern, for descriptors with partial PRN groups and odd sizes, in every kernel
+    variant the API can select; the guards must come back untouched."""
+    import ctypes as C
+    from stm32f4_sdr_gps_amd import capi
+    GUARD = 4096
+    pattern = np.frombuffer(np.random.default_rng(99).bytes(GUARD), np.uint8)
+
+    def guarded(nbytes):
+        total = nbytes + 2 * GUARD
+        p = eng.malloc(total)
+        eng.h2d(p, np.concatenate([pattern, np.zeros(nbytes, np.uint8), pattern]))
+        return p, p + GUARD, nbytes
+
+    def check(p, nbytes):
+        back = np.zeros(nbytes + 2 * GUARD, np.uint8)
+        eng.d2h(back, p)
+        eng.free(p)
+        assert np.array_equal(back[:GUARD], pattern) and np.array_equal(back[-GUARD:], pattern)
+        return back[GUARD:-GUARD]
+
+    blocks = np.ascontiguousarray(stream[:6])
+    d_if = eng.malloc(blocks.size + 2)
+    eng.h2d(d_if, np.concatenate([blocks.reshape(-1), np.zeros(2, np.uint8)]))
+    for (n_prn, n_dopp, n_search, n_ms, mode, dbg) in [(13, 3, 2, 1, capi.PHASES_FINE, False),   # polyphase, 8-offset form
+                                                        (9, 2, 1, 1, capi.PHASES_BYTE, False),    # dot8, byte phases
+                                                        (5, 2, 2, 3, capi.PHASES_FINE, False),    # multi-block
+                                                        (3, 1, 1, 2, capi.PHASES_FINE, True)]:    # inspection outputs
+        prns = np.arange(1, n_prn + 1, dtype=np.uint8)
+        g = eng.grid_desc(prns, n_search=n_search, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=-500,
+                          dopp_step_hz=500, n_dopp=n_dopp, phase_mode=mode)
+        n_bits = 8 if mode == capi.PHASES_FINE else 1
+        n_pk = n_search * n_prn * n_dopp * n_bits
+        bufs = [guarded(n_pk * 16), guarded(n_search * n_prn * n_dopp * 8)]
+        if dbg:
+            bufs += [guarded(n_pk * n_ms * 16), guarded(n_pk * 2046 * 4), guarded(n_pk * 2046 * 4)]
+        ptrs = [b[1] for b in bufs] + [None] * (5 - len(bufs))
+        rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if, len(blocks), *ptrs)
+        assert rc == 0
+        eng.synchronize()
+        outs = [check(b[0], b[2]) for b in bufs]
+        assert outs[0].view(capi.PEAK_DTYPE)["sum"].all()      # every owned entry was produced
+    # tracking
+    st = np.zeros(37, capi.TRK_DTYPE)
+    st["prn"] = (np.arange(37) % 32) + 1
+    st["code_phase_fine"] = np.linspace(0, 16367, 37).astype(np.float32)
+    p_st, d_st, n_st = guarded(st.nbytes)
+    eng.h2d(d_st, st)
+    p_iq, d_iq, n_iq = guarded(37 * 12)
+    assert eng.lib.gpsx_track_epl_batch_dev(eng.h, d_if, d_st, 37, d_iq) == 0
+    eng.synchronize()
+    check(p_st, n_st)
+    check(p_iq, n_iq)
+    eng.free(d_if)
