@@ -276,7 +276,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8",
+            "dtype": "u1 (bit planes; u32 popcount accumulators)",
             "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11)",
             "config": {
                 "workload": ("cold-start acquisition grid: 32 PRN x 21 Doppler (+-5 kHz @ 500 Hz) x 16368 code phases, "
