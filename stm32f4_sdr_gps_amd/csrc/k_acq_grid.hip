@@ -22,7 +22,10 @@
 // I and Q: 4 x G x 2 accumulators.  Per 4-chip step j it reads one new dword of S' per stream from LDS, forms the
 // three unaligned windows with v_alignbyte_b32 and issues 8 G SADs against G wave-uniform code words (SGPRs).
 //
-// ALGO_DOT8 (default) halves the main loop again: with 0/1 code nibbles,
+// This kernel serves byte-granular grids, multi-block (non-coherent) searches, job lists and the inspection outputs; the
+// single-block fine grid of the cold-start sweep runs k_acq_poly (k_acq_poly.hip), which reuses B0/C below.
+//
+// ALGO_DOT8 (default here; ALGO_SAD is kept for A/B) halves the main loop again: with 0/1 code nibbles,
 //       C0(16 q + t0) = pop(D) + 8192 - 2 M,     M = sum_c chip[c] * S_t0[q + c]
 //   and v_dot8_u32_u4 multiplies EIGHT 4-bit block sums by eight chips per instruction.  A block sum is 0..16; the one
 //   value that does not fit a nibble (16 = a window of sixteen ones) is stored as 15 and its deficit restored exactly

@@ -12,8 +12,9 @@
 // pairs in the reference).  d_t0 is the t0-th polyphase component of the wiped stream (every 16th sample).
 // A workgroup owns 1024 chip offsets q x G PRNs x I,Q for a SEGMENT of 8 or 16 consecutive t0: the first is computed
 // directly (4-bit block sums, v_dot8_u32_u4, exact saturation pass -- as in k_acq), the others by the recurrence.
-// Per-(PRN, bit shift) search results are merged across even / odd byte offsets (t0 = b and b + 8), segments and
-// waves with atomicMax / atomicAdd on two u32 planes; k_acq_finalize turns them into gpsx_peak_t.
+// Per-(PRN, bit shift) search results are merged across even / odd byte offsets (t0 = b and b + 8) and the four waves:
+// in LDS when the workgroup walks all 16 offsets (the triplet is then written once), through atomicMax / atomicAdd on
+// two global u32 planes + k_acq_finalize when the chip is split between two 8-offset workgroups.
 //
 // Lane l owns q = 4 l .. 4 l + 3; X_t0(4 l + 4) is lane l + 1's first value, exchanged through LDS.
 #include <cstdlib>
