@@ -106,8 +106,10 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
     const bool exists = q < kChips;
     const bool in_win = exists && o >= win_start && o < win_stop;
     const int oc = exists ? o : 0;
-    const int adj_i = 2 * (int)__popc(lds_byte(sh.d[0], oc) & low_mask) - b;   // quirk Q5
-    const int adj_q = 2 * (int)__popc(lds_byte(sh.d[1], oc) & low_mask) - b;
+    // quirk Q5 applies to PRNs whose chip 1022 is set: two candidate bases per offset, picked per PRN by a scalar mask
+    const int base0_i = base_i, base0_q = base_q;
+    const int base1_i = base_i + 2 * (int)__popc(lds_byte(sh.d[0], oc) & low_mask) - b;
+    const int base1_q = base_q + 2 * (int)__popc(lds_byte(sh.d[1], oc) & low_mask) - b;
     const bool odd_tail = half && q > 0 && exists;                             // quirk Q3, replica word 1022
     u32 prev_i = 0, prev_q = 0;
     if (odd_tail) {
@@ -120,8 +122,8 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
     for (int p = 0; p < G; p++) {
       const u32 tail_bits = chipbits_g[p * 32 + 31];   // wave-uniform -> scalar load
       const bool c1022 = (tail_bits >> 30) & 1u, c1021 = (tail_bits >> 29) & 1u;
-      int ci = base_i - 2 * (int)m_i[i][p] + (c1022 ? adj_i : 0);
-      int cq = base_q - 2 * (int)m_q[i][p] + (c1022 ? adj_q : 0);
+      int ci = (c1022 ? base1_i : base0_i) + __mul24((int)m_i[i][p], -2);   // -> v_cndmask + v_mad_i32_i24
+      int cq = (c1022 ? base1_q : base0_q) + __mul24((int)m_q[i][p], -2);
       if (half) {
         const u32 sel8 = ((chipwin[p] >> k0) & 3u) * 8u;   // bit 0 = chip[p1 - 1], bit 1 = chip[p1], p1 = 1022 - q
         ci -= (int)__builtin_amdgcn_ubfe(wrap_tab_i, sel8, 8u);
