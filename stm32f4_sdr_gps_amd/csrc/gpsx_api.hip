@@ -30,6 +30,8 @@ struct gpsx_ctx {
   int algo = kAlgoPoly;              // $GPSX_ACQ_ALGO = poly (default) | dot8 | sad, for A/B measurements
   uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
   size_t acc_entries = 0;
+  uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
+  size_t energy_bytes = 0;
 
   // grouped tables for the PRN list of the last grid call
   std::vector<uint8_t> grid_prns;
@@ -256,7 +258,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
-                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc};
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc, ctx->d_energy};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
@@ -456,7 +458,28 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.energy = d_energy;
   prm.cnt = d_cnt;
   const bool inspect = d_per_ms || d_energy || d_cnt;
-  if (ctx->algo == kAlgoPoly && n_bits == 8 && g->n_ms == 1 && !inspect) {
+  bool poly = ctx->algo == kAlgoPoly && n_bits == 8 && !inspect;
+  if (poly && g->n_ms > 1) {
+    // the multi-block form keeps 64 KB of running sums per (PRN, Doppler) pair of this shard in HBM; when that cannot
+    // be had (it is 2.7 GB for 64 simultaneous cold-start searches) the register-resident dot8 kernel does the job
+    const size_t need = acq_poly_energy_bytes(local_units);
+    if (need > ctx->energy_bytes) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_energy)
+        (void)hipFree(ctx->d_energy);
+      ctx->d_energy = nullptr;
+      ctx->energy_bytes = 0;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2 &&
+          hipMalloc((void **)&ctx->d_energy, need) == hipSuccess)
+        ctx->energy_bytes = need;
+      else {
+        (void)hipGetLastError();
+        poly = false;
+      }
+    }
+  }
+  if (poly) {
     const size_t n_peaks = gpsx_acq_peaks_count(g);
     if (n_peaks > ctx->acc_entries) {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -468,7 +491,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
       ctx->acc_entries = n_peaks;
     }
     launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
-                    ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1);
+                    ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1,
+                    ctx->d_energy);
     LAUNCHCHK(ctx, "k_acq_poly");
   } else {
     const int algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;

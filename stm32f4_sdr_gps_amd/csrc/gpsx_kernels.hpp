@@ -57,12 +57,17 @@ void launch_build_codes(hipStream_t s, const uint8_t *d_prns, int n_slots, int g
 // list; local_units = jobs).  d_cw is the table matching `algo` (cw for kAlgoSad, cw8 for kAlgoDot8).
 void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits);
-// Polyphase variant for phase_mode FINE, n_ms == 1, no inspection outputs (k_acq_poly.hip).  d_keyacc / d_sumacc: two
+// Polyphase variant for phase_mode FINE, no inspection outputs (k_acq_poly.hip).  n_ms > 1 needs d_energy:
+// acq_poly_energy_bytes(local_units) of scratch for the running per-hypothesis sums between blocks.  d_keyacc / d_sumacc: two
 // u32 scratch planes of n_peaks entries, used (zeroed, merged with atomics, converted into d_peaks) only when the launch
 // is split into two 8-offset workgroups per chip; the one-workgroup-per-chip form writes d_peaks directly.
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks, bool peaks_are_zero);
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy);
+inline size_t acq_poly_energy_bytes(long local_units)
+{
+  return (size_t)local_units * kSuperGroups * kAcqGroup * 16 * 1024 * sizeof(uint32_t);
+}
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
                      int n_dopp, int n_bits, int shard_index, int shard_count);

@@ -16,6 +16,10 @@
 // in LDS when the workgroup walks all 16 offsets (the triplet is then written once), through atomicMax / atomicAdd on
 // two global u32 planes + k_acq_finalize when the chip is split between two 8-offset workgroups.
 //
+// Non-coherent integration over n_ms > 1 blocks (MULTI): the workgroup walks the blocks itself; between blocks the
+// running energy of every hypothesis it owns sits in a private 64 KB-per-PRN slice of an HBM scratch buffer (read-add-
+// write per block, dword per lane, coalesced; the last block searches on the sums instead of writing them back).
+//
 // Lane l owns q = 4 l .. 4 l + 3; X_t0(4 l + 4) is lane l + 1's first value, exchanged through LDS.
 #include <cstdlib>
 
@@ -55,12 +59,16 @@ __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
 
 // Corrections of the reference's quirks, magnitude, windowed max / sum, merge into the global planes.
 // m_i / m_q: M_t0(q) for the lane's four q and G PRNs.
-template <int G, int SEG>
+// MULTI (non-coherent integration over several blocks): the per-hypothesis energies live in HBM between blocks --
+// energy[workgroup][PRN of the group][t0][i][tid] (q = 4 tid + i), 64 KB per PRN; every access is one dword per lane,
+// 256 B contiguous per wave.  ms_first: nothing to read yet; ms_last: search on the sums instead of writing them back.
+template <int G, int SEG, bool MULTI>
 __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
                                                    const u32 (&m_q)[4][G], int win_start, int win_stop,
                                                    const u32 *__restrict__ chipbits_g, int n_valid, size_t out0,
                                                    size_t out_pstride, u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
-                                                   gpsx_peak_t *__restrict__ peaks)
+                                                   gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
+                                                   size_t energy_pair0, size_t energy_pstride, bool ms_first, bool ms_last)
 {
   const int b = t0 & 7, half = t0 >> 3;
   const u32 low_mask = (1u << b) - 1u;
@@ -132,13 +140,24 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
         ci -= odd_tail ? (int)__popc(prev_i ^ r_last) : 0;
         cq -= odd_tail ? (int)__popc(prev_q ^ r_last) : 0;
       }
-      const u32 val = in_win ? (u32)mag8_fast(ci, cq) : 0u;
+      u32 val = in_win ? (u32)mag8_fast(ci, cq) : 0u;
+      if (MULTI) {
+        if (p < n_valid) {
+          u32 *slot = energy + ((energy_pair0 + (size_t)p * energy_pstride) * 16 + (size_t)t0) * 1024 + i * 256 + tid_e;
+          if (!ms_first)
+            val += *slot;   // (non-temporal hints and 2 workgroups/CU with no scratch both measured slower)
+          if (!ms_last)
+            *slot = val;
+        }
+      }
       const u32 key = in_win ? (val << 11) | key_lo : 0u;
       best[p] = key > best[p] ? key : best[p];
       total[p] += val;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (MULTI && !ms_last)
+    return;
   // Wave reduction, then merge.  SEG == 16: the workgroup sees both offsets of every bit shift, so the merge stays in
   // LDS and the finished triplet is written once; SEG == 8: the other offset belongs to another workgroup, merge through
   // global atomics (k_acq_finalize converts the planes afterwards).
@@ -173,11 +192,11 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
 
 }  // namespace
 
-template <int G, int SEG>
+template <int G, int SEG, bool MULTI>
 __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ cw8, const u32 *__restrict__ chipbits,
                                                           u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
-                                                          gpsx_peak_t *__restrict__ peaks)
+                                                          gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy)
 {
   __shared__ PolyShared<G, SEG> sh;
   const int tid = threadIdx.x;
@@ -214,9 +233,19 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     sh.chipbits[p][w] = w < 32 ? chipbits_g[p * 32 + w] : 0u;
   }
 
+  const size_t energy_pair0 = (size_t)blockIdx.x * G;   // this workgroup's private slices, one per PRN of its group
+  const size_t energy_pstride = 1;
+  for (int i = tid; i < 8 * G * 2; i += kThreads)
+    (&sh.part[0][0][0])[i] = 0;
+
+  const int n_ms = MULTI ? prm.n_ms : 1;
+#pragma unroll 1
+  for (int ms = 0; ms < n_ms; ms++) {
+  const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
+  __syncthreads();   // the previous block's readers of the LDS arrays are done
   // ---- A1 / A2: capture -> LDS, carrier wipe-off (as k_acq) ---------------------------------------------------------
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
-  const uint8_t *blk = if_blocks + (size_t)(search * prm.search_stride_blocks) * block_bytes;
+  const uint8_t *blk = if_blocks + (size_t)(search * prm.search_stride_blocks + ms) * block_bytes;
   for (int i = tid; i < 1024; i += kThreads)
     sh.x[i] = i < kWords16 ? load_sign16(blk, i, prm.if_format) : (uint16_t)0;
   for (int i = tid; i < 2 * kFullWords; i += kThreads)
@@ -225,8 +254,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     sh.any_full[tid] = 0;
     sh.ones[tid] = 0;
   }
-  for (int i = tid; i < 8 * G * 2; i += kThreads)
-    (&sh.part[0][0][0])[i] = 0;
   __syncthreads();
   {
     const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
@@ -362,8 +389,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
       }
     }
   }
-  poly_finish_offset<G, SEG>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid, out0,
-                        out_pstride, keyacc, sumacc, peaks);
+  poly_finish_offset<G, SEG, MULTI>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
+                                    out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0, energy_pstride,
+                                    ms_first, ms_last);
 
   // ---- B1..B7: one sample further each: M += X(q + 1) - X(q), X = AND + popcount against the polyphase plane ----------
 #pragma unroll 1
@@ -445,9 +473,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
         m_q[3][pp] += right_q - x_q[3][p];
       }
     }
-    poly_finish_offset<G, SEG>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
-                          out0, out_pstride, keyacc, sumacc, peaks);
+    poly_finish_offset<G, SEG, MULTI>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g,
+                                      n_valid, out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0,
+                                      energy_pstride, ms_first, ms_last);
   }
+  }  // ms
 }
 
 // (packed key, sum) planes -> gpsx_peak_t
@@ -468,10 +498,17 @@ __global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__rest
 
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks, bool peaks_are_zero)
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy)
 {
   if (local_units <= 0 || n_peaks == 0)
     return;
+  if (prm.n_ms > 1) {
+    // Non-coherent integration: always one workgroup per chip -- the energies of a (PRN, Doppler) pair then have one
+    // owner, which walks the blocks itself and keeps the running sums in its own 64 KB-per-PRN slice of d_energy.
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, true>), dim3((unsigned)(local_units * kSuperGroups)), dim3(kThreads), 0,
+                       s, prm, d_if, d_cw8, d_chipbits, d_keyacc, d_sumacc, d_peaks, d_energy);
+    return;
+  }
   // One workgroup per chip (16 offsets: one direct step + 15 recurrence steps; results merged in LDS and written once)
   // when that still leaves several waves of workgroups per CU slot; otherwise two (8 offsets each, merged through
   // global atomics on two scratch planes and converted by k_acq_finalize) for balance.
@@ -480,12 +517,12 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
   const bool seg16 = force ? force[0] == '1' : wg16 >= 6 * 768;
   if (seg16) {
     (void)peaks_are_zero;   // units of other shards keep whatever the caller zeroed
-    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
-                       d_chipbits, d_keyacc, d_sumacc, d_peaks);
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, false>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                       d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
   } else {
     (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
-    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
-                       d_chipbits, d_keyacc, d_sumacc, d_peaks);
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8, false>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                       d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
     hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
                        n_peaks, d_peaks);
   }

@@ -13,7 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag="r01", searches=64):
+def main(tag="r01", searches=64, n_ms=1):
+    searches, n_ms = int(searches), int(n_ms)   # n_ms > 1: a side profile, profiles/hbm_traffic.json is left alone
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -50,8 +51,11 @@ def main(tag="r01", searches=64):
         tr = {"searches_per_launch": searches, "hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_corrected": fetch_b,
               "write_bytes": write_b, "fetch_kib_raw": c["FETCH_SIZE"], "write_kib_raw": c["WRITE_SIZE"],
               "source": f"profiles/{tag}_pmc_summary.json"}
-        with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
-            json.dump(tr, f, indent=1)
+        if n_ms == 1:
+            with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
+                json.dump(tr, f, indent=1)
+        else:
+            tr["blocks_per_search"] = n_ms
         summary["hbm_traffic"] = tr
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
@@ -60,11 +64,11 @@ def main(tag="r01", searches=64):
             "valu_issue_cycles_per_simd": c["SQ_INSTS_VALU"] * 4.0 / 1024.0,   # 4 cycles per wave64 int op, 1024 SIMDs
             "valu_issue_utilisation": c["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cycles,
             # main-loop instructions the formulation needs: workgroups x 4 waves x 2 halves x steps x 64
-            "main_loop_wave_instructions_sad": searches * 672 * 4 * 2 * 256 * 64,
-            "main_loop_wave_instructions_dot8": searches * 672 * 4 * 2 * 128 * 64,
+            "main_loop_wave_instructions_sad": n_ms * searches * 672 * 4 * 2 * 256 * 64,
+            "main_loop_wave_instructions_dot8": n_ms * searches * 672 * 4 * 2 * 128 * 64,
             # polyphase kernel: per (search, Doppler, PRN group) 4 waves x (one direct offset of 128 x 64 dots
             # + 15 recurrence offsets of 32 words x 64 (and + bcnt) pairs)
-            "main_loop_wave_instructions_poly": searches * 21 * 4 * 4 * (128 * 64 + 15 * 32 * 128),
+            "main_loop_wave_instructions_poly": n_ms * searches * 21 * 4 * 4 * (128 * 64 + 15 * 32 * 128),
         }
         d = summary["derived"]
         d["sad_share_of_valu"] = d["main_loop_wave_instructions_sad"] / c["SQ_INSTS_VALU"]
@@ -76,4 +80,4 @@ def main(tag="r01", searches=64):
 
 
 if __name__ == "__main__":
-    main(*(sys.argv[1:2] or ["r01"]))
+    main(*(sys.argv[1:4] or ["r01"]))   # tag [searches_per_launch [n_ms]]
