@@ -68,7 +68,7 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
                                                    const u32 *__restrict__ chipbits_g, int n_valid, size_t out0,
                                                    size_t out_pstride, u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
                                                    gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
-                                                   size_t energy_pair0, size_t energy_pstride, bool ms_first, bool ms_last)
+                                                   size_t energy_pair0, bool ms_first, bool ms_last)
 {
   const int b = t0 & 7, half = t0 >> 3;
   const u32 low_mask = (1u << b) - 1u;
@@ -126,6 +126,17 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
     }
     const int k0 = exists ? (kChips - 2 - q) - chip_base : 0;
     const u32 key_lo = (u32)(2047 - o);
+    // MULTI: the running sums of this lane's eight hypotheses, fetched up front so that the eight magnitudes below
+    // cover the latency (slices exist for all G PRNs of the group and whatever they hold before the first block is
+    // never used: no guards, no branches around the loads)
+    u32 *e_grp = energy + energy_pair0 * (16 * 1024);                 // wave-uniform base, 32-bit lane offset
+    const u32 e_off = (u32)(t0 * 1024 + i * 256 + tid_e);
+    u32 prev[MULTI ? G : 1];
+    if (MULTI) {
+#pragma unroll
+      for (int p = 0; p < G; p++)
+        prev[MULTI ? p : 0] = (e_grp + p * (16 * 1024))[e_off];
+    }
 #pragma unroll
     for (int p = 0; p < G; p++) {
       const u32 tail_bits = chipbits_g[p * 32 + 31];   // wave-uniform -> scalar load
@@ -142,13 +153,9 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
       }
       u32 val = in_win ? (u32)mag8_fast(ci, cq) : 0u;
       if (MULTI) {
-        if (p < n_valid) {
-          u32 *slot = energy + ((energy_pair0 + (size_t)p * energy_pstride) * 16 + (size_t)t0) * 1024 + i * 256 + tid_e;
-          if (!ms_first)
-            val += *slot;   // (non-temporal hints and 2 workgroups/CU with no scratch both measured slower)
-          if (!ms_last)
-            *slot = val;
-        }
+        val += ms_first ? 0u : prev[MULTI ? p : 0];
+        if (!ms_last)
+          (e_grp + p * (16 * 1024))[e_off] = val;
       }
       const u32 key = in_win ? (val << 11) | key_lo : 0u;
       best[p] = key > best[p] ? key : best[p];
@@ -234,7 +241,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
   }
 
   const size_t energy_pair0 = (size_t)blockIdx.x * G;   // this workgroup's private slices, one per PRN of its group
-  const size_t energy_pstride = 1;
   for (int i = tid; i < 8 * G * 2; i += kThreads)
     (&sh.part[0][0][0])[i] = 0;
 
@@ -390,8 +396,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     }
   }
   poly_finish_offset<G, SEG, MULTI>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
-                                    out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0, energy_pstride,
-                                    ms_first, ms_last);
+                                    out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0, ms_first, ms_last);
 
   // ---- B1..B7: one sample further each: M += X(q + 1) - X(q), X = AND + popcount against the polyphase plane ----------
 #pragma unroll 1
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     }
     poly_finish_offset<G, SEG, MULTI>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g,
                                       n_valid, out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0,
-                                      energy_pstride, ms_first, ms_last);
+                                      ms_first, ms_last);
   }
   }  // ms
 }
