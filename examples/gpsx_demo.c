@@ -3,9 +3,9 @@
  * This is the shape of the firmware's main loop (Firmware/project_main/main.c:45-168 of iliasam/STM32F4_SDR_GPS) on
  * a hosted system: the 4-satellite channel table with PRN + Doppler-hint inputs, acquisition steps on captured
  * milliseconds until every channel is acquired, then 17-slot multiplexed tracking steps -- with libgpsx.so in place of
- * gps_misc.c / acquisition.c / tracking.c.  The capture driver is replaced by a raw IF file (1 bit per sample, LSB
- * first, 2046 bytes per millisecond: the format PC_SpiLight replays); gps_master_handling() / gps_master_need_acq()
- * (gps_master.h) sequence the channels exactly as in the firmware.
+ * gps_misc.c / acquisition.c / tracking.c.  The SPI/DMA capture driver is fed from a raw IF file (1 bit per sample,
+ * LSB first, 2046 bytes per millisecond: the format PC_SpiLight replays) through the firmware's own signal_capture_*
+ * interface; gps_master_handling() / gps_master_need_acq() (gps_master.h) sequence the channels as in the firmware.
  *
  *   gcc -O2 -I include examples/gpsx_demo.c -L stm32f4_sdr_gps_amd/lib -lgpsx \
  *       -Wl,-rpath,$PWD/stm32f4_sdr_gps_amd/lib -lm -o gpsx_demo
@@ -47,23 +47,35 @@ int main(int argc, char **argv)
     gps_channell_prepare(&gps_channels[i]);
   }
 
+  /* The capture driver: each block read from the file is what one DMA half/full-transfer interrupt delivers
+   * (PM/signal_capture.c:57-82) -- gpsx_compat_capture_push() moves the ready pointer, counts the 1 ms tick, raises
+   * the flag and starts the block's copy to the GPU.  Unlike the MCU this host never drops a millisecond while it
+   * is acquiring, so the "not realtime" branch takes every block too. */
   uint8_t block[BLOCK_BYTES];
   long t = 0, acquired_at = -1;
+  signal_capture_init();
   gpsx_compat_set_packet_cnt(0);
-  gps_master_handling(gps_channels, 0);
+  gps_master_handling(gps_channels, 0);                 /* boot: starts the first channel's search at tick 0 */
+  gpsx_compat_set_packet_cnt(0xFFFFFFFFu);              /* so that the first block received gets tick 0 too */
   for (; t < max_ms && fread(block, 1, BLOCK_BYTES, f) == BLOCK_BYTES; t++) {
-    gpsx_compat_set_packet_cnt((uint32_t)t);           /* the capture driver's 1 ms tick */
-    if (gps_master_need_acq()) {
-      acquisition_process(gps_channels, block);         /* main_process_acq_data, PM/main.c:163-168 */
-      gps_master_handling(gps_channels, 0);
+    gpsx_compat_capture_push(block);
+    if (gps_master_need_acq()) {                          /* main_slow_data_proc, PM/main.c:106-125 */
+      signal_capture_need_data_copy();
+      signal_capture_handling();
+      if (signal_capture_check_copied()) {
+        acquisition_process(gps_channels, signal_capture_get_copy_buf());   /* main_process_acq_data, :163-168 */
+        gps_master_handling(gps_channels, 0);
+      }
       if (!gps_master_need_acq())
         acquired_at = t;
-    } else {
-      const long slot = t % (TRACKING_CH_LENGTH * GPS_SAT_CNT + 1);   /* main_fast_data_proc, PM/main.c:134-158 */
-      long sat = slot / TRACKING_CH_LENGTH;
+    } else if (signal_capture_have_irq()) {               /* main_fast_data_proc, PM/main.c:134-158 */
+      uint8_t *signal_p = signal_capture_get_ready_buf();
+      const uint32_t time_cnt = signal_capture_get_packet_cnt();
+      const uint32_t index_big = time_cnt % (TRACKING_CH_LENGTH * GPS_SAT_CNT + 1);
+      uint32_t sat = index_big / TRACKING_CH_LENGTH;
       if (sat >= GPS_SAT_CNT) sat = 0;
-      const uint8_t index = slot == TRACKING_CH_LENGTH * GPS_SAT_CNT ? 0xFF : (uint8_t)(slot % TRACKING_CH_LENGTH);
-      gps_tracking_process(&gps_channels[sat], block, index);
+      const uint8_t index = index_big == TRACKING_CH_LENGTH * GPS_SAT_CNT ? 0xFF : (uint8_t)(index_big % TRACKING_CH_LENGTH);
+      gps_tracking_process(&gps_channels[sat], signal_p, index);
       gps_master_handling(gps_channels, index);
     }
   }

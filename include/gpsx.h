@@ -86,6 +86,38 @@ int gpsx_event_record(gpsx_ctx *ctx, void *event);
 int gpsx_event_elapsed_ms(gpsx_ctx *ctx, void *start, void *stop, float *ms);  /* synchronizes on `stop` */
 int gpsx_event_destroy(gpsx_ctx *ctx, void *event);
 
+/* ---- IF ingest: the capture ring  (replaces the circular DMA buffer and its half/full-transfer interrupt,
+ *      PM/signal_capture.c:14-24,57-82, and the file replay of PC_SpiLight: raw stream, 2046 bytes per ms in the 1-bit
+ *      format, 4092 in GPSX_IF_2BIT_SM) -------------------------------------------------------------------------------
+ * A ring of n_slots 1 ms blocks in pinned host memory with a mirror in HBM.  The producer fills the write slot and
+ * commits it -- what the DMA interrupt does: the ready pointer moves on, the packet counter counts, and the block goes
+ * to the device by an asynchronous copy from pinned memory, enqueued on the context's stream (the call does not wait).
+ * Host entry points of this library (gpsx_acq_grid, gpsx_acq_jobs, gpsx_track_epl_batch and the reference-named step
+ * calls on top of them) recognise a pointer into a committed part of the ring and read the HBM mirror instead of
+ * copying the block again.  The format is the context's if_format at creation time. */
+typedef struct gpsx_capture gpsx_capture;
+int            gpsx_capture_create(gpsx_ctx *ctx, int n_slots, gpsx_capture **cap);      /* 1 <= n_slots <= 4096 */
+void           gpsx_capture_destroy(gpsx_capture *cap);
+/* the slot the next block goes into (block_bytes of pinned memory); valid until the next commit */
+uint8_t       *gpsx_capture_write_slot(gpsx_capture *cap);
+int            gpsx_capture_commit(gpsx_capture *cap);
+/* convenience: copy one block into the write slot and commit it */
+int            gpsx_capture_push(gpsx_capture *cap, const uint8_t *block);
+/* newest committed block, host view (NULL before the first commit) */
+const uint8_t *gpsx_capture_ready_buf(const gpsx_capture *cap);
+/* the last n_blocks committed blocks, oldest first, contiguous in HBM (n_blocks <= min(n_slots, blocks committed));
+ * a window that wraps around the ring is gathered into a side buffer on the stream, valid until the next call.  Pass
+ * the pointer to the *_dev entry points. */
+int            gpsx_capture_window_dev(gpsx_capture *cap, int n_blocks, const void **d_blocks);
+uint32_t       gpsx_capture_packet_cnt(const gpsx_capture *cap);                          /* blocks committed so far */
+size_t         gpsx_capture_block_bytes(const gpsx_capture *cap);
+/* Replay a recorded raw IF file through the ring: blocks first_block .. (at most max_blocks, < 0 = to the end) are read
+ * into the write slot and committed one by one; after each commit on_block(user, cap, index) runs (may be NULL) and a
+ * non-zero return stops the replay.  Returns the number of blocks committed, or a negative GPSX_E* code. */
+typedef int (*gpsx_capture_block_fn)(void *user, gpsx_capture *cap, long block_index);
+long           gpsx_capture_replay_file(gpsx_capture *cap, const char *path, long first_block, long max_blocks,
+                                        gpsx_capture_block_fn on_block, void *user);
+
 /* ---- K1: C/A Gold codes  (replaces gps_generate_prn / gps_channell_prepare, PM/GPS/gps_misc.c:306-372) -------- */
 
 /* chips_out: n_prn x 1023 bytes of 0/1.  prn must be 1..210 (the reference silently ignores prn < 1; this

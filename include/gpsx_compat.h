@@ -211,6 +211,22 @@ void     gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t
 void     gps_nav_data_words_detection(gps_ch_t *channel, uint8_t new_bit);
 void     gpsx_compat_set_packet_cnt(uint32_t ticks_ms);
 
+/* The capture interface of PM/signal_capture.h (weak, like the hooks above) on top of the engine's capture rings
+ * (include/gpsx.h): a two-slot circular buffer standing for the DMA target, plus the copy buffer for long processing.
+ * gpsx_compat_capture_push (not in the reference) is the DMA half / full transfer interrupt (PM/signal_capture.c:57-82):
+ * it takes one 1 ms block, moves the ready pointer, advances the 1 ms tick, raises the "new data" flag -- and starts the
+ * block's copy to the device, so that the step calls above, handed signal_capture_get_ready_buf() /
+ * signal_capture_get_copy_buf(), read it from HBM without copying it again.  The interrupt deadline test of
+ * signal_capture_handling (900 us) has no equivalent: blocks arrive when the host pushes them. */
+void     signal_capture_init(void);
+void     signal_capture_need_data_copy(void);
+void     signal_capture_handling(void);
+uint8_t  signal_capture_have_irq(void);
+uint8_t  signal_capture_check_copied(void);
+uint8_t *signal_capture_get_copy_buf(void);
+uint8_t *signal_capture_get_ready_buf(void);
+void     gpsx_compat_capture_push(const uint8_t *block);
+
 /* not in the reference: release the default context (optional, for leak checkers) */
 void gpsx_compat_shutdown(void);
 

@@ -42,6 +42,9 @@ class GpsxError(RuntimeError):
     pass
 
 
+CAPTURE_BLOCK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long)   # gpsx_capture_block_fn
+
+
 def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise GpsxError(f"{LIB_PATH} is missing: run `python -m stm32f4_sdr_gps_amd.build` (needs hipcc)")
@@ -80,6 +83,30 @@ def load_library() -> C.CDLL:
     lib.gpsx_if_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gpsx_mag8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+    # capture ring (IF ingest)
+    lib.gpsx_capture_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.gpsx_capture_destroy.argtypes = [C.c_void_p]
+    lib.gpsx_capture_destroy.restype = None
+    lib.gpsx_capture_write_slot.argtypes = [C.c_void_p]
+    lib.gpsx_capture_write_slot.restype = C.c_void_p
+    lib.gpsx_capture_commit.argtypes = [C.c_void_p]
+    lib.gpsx_capture_push.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_capture_ready_buf.argtypes = [C.c_void_p]
+    lib.gpsx_capture_ready_buf.restype = C.c_void_p
+    lib.gpsx_capture_window_dev.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.gpsx_capture_packet_cnt.argtypes = [C.c_void_p]
+    lib.gpsx_capture_packet_cnt.restype = C.c_uint32
+    lib.gpsx_capture_block_bytes.argtypes = [C.c_void_p]
+    lib.gpsx_capture_block_bytes.restype = C.c_size_t
+    lib.gpsx_capture_replay_file.argtypes = [C.c_void_p, C.c_char_p, C.c_long, C.c_long, CAPTURE_BLOCK_FN, C.c_void_p]
+    lib.gpsx_capture_replay_file.restype = C.c_long
+    for name in ("signal_capture_get_ready_buf", "signal_capture_get_copy_buf"):
+        getattr(lib, name).restype = C.c_void_p
+    for name in ("signal_capture_have_irq", "signal_capture_check_copied"):
+        getattr(lib, name).restype = C.c_uint8
+    lib.signal_capture_get_packet_cnt.restype = C.c_uint32
+    lib.gpsx_compat_capture_push.argtypes = [C.c_void_p]
+    lib.gpsx_compat_capture_push.restype = None
     # compat (reference names)
     lib.gps_generate_prn.argtypes = [C.c_void_p, C.c_int]
     lib.gps_channell_prepare.argtypes = [C.c_void_p]
@@ -312,3 +339,49 @@ class Engine:
         self._chk(self.lib.gpsx_corr_search(self.h, rep.ctypes.data, di.ctypes.data, dq.ctypes.data, start, stop,
                                             pk.ctypes.data), "gpsx_corr_search")
         return int(pk["max_val"][0]), int(pk["avr"][0]), int(pk["phase"][0])
+
+
+class Capture:
+    """A capture ring of `eng` (include/gpsx.h "IF ingest"): pinned host slots mirrored in HBM by asynchronous copies."""
+
+    def __init__(self, eng: Engine, n_slots: int):
+        self.eng, self.lib = eng, eng.lib
+        h = C.c_void_p()
+        eng._chk(self.lib.gpsx_capture_create(eng.h, n_slots, C.byref(h)), "gpsx_capture_create")
+        self.h = h
+        self.block_bytes = int(self.lib.gpsx_capture_block_bytes(h))
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.eng, "h", None):
+            self.lib.gpsx_capture_destroy(self.h)
+        self.h = None
+
+    def push(self, block: np.ndarray):
+        block = np.ascontiguousarray(block, np.uint8).reshape(-1)
+        assert block.size == self.block_bytes
+        self.eng._chk(self.lib.gpsx_capture_push(self.h, _ptr(block)), "gpsx_capture_push")
+
+    def ready_ptr(self) -> int:
+        """Host address of the newest committed block (what signal_capture_get_ready_buf returns), 0 before the first."""
+        return int(self.lib.gpsx_capture_ready_buf(self.h) or 0)
+
+    def ready_view(self, n_blocks: int = 1) -> np.ndarray:
+        """numpy view (no copy) of the pinned slot(s) ending at the newest block; only windows that do not wrap."""
+        p = self.ready_ptr() - (n_blocks - 1) * self.block_bytes
+        buf = (C.c_uint8 * (n_blocks * self.block_bytes)).from_address(p)
+        return np.frombuffer(buf, np.uint8).reshape(n_blocks, self.block_bytes)
+
+    def window_dev(self, n_blocks: int) -> int:
+        d = C.c_void_p()
+        self.eng._chk(self.lib.gpsx_capture_window_dev(self.h, n_blocks, C.byref(d)), "gpsx_capture_window_dev")
+        return int(d.value)
+
+    def packet_cnt(self) -> int:
+        return int(self.lib.gpsx_capture_packet_cnt(self.h))
+
+    def replay_file(self, path: str, first_block=0, max_blocks=-1, on_block=None) -> int:
+        cb = CAPTURE_BLOCK_FN((lambda user, cap, idx: int(on_block(idx) or 0)) if on_block else 0)
+        n = int(self.lib.gpsx_capture_replay_file(self.h, path.encode(), first_block, max_blocks, cb, None))
+        if n < 0:
+            self.eng._chk(n, "gpsx_capture_replay_file")
+        return n

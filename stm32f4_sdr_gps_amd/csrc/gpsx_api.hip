@@ -14,6 +14,24 @@
 
 using namespace gpsx;
 
+// IF ingest ring (include/gpsx.h "capture ring"): pinned host slots + HBM mirror.  Blocks are 2 KB: their copies go on the
+// context's own stream (measured: a separate copy stream costs two more events per block than it can ever win back),
+// so readers enqueued later need no synchronisation object at all; one event per slot tells the producer when a slot's
+// pinned bytes have left.
+struct gpsx_capture {
+  gpsx_ctx *ctx = nullptr;
+  int n_slots = 0;
+  size_t block_bytes = 0;
+  uint8_t *h_ring = nullptr;           // [n_slots][block_bytes], hipHostMalloc
+  uint8_t *d_ring = nullptr;           // [n_slots][block_bytes] + 2
+  uint8_t *d_window = nullptr;         // [n_slots][block_bytes] + 2: windows that wrap are gathered here
+  std::vector<hipEvent_t> sent;        // per slot: its host bytes have been read by the copy engine
+  std::vector<uint8_t> mirrored;       // per slot: HBM mirror matches the host slot (cleared when handed out for writing)
+  int write_slot = 0;
+  int ready_slot = -1;
+  uint32_t packet_cnt = 0;
+};
+
 struct gpsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -41,6 +59,8 @@ struct gpsx_ctx {
   uint32_t *d_grid_bits = nullptr;
   uint32_t *d_grid_cw = nullptr;
   uint32_t *d_grid_cw8 = nullptr;
+
+  std::vector<gpsx_capture *> captures;   // IF ingest rings opened on this context
 
   // grow-only scratch arena for the host-pointer entry points
   char *d_arena = nullptr;
@@ -106,6 +126,25 @@ int use_device(gpsx_ctx *ctx)
     return GPSX_EINVAL;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return GPSX_OK;
+}
+
+// A host pointer that lies in a committed, unmodified part of one of the context's capture rings has an HBM mirror:
+// returns the mirror (and makes the compute stream wait for the ring's copies), or nullptr -> the caller copies.
+const uint8_t *capture_mirror(gpsx_ctx *ctx, const uint8_t *host, size_t bytes)
+{
+  for (gpsx_capture *cap : ctx->captures) {
+    const size_t ring_bytes = (size_t)cap->n_slots * cap->block_bytes;
+    if (host < cap->h_ring || host >= cap->h_ring + ring_bytes || bytes == 0 || bytes > ring_bytes)
+      continue;
+    const size_t off = (size_t)(host - cap->h_ring);
+    if (off % cap->block_bytes || bytes % cap->block_bytes || off + bytes > ring_bytes)
+      return nullptr;
+    for (size_t slot = off / cap->block_bytes; slot < (off + bytes) / cap->block_bytes; slot++)
+      if (!cap->mirrored[slot])
+        return nullptr;
+    return cap->d_ring + off;   // the copies were enqueued on this very stream: ordered before any reader
+  }
+  return nullptr;
 }
 
 int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
@@ -255,6 +294,8 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (!ctx)
     return;
   (void)hipSetDevice(ctx->device);
+  while (!ctx->captures.empty())
+    gpsx_capture_destroy(ctx->captures.back());
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
@@ -520,10 +561,14 @@ int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blo
   if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_peaks * sizeof(gpsx_peak_t)) +
                                     arena_size(n_keys * sizeof(int64_t))))
     return rc;
-  uint8_t *d_if = arena_take<uint8_t>(ctx, if_bytes + 2);
+  const uint8_t *d_if = capture_mirror(ctx, if_blocks, if_bytes);
+  uint8_t *d_if_copy = arena_take<uint8_t>(ctx, if_bytes + 2);
   gpsx_peak_t *d_peaks = arena_take<gpsx_peak_t>(ctx, n_peaks);
   int64_t *d_keys = keys ? arena_take<int64_t>(ctx, n_keys) : nullptr;
-  HIPCHK(ctx, hipMemcpyAsync(d_if, if_blocks, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!d_if) {
+    HIPCHK(ctx, hipMemcpyAsync(d_if_copy, if_blocks, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+    d_if = d_if_copy;
+  }
   if (int rc = gpsx_acq_grid_dev(ctx, g, d_if, n_blocks, d_peaks, d_keys, nullptr, nullptr, nullptr)) return rc;
   HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_peaks * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
   if (keys)
@@ -561,11 +606,15 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
   if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_jobs * sizeof(AcqJobRec)) +
                                     arena_size(n_jobs * sizeof(gpsx_peak_t)) + arena_size(e_count * 4)))
     return rc;
-  uint8_t *d_if = arena_take<uint8_t>(ctx, if_bytes + 2);
+  const uint8_t *d_if = capture_mirror(ctx, if_blocks, if_bytes);
+  uint8_t *d_if_copy = arena_take<uint8_t>(ctx, if_bytes + 2);
   AcqJobRec *d_jobs = arena_take<AcqJobRec>(ctx, n_jobs);
   gpsx_peak_t *d_peaks = arena_take<gpsx_peak_t>(ctx, n_jobs);
   uint32_t *d_energy = energy_opt ? arena_take<uint32_t>(ctx, e_count) : nullptr;
-  HIPCHK(ctx, hipMemcpyAsync(d_if, if_blocks, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!d_if) {
+    HIPCHK(ctx, hipMemcpyAsync(d_if_copy, if_blocks, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+    d_if = d_if_copy;
+  }
   HIPCHK(ctx, hipMemcpyAsync(d_jobs, recs.data(), n_jobs * sizeof(AcqJobRec), hipMemcpyHostToDevice, ctx->stream));
   if (d_energy)
     HIPCHK(ctx, hipMemsetAsync(d_energy, 0, e_count * 4, ctx->stream));
@@ -612,10 +661,14 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   if (int rc = arena_reset(ctx, arena_size(blk_bytes + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
                                     arena_size((size_t)n_ch * 12)))
     return rc;
-  uint8_t *d_if = arena_take<uint8_t>(ctx, blk_bytes + 2);
+  const uint8_t *d_if = capture_mirror(ctx, if_block, blk_bytes);
+  uint8_t *d_if_copy = arena_take<uint8_t>(ctx, blk_bytes + 2);
   gpsx_trk_state_t *d_st = arena_take<gpsx_trk_state_t>(ctx, n_ch);
   int16_t *d_iq = arena_take<int16_t>(ctx, (size_t)n_ch * 6);
-  HIPCHK(ctx, hipMemcpyAsync(d_if, if_block, blk_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!d_if) {
+    HIPCHK(ctx, hipMemcpyAsync(d_if_copy, if_block, blk_bytes, hipMemcpyHostToDevice, ctx->stream));
+    d_if = d_if_copy;
+  }
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
   if (int rc = gpsx_track_epl_batch_dev(ctx, d_if, d_st, n_ch, d_iq)) return rc;
   HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -765,3 +818,153 @@ int gpsx_corr_search(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *dat
 }
 
 }  // extern "C"
+
+/* ---- IF ingest: capture ring ---------------------------------------------------------------------------------- */
+
+int gpsx_capture_create(gpsx_ctx *ctx, int n_slots, gpsx_capture **out)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!out || n_slots < 1 || n_slots > 4096)
+    return fail(ctx, GPSX_EINVAL, "capture ring: 1 <= n_slots <= 4096");
+  gpsx_capture *cap = new (std::nothrow) gpsx_capture;
+  if (!cap)
+    return fail(ctx, GPSX_ENOMEM, "out of host memory");
+  cap->ctx = ctx;
+  cap->n_slots = n_slots;
+  cap->block_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
+  cap->mirrored.assign(n_slots, 0);
+  cap->sent.assign(n_slots, nullptr);
+  const size_t ring_bytes = (size_t)n_slots * cap->block_bytes;
+  bool ok = hipHostMalloc((void **)&cap->h_ring, ring_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc((void **)&cap->d_ring, ring_bytes + 2) == hipSuccess &&
+            hipMalloc((void **)&cap->d_window, ring_bytes + 2) == hipSuccess &&
+            hipMemsetAsync(cap->d_ring, 0, ring_bytes + 2, ctx->stream) == hipSuccess &&
+            hipMemsetAsync(cap->d_window, 0, ring_bytes + 2, ctx->stream) == hipSuccess;
+  for (int i = 0; ok && i < n_slots; i++)
+    ok = hipEventCreateWithFlags(&cap->sent[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+  ctx->captures.push_back(cap);
+  if (!ok) {
+    const hipError_t e = hipGetLastError();
+    gpsx_capture_destroy(cap);
+    return fail(ctx, GPSX_ENOMEM, std::string("capture ring allocation: ") + hipGetErrorString(e));
+  }
+  std::memset(cap->h_ring, 0, ring_bytes);
+  *out = cap;
+  return GPSX_OK;
+}
+
+void gpsx_capture_destroy(gpsx_capture *cap)
+{
+  if (!cap)
+    return;
+  gpsx_ctx *ctx = cap->ctx;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream)
+    (void)hipStreamSynchronize(ctx->stream);   // pending copies, and launches that read the mirror
+  ctx->captures.erase(std::remove(ctx->captures.begin(), ctx->captures.end(), cap), ctx->captures.end());
+  for (hipEvent_t e : cap->sent)
+    if (e) (void)hipEventDestroy(e);
+  if (cap->d_ring) (void)hipFree(cap->d_ring);
+  if (cap->d_window) (void)hipFree(cap->d_window);
+  if (cap->h_ring) (void)hipHostFree(cap->h_ring);
+  delete cap;
+}
+
+uint8_t *gpsx_capture_write_slot(gpsx_capture *cap)
+{
+  if (!cap)
+    return nullptr;
+  if (cap->mirrored[cap->write_slot]) {
+    // the slot's previous block may not have left the pinned buffer yet: the producer must not overwrite it
+    (void)hipSetDevice(cap->ctx->device);
+    (void)hipEventSynchronize(cap->sent[cap->write_slot]);
+    cap->mirrored[cap->write_slot] = 0;
+  }
+  return cap->h_ring + (size_t)cap->write_slot * cap->block_bytes;
+}
+
+int gpsx_capture_commit(gpsx_capture *cap)
+{
+  if (!cap)
+    return GPSX_EINVAL;
+  gpsx_ctx *ctx = cap->ctx;
+  if (int rc = use_device(ctx)) return rc;
+  const int slot = cap->write_slot;
+  // stream order does the rest: earlier launches that read this device slot finish first, later ones see the new block
+  HIPCHK(ctx, hipMemcpyAsync(cap->d_ring + (size_t)slot * cap->block_bytes, cap->h_ring + (size_t)slot * cap->block_bytes,
+                             cap->block_bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipEventRecord(cap->sent[slot], ctx->stream));
+  cap->mirrored[slot] = 1;
+  cap->ready_slot = slot;
+  cap->write_slot = (slot + 1) % cap->n_slots;
+  cap->packet_cnt++;
+  return GPSX_OK;
+}
+
+int gpsx_capture_push(gpsx_capture *cap, const uint8_t *block)
+{
+  if (!cap || !block)
+    return GPSX_EINVAL;
+  std::memcpy(gpsx_capture_write_slot(cap), block, cap->block_bytes);
+  return gpsx_capture_commit(cap);
+}
+
+const uint8_t *gpsx_capture_ready_buf(const gpsx_capture *cap)
+{
+  return cap && cap->ready_slot >= 0 ? cap->h_ring + (size_t)cap->ready_slot * cap->block_bytes : nullptr;
+}
+
+int gpsx_capture_window_dev(gpsx_capture *cap, int n_blocks, const void **d_blocks)
+{
+  if (!cap || !d_blocks)
+    return GPSX_EINVAL;
+  gpsx_ctx *ctx = cap->ctx;
+  if (int rc = use_device(ctx)) return rc;
+  if (n_blocks < 1 || n_blocks > cap->n_slots || (uint32_t)n_blocks > cap->packet_cnt)
+    return fail(ctx, GPSX_EINVAL, "capture window: more blocks than the ring holds / has received");
+  const int first = (cap->ready_slot - (n_blocks - 1) + cap->n_slots) % cap->n_slots;   // oldest block of the window
+  if (first + n_blocks <= cap->n_slots) {
+    *d_blocks = cap->d_ring + (size_t)first * cap->block_bytes;
+    return GPSX_OK;
+  }
+  // the window wraps: gather its two pieces (device to device, on the stream) into the window buffer
+  const int head = cap->n_slots - first;
+  HIPCHK(ctx, hipMemcpyAsync(cap->d_window, cap->d_ring + (size_t)first * cap->block_bytes, (size_t)head * cap->block_bytes,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(cap->d_window + (size_t)head * cap->block_bytes, cap->d_ring,
+                             (size_t)(n_blocks - head) * cap->block_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  *d_blocks = cap->d_window;
+  return GPSX_OK;
+}
+
+uint32_t gpsx_capture_packet_cnt(const gpsx_capture *cap) { return cap ? cap->packet_cnt : 0; }
+size_t gpsx_capture_block_bytes(const gpsx_capture *cap) { return cap ? cap->block_bytes : 0; }
+
+long gpsx_capture_replay_file(gpsx_capture *cap, const char *path, long first_block, long max_blocks,
+                              gpsx_capture_block_fn on_block, void *user)
+{
+  if (!cap || !path || first_block < 0)
+    return GPSX_EINVAL;
+  gpsx_ctx *ctx = cap->ctx;
+  std::FILE *f = std::fopen(path, "rb");
+  if (!f)
+    return fail(ctx, GPSX_EIO, std::string("cannot open ") + path);
+  long done = 0;
+  int rc = GPSX_OK;
+  if (fseeko(f, (off_t)first_block * (off_t)cap->block_bytes, SEEK_SET) != 0)
+    rc = fail(ctx, GPSX_EIO, "seek past the end of the IF file");
+  while (rc == GPSX_OK && (max_blocks < 0 || done < max_blocks)) {
+    uint8_t *slot = gpsx_capture_write_slot(cap);
+    if (std::fread(slot, 1, cap->block_bytes, f) != cap->block_bytes)
+      break;   // end of the recording (a trailing partial block is dropped, as a 1 ms DMA transfer would never complete)
+    rc = gpsx_capture_commit(cap);
+    if (rc != GPSX_OK)
+      break;
+    done++;
+    if (on_block && on_block(user, cap, first_block + done - 1) != 0)
+      break;
+  }
+  std::fclose(f);
+  return rc == GPSX_OK ? done : rc;
+}

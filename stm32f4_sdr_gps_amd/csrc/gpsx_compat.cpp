@@ -65,6 +65,7 @@ extern "C" {
 
 void gpsx_compat_shutdown(void)
 {
+  gpsx_compat_capture_forget();   // the rings die with the context
   gpsx_destroy(g_ctx);
   g_ctx = nullptr;
 }

@@ -5,3 +5,5 @@
 // the process-wide default context of the reference-named interface; aborts loudly if no GPU can be opened
 gpsx_ctx *gpsx_compat_ctx();
 [[noreturn]] void gpsx_compat_die(const char *what, int rc);
+// the reference-named capture interface (gpsx_steps.cpp) drops its ring handles; called before the context goes away
+void gpsx_compat_capture_forget();

@@ -519,6 +519,86 @@ void gpsx_compat_set_packet_cnt(uint32_t ticks_ms) { g_ticks = ticks_ms; }
 
 __attribute__((weak)) uint32_t signal_capture_get_packet_cnt(void) { return g_ticks; }
 
+// ---- capture interface (PM/signal_capture.h) on two capture rings of the default context ---------------------------
+// g_ring: the two-slot circular buffer the DMA fills (PM/signal_capture.c:14-19); g_copy: the "long processing" copy
+// (spi_rx_copy_buffer, :22).  gpsx_compat_capture_push is the half / full transfer interrupt (:57-82).  Blocks go to
+// the device when they arrive, so the step calls that get these pointers back find them in HBM already.
+namespace {
+
+gpsx_capture *g_ring = nullptr;
+gpsx_capture *g_copy = nullptr;
+uint8_t g_need_copy = 0;        // signal_capture_need_copy_flag
+uint8_t g_irq_unprocessed = 0;  // signal_capture_irq_unprocessed_flag
+
+void capture_open()
+{
+  if (g_ring)
+    return;
+  gpsx_ctx *gx = gpsx_compat_ctx();
+  int rc = gpsx_capture_create(gx, 2, &g_ring);
+  if (rc == GPSX_OK)
+    rc = gpsx_capture_create(gx, 1, &g_copy);
+  if (rc != GPSX_OK)
+    gpsx_compat_die("gpsx_capture_create", rc);
+}
+
+}  // namespace
+
+}  // extern "C"
+
+void gpsx_compat_capture_forget()
+{
+  g_ring = g_copy = nullptr;
+  g_need_copy = g_irq_unprocessed = 0;
+}
+
+extern "C" {
+
+__attribute__((weak)) void signal_capture_init(void) { capture_open(); }
+
+void gpsx_compat_capture_push(const uint8_t *block)
+{
+  capture_open();
+  const int rc = gpsx_capture_push(g_ring, block);
+  if (rc != GPSX_OK)
+    gpsx_compat_die("gpsx_capture_push", rc);
+  g_ticks++;
+  g_irq_unprocessed = 1;
+}
+
+__attribute__((weak)) uint8_t *signal_capture_get_ready_buf(void)
+{
+  capture_open();
+  g_irq_unprocessed = 0;
+  const uint8_t *p = gpsx_capture_ready_buf(g_ring);
+  return const_cast<uint8_t *>(p ? p : gpsx_capture_write_slot(g_ring));   // nothing received yet: a zeroed slot
+}
+
+__attribute__((weak)) uint8_t *signal_capture_get_copy_buf(void)
+{
+  capture_open();
+  const uint8_t *p = gpsx_capture_ready_buf(g_copy);
+  return const_cast<uint8_t *>(p ? p : gpsx_capture_write_slot(g_copy));   // one slot: a fixed address either way
+}
+
+__attribute__((weak)) void signal_capture_handling(void)   // PM/signal_capture.c:108-135 without the 900 us deadline
+{
+  if (!g_irq_unprocessed || !g_ring)
+    return;
+  if (g_need_copy) {
+    const uint8_t *ready = gpsx_capture_ready_buf(g_ring);
+    const int rc = ready ? gpsx_capture_push(g_copy, ready) : GPSX_OK;
+    if (rc != GPSX_OK)
+      gpsx_compat_die("gpsx_capture_push", rc);
+    g_need_copy = 0;
+    g_irq_unprocessed = 0;
+  }
+}
+
+__attribute__((weak)) uint8_t signal_capture_have_irq(void) { return g_irq_unprocessed; }
+__attribute__((weak)) void signal_capture_need_data_copy(void) { g_need_copy = 1; }
+__attribute__((weak)) uint8_t signal_capture_check_copied(void) { return g_need_copy == 0; }
+
 __attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *, uint8_t) {}
 
 // Default prompt-I hook: 20 ms bit-period synchronisation and bit integration (PM/GPS/nav_data.c:46-250), without the

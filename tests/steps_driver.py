@@ -85,11 +85,18 @@ def preset_channel(steps: "StepsLib", prn: int, found_freq_hz: int, found_code_p
     return ch
 
 
-def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int):
+def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int, via_capture: bool = False):
     """Cold boot exactly as PM/main.c does: memset the table, set PRN + Doppler hint, gps_channell_prepare, then the main
     loop: acquisition (one captured block per call) until every channel is GPS_ACQ_DONE, then 17-slot multiplexed
-    tracking.  Returns uint8 snapshots [n_ms, 4, 226] taken after each millisecond's calls."""
+    tracking.  Returns uint8 snapshots [n_ms, 4, 226] taken after each millisecond's calls.
+
+    via_capture (libgpsx only): the blocks arrive through the capture interface of PM/signal_capture.h -- pushed as the DMA
+    interrupt would, fetched back with signal_capture_get_copy_buf (acquisition, PM/main.c:106-125,163-168) or
+    signal_capture_get_ready_buf (tracking, PM/main.c:134-137) -- instead of being handed over as numpy buffers."""
     lib = steps.lib
+    if via_capture:
+        assert not steps.is_reference
+        lib.signal_capture_init()
     table = np.zeros((N_CH, CH_SIZE), np.uint8)
     for i in range(N_CH):
         table[i, 664] = prns[i]
@@ -132,10 +139,21 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int)
     steps.set_time(0)
     need_acq = master(0)
     for t in range(n_ms):
-        steps.set_time(t)
         blk = np.ascontiguousarray(stream[t])
+        if via_capture:
+            lib.gpsx_compat_capture_push(blk.ctypes.data)         # the interrupt: new block, tick + 1, flag raised
+            assert lib.signal_capture_have_irq() == 1
+        steps.set_time(t)
         if need_acq:
-            lib.acquisition_process(base, blk.ctypes.data)      # main_process_acq_data, PM/main.c:163-168
+            if via_capture:                                        # main_slow_data_proc: request a copy, take it
+                lib.signal_capture_need_data_copy()
+                assert lib.signal_capture_check_copied() == 0
+                lib.signal_capture_handling()
+                assert lib.signal_capture_check_copied() == 1 and lib.signal_capture_have_irq() == 0
+                data = lib.signal_capture_get_copy_buf()
+            else:
+                data = blk.ctypes.data
+            lib.acquisition_process(base, data)                    # main_process_acq_data, PM/main.c:163-168
             need_acq = master(0)
         else:
             big = t % (4 * N_CH + 1)                               # main_fast_data_proc, PM/main.c:134-158
@@ -143,7 +161,8 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int)
             if sat >= N_CH:
                 sat = 0
             index = 0xFF if big == 4 * N_CH else big % 4
-            lib.gps_tracking_process(ch_ptr(sat), blk.ctypes.data, index)
+            data = lib.signal_capture_get_ready_buf() if via_capture else blk.ctypes.data
+            lib.gps_tracking_process(ch_ptr(sat), data, index)
             need_acq = master(index)
         snaps[t] = snapshot(table)
     return snaps

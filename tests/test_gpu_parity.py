@@ -3,6 +3,8 @@
   (b) the CPU oracle (oracle/liboracle.so) on seeded inputs.
 Everything here is integer/bit work: the bar is bit-exact equality.  Nothing reads /root/reference.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -578,3 +580,95 @@ def test_kernels_do_not_write_outside_their_outputs(eng, stream):
     check(p_st, n_st)
     check(p_iq, n_iq)
     eng.free(d_if)
+
+
+# ---- IF ingest: capture ring (include/gpsx.h; PM/signal_capture.c:14-24,57-82, PC_SpiLight replay) ---------------------
+
+def test_capture_ring_mirror_windows_and_wrap(eng, stream):
+    from stm32f4_sdr_gps_amd import capi
+    cap = capi.Capture(eng, 4)
+    try:
+        assert cap.block_bytes == 2046 and cap.packet_cnt() == 0 and cap.ready_ptr() == 0
+        with pytest.raises(capi.GpsxError):
+            cap.window_dev(1)                                    # nothing received yet
+        for t in range(6):                                       # slots 0 1 2 3 0 1: the ring has wrapped
+            cap.push(stream[t])
+            assert cap.packet_cnt() == t + 1
+            assert np.array_equal(cap.ready_view()[0], stream[t])
+        for n in (1, 3, 4):                                      # 3 and 4 straddle the wrap: contiguous in HBM anyway
+            back = np.zeros((n, 2046), np.uint8)
+            eng.d2h(back, cap.window_dev(n))
+            assert np.array_equal(back, stream[6 - n:6]), n
+        with pytest.raises(capi.GpsxError):
+            cap.window_dev(5)                                    # more than the ring holds
+    finally:
+        cap.close()
+
+
+def test_host_entry_points_read_ring_pointers_from_the_mirror(eng, stream):
+    """Pointers into committed ring slots are served from HBM; results equal the plain host-buffer path.  A slot handed
+    out for writing again is no longer trusted: the call then copies what the host memory holds NOW."""
+    from stm32f4_sdr_gps_amd import capi
+    prns = np.array([5, 14, 20, 30], np.uint8)
+    kw = dict(n_search=1, n_ms=2, dopp_min_hz=500, dopp_step_hz=500, n_dopp=3)
+    want_pk, want_keys = eng.acq_grid(stream[2:4], prns, **kw)
+    st0 = np.zeros(4, capi.TRK_DTYPE)
+    st0["prn"] = prns
+    st0["code_phase_fine"] = [1600.0, 4000.5, 9003.0, 13007.9]
+    st0["if_freq_offset_hz"] = [912.5, 4037.0, -1025.0, 2018.0]
+    st_w = st0.copy()
+    want_iq = eng.track_epl(stream[3], st_w)
+    cap = capi.Capture(eng, 8)
+    try:
+        for t in range(4):
+            cap.push(stream[t])
+        pk, keys = eng.acq_grid(cap.ready_view(2), prns, **kw)                 # slots 2..3
+        assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys)
+        st = st0.copy()
+        assert np.array_equal(eng.track_epl(cap.ready_view()[0], st), want_iq) and np.array_equal(st, st_w)
+        # staleness: take slot 4 for writing, scribble over it WITHOUT committing -> must not be read from the mirror
+        slot = eng.lib.gpsx_capture_write_slot(cap.h)
+        view = np.frombuffer((C.c_uint8 * 2046).from_address(slot), np.uint8)
+        view[:] = stream[3]
+        st = st0.copy()
+        assert np.array_equal(eng.track_epl(view, st), want_iq)
+        # and a committed slot whose HOST bytes are then modified keeps serving the committed block (documented: the
+        # ring belongs to the producer between write_slot and commit only)
+        eng._chk(eng.lib.gpsx_capture_commit(cap.h), "commit")
+        assert cap.packet_cnt() == 5
+    finally:
+        cap.close()
+
+
+def test_capture_replay_of_a_recorded_if_file(eng, stream, tmp_path):
+    from stm32f4_sdr_gps_amd import capi
+    path = str(tmp_path / "rec_file.bin")
+    stream[:9].tofile(path)
+    with open(path, "ab") as f:
+        f.write(b"\x55" * 1000)                                  # trailing partial block: dropped
+    prns = np.array([5, 14, 20, 30], np.uint8)
+    st0 = np.zeros(4, capi.TRK_DTYPE)
+    st0["prn"] = prns
+    st0["code_phase_fine"] = [1600.0, 4000.5, 9003.0, 13007.9]
+    st0["if_freq_offset_hz"] = [912.5, 4037.0, -1025.0, 2018.0]
+    cap = capi.Capture(eng, 2)
+    try:
+        seen, st, iqs = [], st0.copy(), []
+
+        def on_block(idx):
+            seen.append(idx)
+            iqs.append(eng.track_epl(cap.ready_view()[0], st).copy())          # per-ms processing on the fresh block
+            return 1 if idx == 7 else 0                                         # stop early once
+
+        assert cap.replay_file(path, first_block=2, on_block=on_block) == 6 and seen == [2, 3, 4, 5, 6, 7]
+        st_w, want = st0.copy(), []
+        for t in range(2, 8):
+            want.append(eng.track_epl(stream[t], st_w).copy())
+        assert np.array_equal(np.array(iqs), np.array(want)) and np.array_equal(st, st_w)
+        assert cap.replay_file(path, first_block=7, max_blocks=-1) == 2         # blocks 7, 8; the partial tail is not one
+        assert cap.replay_file(path, first_block=0, max_blocks=3) == 3
+        assert cap.packet_cnt() == 11
+        with pytest.raises(capi.GpsxError):
+            cap.replay_file(str(tmp_path / "missing.bin"))
+    finally:
+        cap.close()

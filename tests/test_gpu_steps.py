@@ -59,6 +59,22 @@ def test_step_trace_matches_reference(gpsx_lib, name):
         assert abs(end[0]["code_phase_fine"] - 1600.0) < 1.0 and abs(end[0]["freq"] - 912.5) < 2.0
 
 
+def test_step_trace_through_the_capture_interface(gpsx_lib):
+    """Same scenario, blocks delivered through signal_capture_* (PM/signal_capture.h) on the engine's capture rings: the
+    step calls get pinned ring pointers and read the HBM mirror.  1200 ms cover acquisition, pre-track and tracking."""
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_hints.npz")
+    n_ms = 1200
+    stream = synth.four_sv_with_nav(int(g["n_ms"]), seed=7)[:n_ms]
+    C.CDLL("libc.so.6").srand(1)
+    snaps = sd.run_scenario(sd.StepsLib(gpsx_lib, False), stream, g["prns"].tolist(), g["hints"].tolist(), n_ms,
+                            via_capture=True)
+    want = g["snaps"][:n_ms]
+    assert _first_mismatch(snaps, want, 0, 223) is None, _first_mismatch(snaps, want, 0, 223)
+    assert gpsx_lib.signal_capture_get_packet_cnt() == n_ms - 1      # set_time(t) each step; push made it t + 1 before
+    assert {sd.summarize(snaps)[i]["trk_state"] for i in range(4)} == {sd.TRK_RUN}
+
+
 def test_time_source_is_overridable_weak_symbol(gpsx_lib):
     import subprocess
     out = subprocess.check_output(["nm", "-D", os.path.join(os.path.dirname(gpsx_lib._name), "libgpsx.so")], text=True)
