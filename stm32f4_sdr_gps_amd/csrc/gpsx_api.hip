@@ -50,6 +50,13 @@ struct gpsx_ctx {
   size_t acc_entries = 0;
   uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
   size_t energy_bytes = 0;
+  // Doppler-shared kernel: boundary tables of the last Doppler grid, per-(search, Doppler) prepared data (grow-only)
+  int ds_grid[3] = {0, 0, 0};        // dopp_min_hz, dopp_step_hz, n_dopp the tables were built for
+  bool ds_ok = false;
+  uint32_t *d_ds_tables = nullptr;
+  size_t ds_rows_off = 0, ds_cst0_off = 0;
+  uint32_t *d_ds_work = nullptr;
+  size_t ds_work_dwords = 0;
 
   // grouped tables for the PRN list of the last grid call
   std::vector<uint8_t> grid_prns;
@@ -252,7 +259,10 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     return GPSX_ENODEV;
   }
   if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
-    ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad : (std::strcmp(a, "dot8") == 0 ? kAlgoDot8 : kAlgoPoly);
+    ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad
+                : std::strcmp(a, "dot8") == 0 ? kAlgoDot8
+                : std::strcmp(a, "ds") == 0   ? kAlgoDs
+                                              : kAlgoPoly;
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -299,7 +309,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
-                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc, ctx->d_energy};
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc, ctx->d_energy, ctx->d_ds_tables, ctx->d_ds_work};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
@@ -456,6 +466,93 @@ size_t gpsx_acq_peaks_count(const gpsx_acq_grid_t *g)
   return g ? gpsx_acq_keys_count(g) * gpsx_acq_bits(g->phase_mode) : 0;
 }
 
+namespace {
+
+int ensure_acc(gpsx_ctx *ctx, size_t n_peaks)
+{
+  if (n_peaks <= ctx->acc_entries)
+    return GPSX_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_acc)
+    (void)hipFree(ctx->d_acc);
+  ctx->d_acc = nullptr;
+  ctx->acc_entries = 0;
+  HIPCHK(ctx, hipMalloc((void **)&ctx->d_acc, 2 * n_peaks * sizeof(uint32_t)));
+  ctx->acc_entries = n_peaks;
+  return GPSX_OK;
+}
+
+// The Doppler-shared kernel.  Returns false when this grid cannot use it (the caller falls through to k_acq_poly);
+// true with *rc set otherwise.
+bool acq_grid_ds(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const AcqParams &prm, const uint8_t *d_if, gpsx_peak_t *d_peaks,
+                 int *rc)
+{
+  auto run = [&]() -> int {
+    if (ctx->ds_grid[0] != g->dopp_min_hz || ctx->ds_grid[1] != g->dopp_step_hz || ctx->ds_grid[2] != g->n_dopp ||
+        !ctx->d_ds_tables) {
+      std::vector<uint32_t> rows;
+      std::vector<int32_t> cst0;
+      ctx->ds_ok = build_ds_tables(g->dopp_min_hz, g->dopp_step_hz, g->n_dopp, rows, cst0);
+      ctx->ds_grid[0] = g->dopp_min_hz;
+      ctx->ds_grid[1] = g->dopp_step_hz;
+      ctx->ds_grid[2] = g->n_dopp;
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_ds_tables)
+        (void)hipFree(ctx->d_ds_tables);
+      ctx->d_ds_tables = nullptr;
+      if (!ctx->ds_ok)
+        return GPSX_OK;
+      ctx->ds_rows_off = 0;
+      ctx->ds_cst0_off = rows.size();
+      std::vector<uint32_t> blob(rows);
+      for (int32_t v : cst0)
+        blob.push_back((uint32_t)v);
+      HIPCHK(ctx, hipMalloc((void **)&ctx->d_ds_tables, blob.size() * 4));
+      HIPCHK(ctx, hipMemcpy(ctx->d_ds_tables, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!ctx->ds_ok)
+      return GPSX_OK;
+    const size_t pairs = (size_t)g->n_search * g->n_dopp;
+    const size_t hdr_dw = pairs * 4, rec_dw = pairs * 2 * kDsRecDwords, xpl_dw = (size_t)g->n_search * 16 * 32;
+    const size_t etab_dw = pairs * 16 * 4;
+    if (hdr_dw + rec_dw + xpl_dw + etab_dw > ctx->ds_work_dwords) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_ds_work)
+        (void)hipFree(ctx->d_ds_work);
+      ctx->d_ds_work = nullptr;
+      ctx->ds_work_dwords = 0;
+      HIPCHK(ctx, hipMalloc((void **)&ctx->d_ds_work, (hdr_dw + rec_dw + xpl_dw + etab_dw) * 4));
+      ctx->ds_work_dwords = hdr_dw + rec_dw + xpl_dw + etab_dw;
+    }
+    const size_t n_peaks = gpsx_acq_peaks_count(g);
+    if (int e = ensure_acc(ctx, n_peaks)) return e;
+    DsParams P{};
+    P.n_search = g->n_search;
+    P.n_prn = g->n_prn;
+    P.n_dopp = g->n_dopp;
+    P.n_chunks = (g->n_dopp + kDsDopplersPerWave - 1) / kDsDopplersPerWave;
+    P.win_start = g->win_start;
+    P.win_stop = g->win_stop;
+    P.rows = ctx->d_ds_tables + ctx->ds_rows_off;
+    P.cst0 = reinterpret_cast<const int32_t *>(ctx->d_ds_tables + ctx->ds_cst0_off);
+    P.hdr = ctx->d_ds_work;
+    P.rec = ctx->d_ds_work + hdr_dw;
+    P.xpl = ctx->d_ds_work + hdr_dw + rec_dw;
+    P.etab = reinterpret_cast<uint4 *>(ctx->d_ds_work + hdr_dw + rec_dw + xpl_dw);   // 16-byte aligned: all sizes are multiples of 4 dwords
+    P.chipbits = ctx->d_grid_bits;
+    P.keyacc = ctx->d_acc;
+    P.sumacc = ctx->d_acc + n_peaks;
+    launch_acq_ds(ctx->stream, P, d_if, prm.if_format, prm.search_stride_blocks, g->dopp_min_hz, g->dopp_step_hz, n_peaks,
+                  d_peaks);
+    LAUNCHCHK(ctx, "k_acq_ds");
+    return GPSX_OK;
+  };
+  *rc = run();
+  return *rc != GPSX_OK || ctx->ds_ok;
+}
+
+}  // namespace
+
 int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_blocks, int n_blocks,
                       gpsx_peak_t *d_peaks, int64_t *d_keys, gpsx_peak_t *d_per_ms, uint32_t *d_energy, uint16_t *d_cnt)
 {
@@ -499,7 +596,21 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.energy = d_energy;
   prm.cnt = d_cnt;
   const bool inspect = d_per_ms || d_energy || d_cnt;
-  bool poly = ctx->algo == kAlgoPoly && n_bits == 8 && !inspect;
+  const bool fine = (ctx->algo == kAlgoPoly || ctx->algo == kAlgoDs) && n_bits == 8 && !inspect;
+  if (fine && ctx->algo == kAlgoDs && g->n_ms == 1 && shard_count == 1) {
+    int rc = GPSX_OK;
+    if (acq_grid_ds(ctx, g, prm, static_cast<const uint8_t *>(d_if_blocks), d_peaks, &rc)) {
+      if (rc != GPSX_OK)
+        return rc;
+      if (d_keys) {
+        launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
+                        shard_count);
+        LAUNCHCHK(ctx, "k_acq_keys");
+      }
+      return GPSX_OK;
+    }
+  }
+  bool poly = fine;
   if (poly && g->n_ms > 1) {
     // the multi-block form keeps 64 KB of running sums per (PRN, Doppler) pair of this shard in HBM; when that cannot
     // be had (it is 2.7 GB for 64 simultaneous cold-start searches) the register-resident dot8 kernel does the job

@@ -501,6 +501,13 @@ __global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__rest
   peaks[idx] = pk;
 }
 
+void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
+                         gpsx_peak_t *d_peaks)
+{
+  hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
+                     d_peaks);
+}
+
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
                      gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy)
