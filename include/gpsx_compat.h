@@ -112,10 +112,13 @@ typedef struct {
   gps_tracking_state_t state;
 } gps_tracking_t;
 
-/* Navigation-bit synchronisation state: the leading members of the reference's gps_nav_data_t (gps_misc.h:101-133),
- * which the tracking step reads (PLL gain selection) and its nav-bit hook writes.  Word / subframe assembly, observation
- * and ephemeris state are outside the correlator path and are carried as opaque storage of the reference's size so that
- * gps_ch_t keeps its layout (gps_misc.h:134-182). */
+/* Navigation-data state of a channel (gps_misc.h:101-133): 20 ms bit synchronisation, which the tracking step reads
+ * (PLL gain selection) and its nav-bit hook writes; then the word layer -- preamble search, parity, polarity, subframe
+ * assembly and the subframe's time stamp.  Observation and ephemeris state (pseudorange, decoded orbit) are outside this
+ * library and are carried as opaque storage of the reference's size so that gps_ch_t keeps its layout
+ * (gps_misc.h:134-182). */
+#define GPS_NAV_WORD_LENGTH           30   /* bits */
+#define GPS_NAV_SUBFRAME_LENGTH_BYTES 38   /* 300 bits */
 typedef struct {
   uint8_t  period_sync_ok_flag;    /* 20 ms bit period found                                       */
   uint8_t  right_period_cnt;
@@ -125,8 +128,21 @@ typedef struct {
   uint8_t  accurate_swap_ok;
   uint8_t  last_bit_pos_cnt;
   uint8_t  last_bit_neg_cnt;
-  uint8_t  inv_polarity_flag;
-  uint8_t  opaque_[98];
+  uint8_t  inv_polarity_flag;      /* the Costas loop locked 180 degrees off: bits are inverted    */
+  uint8_t  polarity_found;         /* a word passed parity with the current polarity               */
+  uint8_t  inv_preabmle_cnt;       /* inverted preambles seen while hunting                        */
+  uint8_t  word_buf[GPS_NAV_WORD_LENGTH];   /* one bit per byte: the word being collected          */
+  uint8_t  word_cnt;               /* words of the current subframe received (0 = hunting)         */
+  uint8_t  word_bit_cnt;
+  uint8_t  old_D29;                /* last two bits of the previous word, for the parity equations */
+  uint8_t  old_D30;
+  uint32_t word_detection_timestamp;        /* ms tick of the last word that passed parity         */
+  uint32_t word_cnt_test;
+  uint32_t last_subframe_time;     /* ms tick of the bit edge that began the current subframe      */
+  uint32_t first_subframe_time;
+  uint16_t subframe_cnt;
+  uint8_t  new_subframe_flag;
+  uint8_t  subframe_data[GPS_NAV_SUBFRAME_LENGTH_BYTES];   /* bit n of the subframe = bit (n & 7) of byte n >> 3 */
 } gps_nav_data_t;
 typedef struct { double opaque_[2]; }  gps_obs_data_t;
 typedef struct { double opaque_[40]; } sdreph_t;
@@ -205,10 +221,14 @@ void      gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data,
  *   signal_capture_get_packet_cnt  1 ms tick (PM/signal_capture.c:35); default: a counter set by gpsx_compat_set_packet_cnt
  *   gps_nav_data_analyse_new_code  prompt-I hook (PM/GPS/nav_data.c:46-138); default: 20 ms bit-period synchronisation
  *                                  and bit integration only, ending in gps_nav_data_words_detection
- *   gps_nav_data_words_detection   word / preamble assembly (PM/GPS/nav_data.c:258-...): default no-op (out of scope) */
+ *   gps_nav_data_words_detection   word layer (PM/GPS/nav_data.c:257-351): preamble search, parity, polarity detection,
+ *                                  subframe assembly, ending in gps_nav_data_decode_subframe once per subframe
+ *   gps_nav_data_decode_subframe   ephemeris decode (PM/GPS/nav_data_decode.c:34-52); default: returns the subframe ID
+ *                                  from the hand-over word and decodes nothing (orbit data is out of scope) */
 uint32_t signal_capture_get_packet_cnt(void);
 void     gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t new_i);
 void     gps_nav_data_words_detection(gps_ch_t *channel, uint8_t new_bit);
+uint8_t  gps_nav_data_decode_subframe(gps_ch_t *channel);
 void     gpsx_compat_set_packet_cnt(uint32_t ticks_ms);
 
 /* The capture interface of PM/signal_capture.h (weak, like the hooks above) on top of the engine's capture rings

@@ -81,3 +81,28 @@ def gen_continuous():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "continuous":
     gen_continuous()
+
+
+def gen_lnav():
+    """Golden for the word layer (nav_data.c:257-451): 15 s of the 4-SV table carrying parity-correct LNAV subframes, two
+    satellites with inverted data polarity.  Too long to keep every snapshot: a CRC of the full channel state (acq_data,
+    tracking_data, all of nav_data) per millisecond, the full state every 500 ms, and the final state."""
+    pyoracle.build_ref()
+    n_ms, prns, hints = 15000, [5, 14, 20, 30], [900, 4000, -1000, 2000]
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_steps.so"))
+    C.CDLL("libc.so.6").srand(1)
+    stream = synth.four_sv_with_lnav(n_ms, seed=7)
+    crcs, checkpoints, final = sd.run_scenario(sd.StepsLib(lib, True), stream, prns, hints, n_ms, digest=True)
+    path = os.path.join(ROOT, "tests", "golden", "f7_steps_lnav.npz")
+    np.savez_compressed(path, crcs=crcs, checkpoints=checkpoints, final=final, prns=np.array(prns), hints=np.array(hints),
+                        n_ms=np.int32(n_ms), stream_fnv=np.uint32(fnv1a32(stream[::97])))
+    print("lnav", os.path.getsize(path), "bytes")
+    nav = final[:, 212:324]
+    for i in range(4):
+        print("  PRN", prns[i], "inv_polarity", nav[i, 13], "polarity_found", nav[i, 14], "word_cnt", nav[i, 46],
+              "words ok", int(nav[i, 56:60].view("<u4")[0]), "subframes", int(nav[i, 68:70].view("<u2")[0]),
+              "last_subframe_time", int(nav[i, 60:64].view("<u4")[0]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lnav":
+    gen_lnav()

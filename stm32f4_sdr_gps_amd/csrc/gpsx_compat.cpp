@@ -19,6 +19,11 @@ static_assert(offsetof(gps_tracking_t, if_freq_offset_hz) == 4 && offsetof(gps_t
 static_assert(offsetof(gps_tracking_t, code_phase_fine) == 80 && offsetof(gps_tracking_t, state) == 148,
               "gps_tracking_t layout");
 static_assert(offsetof(gps_ch_t, tracking_data) == 60 && offsetof(gps_ch_t, nav_data) == 212, "gps_ch_t layout");
+static_assert(sizeof(gps_nav_data_t) == 112 && offsetof(gps_nav_data_t, inv_polarity_flag) == 13 &&
+                  offsetof(gps_nav_data_t, word_buf) == 16 && offsetof(gps_nav_data_t, word_cnt) == 46 &&
+                  offsetof(gps_nav_data_t, word_detection_timestamp) == 52 && offsetof(gps_nav_data_t, subframe_cnt) == 68 &&
+                  offsetof(gps_nav_data_t, subframe_data) == 71,
+              "gps_nav_data_t layout");
 static_assert(offsetof(gps_ch_t, obs_data) == 328 && offsetof(gps_ch_t, eph_data) == 344, "gps_ch_t layout");
 static_assert(offsetof(gps_ch_t, prn) == 664 && offsetof(gps_ch_t, prn_code) == 665 && sizeof(gps_ch_t) == 1688,
               "gps_ch_t layout");

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <vector>
 
 #include "../../include/gpsx_compat.h"
@@ -599,10 +600,149 @@ __attribute__((weak)) uint8_t signal_capture_have_irq(void) { return g_irq_unpro
 __attribute__((weak)) void signal_capture_need_data_copy(void) { g_need_copy = 1; }
 __attribute__((weak)) uint8_t signal_capture_check_copied(void) { return g_need_copy == 0; }
 
-__attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *, uint8_t) {}
+// ---- word layer (PM/GPS/nav_data.c:257-451): 50 bit/s stream -> 30-bit words -> 10-word subframes --------------------
+namespace {
 
-// Default prompt-I hook: 20 ms bit-period synchronisation and bit integration (PM/GPS/nav_data.c:46-250), without the
-// word / subframe layer.  A host that links the reference's nav_data.c overrides it.
+constexpr uint32_t kBadPolarityTimeoutMs = 12000;   // two subframes without a good word: forget the polarity (nav_data.c:22)
+const uint8_t kPreamble[8] = {1, 0, 0, 0, 1, 0, 1, 1};
+
+// IS-GPS-200 table 20-XIV: which of the source bits d1..d24 (bit i - 1 of the mask) enter parity bits D25..D30, and
+// which of the previous word's last two bits (D29*, D30*) each starts from
+constexpr uint32_t parity_mask(std::initializer_list<int> bits)
+{
+  uint32_t m = 0;
+  for (int b : bits)
+    m |= 1u << (b - 1);
+  return m;
+}
+constexpr uint32_t kParityMask[6] = {
+    parity_mask({1, 2, 3, 5, 6, 10, 11, 12, 13, 14, 17, 18, 20, 23}),
+    parity_mask({2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24}),
+    parity_mask({1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22}),
+    parity_mask({2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23}),
+    parity_mask({1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24}),
+    parity_mask({3, 5, 6, 8, 9, 10, 11, 13, 15, 19, 22, 23, 24}),
+};
+constexpr bool kParityFromD30[6] = {false, true, false, true, true, false};
+
+bool starts_with_preamble(const gps_nav_data_t &n, uint8_t invert)
+{
+  for (int i = 0; i < 8; i++)
+    if (n.word_buf[i] != (kPreamble[i] ^ invert))
+      return false;
+  return true;
+}
+
+// the collected word becomes word `word_cnt` of the subframe image; its last two bits seed the next word's parity
+void store_word(gps_nav_data_t &n)   // nav_data.c:409-429
+{
+  const int first = n.word_cnt * GPS_NAV_WORD_LENGTH;
+  for (int i = 0; i < GPS_NAV_WORD_LENGTH; i++) {
+    const int bit = first + i;
+    if (n.word_buf[i] == 1)
+      n.subframe_data[bit >> 3] |= (uint8_t)(1u << (bit & 7));
+    else
+      n.subframe_data[bit >> 3] &= (uint8_t)~(1u << (bit & 7));
+  }
+  n.old_D29 = n.word_buf[28];
+  n.old_D30 = n.word_buf[29];
+}
+
+// Removes the D30* inversion from the 24 data bits IN PLACE (as the reference does: what is stored afterwards are source
+// bits), then checks the six parity bits.
+bool word_parity_ok(gps_nav_data_t &n)   // nav_data.c:433-452
+{
+  uint32_t d = 0;
+  for (int i = 0; i < 24; i++) {
+    n.word_buf[i] ^= n.old_D30;
+    d |= (uint32_t)(n.word_buf[i] & 1u) << i;
+  }
+  for (int k = 0; k < 6; k++) {
+    const uint8_t p = (uint8_t)((__builtin_popcount(d & kParityMask[k]) & 1) ^ (kParityFromD30[k] ? n.old_D30 : n.old_D29));
+    if (n.word_buf[24 + k] != p)
+      return false;
+  }
+  return true;
+}
+
+// The subframe that just completed began at the last accurately located bit edge at or before now (nav_data.c:356-378).
+void stamp_subframe(gps_nav_data_t &n)
+{
+  if (n.accurate_swap_ok == 0)
+    return;
+  const uint32_t now = signal_capture_get_packet_cnt();
+  uint32_t edge = now / 20 * 20 + n.accurate_swap_time;
+  if ((int32_t)(now - edge) < 0)
+    edge -= 20;
+  n.subframe_cnt++;
+  n.last_subframe_time = edge;
+}
+
+}  // namespace
+
+__attribute__((weak)) uint8_t gps_nav_data_decode_subframe(gps_ch_t *channel)
+{
+  const uint8_t *sf = channel->nav_data.subframe_data;   // hand-over word, bits 20-22 = subframe bits 49..51, MSB first
+  uint8_t id = 0;
+  for (int bit = 49; bit < 52; bit++)
+    id = (uint8_t)((id << 1) | ((sf[bit >> 3] >> (bit & 7)) & 1u));
+  return id;
+}
+
+__attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *channel, uint8_t new_bit)
+{
+  gps_nav_data_t &n = channel->nav_data;
+  if (n.word_cnt == 0) {
+    // hunting: slide the 30-bit window by one bit and look for the preamble at its head
+    std::memmove(n.word_buf, n.word_buf + 1, GPS_NAV_WORD_LENGTH - 1);
+    n.word_buf[GPS_NAV_WORD_LENGTH - 1] = new_bit;
+    if (starts_with_preamble(n, 0)) {
+      store_word(n);
+      n.word_cnt = 1;
+      n.word_bit_cnt = 0;
+      n.inv_preabmle_cnt = 0;
+    }
+    if (n.polarity_found == 0 && n.word_cnt == 0) {
+      if (starts_with_preamble(n, 1))
+        n.inv_preabmle_cnt++;
+      if (n.inv_preabmle_cnt >= 2)
+        n.inv_polarity_flag = 1;
+    }
+    if (n.polarity_found) {
+      if (signal_capture_get_packet_cnt() - n.word_detection_timestamp > kBadPolarityTimeoutMs) {
+        n.word_detection_timestamp = signal_capture_get_packet_cnt();
+        n.polarity_found = 0;
+        n.inv_polarity_flag = 0;
+      }
+    }
+    return;
+  }
+  // synchronised: collect the next word bit by bit
+  n.word_buf[n.word_bit_cnt++] = new_bit;
+  if (n.word_bit_cnt < GPS_NAV_WORD_LENGTH)
+    return;
+  if (!word_parity_ok(n)) {
+    n.word_cnt = 0;
+    std::memset(n.word_buf, 0, GPS_NAV_WORD_LENGTH);
+    return;
+  }
+  n.word_cnt_test++;
+  store_word(n);
+  n.word_cnt++;
+  n.word_bit_cnt = 0;
+  n.word_detection_timestamp = signal_capture_get_packet_cnt();
+  n.polarity_found = 1;
+  if (n.word_cnt == 10) {
+    (void)gps_nav_data_decode_subframe(channel);
+    stamp_subframe(n);
+    n.word_cnt = 0;
+    n.new_subframe_flag = 1;
+    std::memset(n.word_buf, 0, GPS_NAV_WORD_LENGTH);   // no false preamble out of stale bits
+  }
+}
+
+// Default prompt-I hook: 20 ms bit-period synchronisation and bit integration (PM/GPS/nav_data.c:46-250), feeding the
+// word layer above.  A host that links the reference's nav_data.c overrides it.
 namespace {
 
 void refine_bit_edge(gps_ch_t *ch, const int16_t *ip, uint32_t slot_start_ticks)   // nav_data.c:145-218

@@ -119,6 +119,72 @@ def four_sv_with_nav(n_ms: int, seed: int = 7) -> np.ndarray:
     return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
 
 
+# ---- LNAV framing (IS-GPS-200, 20.3.3 / 20.3.5): what a receiver's word layer needs to lock on -------------------------
+# Parity bits D25..D30 of a word: XOR of the listed source bits d1..d24 with D29* or D30*, the previous word's last two
+# transmitted bits (table 20-XIV); the 24 data bits themselves go out XORed with D30*.
+_PARITY = ((29, (1, 2, 3, 5, 6, 10, 11, 12, 13, 14, 17, 18, 20, 23)), (30, (2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24)),
+           (29, (1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22)), (30, (2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23)),
+           (30, (1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24)), (29, (3, 5, 6, 8, 9, 10, 11, 13, 15, 19, 22, 23, 24)))
+_PREAMBLE = (1, 0, 0, 0, 1, 0, 1, 1)
+
+
+def lnav_word(d: list[int], d29_prev: int, d30_prev: int, solve_tail: bool = False) -> list[int]:
+    """24 source bits -> 30 transmitted bits.  solve_tail: choose source bits 23, 24 (the non-information bearing bits of
+    the hand-over word and of word 10) so that the word ends in D29 = D30 = 0."""
+    for tail in range(4 if solve_tail else 1):
+        if solve_tail:
+            d = d[:22] + [tail >> 1, tail & 1]
+        par = []
+        for start, taps in _PARITY:
+            p = d29_prev if start == 29 else d30_prev
+            for t in taps:
+                p ^= d[t - 1]
+            par.append(p)
+        if not solve_tail or (par[4] == 0 and par[5] == 0):
+            return [b ^ d30_prev for b in d] + par
+    raise AssertionError("no tail bits give D29 = D30 = 0")
+
+
+def lnav_subframe(sub_id: int, tow_count: int, rng: np.random.Generator) -> list[int]:
+    """300 transmitted bits of one subframe: TLM (preamble), HOW (time of week of the next subframe, subframe ID), eight
+    words of random payload.  Starts from D29* = D30* = 0, which every subframe's last word guarantees."""
+    def rand(n):
+        return [int(b) for b in rng.integers(0, 2, n)]
+    words = [list(_PREAMBLE) + rand(16),
+             [(tow_count >> (16 - i)) & 1 for i in range(17)] + [0, 0] + [(sub_id >> (2 - i)) & 1 for i in range(3)] + [0, 0]]
+    words += [rand(24) for _ in range(8)]
+    out, d29, d30 = [], 0, 0
+    for i, d in enumerate(words):
+        w = lnav_word(d, d29, d30, solve_tail=i in (1, 9))
+        out += w
+        d29, d30 = w[28], w[29]
+    return out
+
+
+def lnav_bits(n_bits: int, first_bit: int, seed: int) -> np.ndarray:
+    """0/1 navigation bits of a satellite that is first_bit bits into subframe 1 when the stream begins."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bits, tow, sub = [], 100, 1
+    while len(bits) < first_bit + n_bits:
+        bits += lnav_subframe(sub, tow, rng)
+        tow += 1
+        sub = sub % 5 + 1
+    return np.array(bits[first_bit:first_bit + n_bits], np.uint8)
+
+
+def four_sv_with_lnav(n_ms: int, seed: int = 7) -> np.ndarray:
+    """The 4-SV table carrying parity-correct LNAV subframes (different payload and subframe timing per satellite;
+    satellites 2 and 4 with the opposite data polarity), for the word layer: preamble search, parity, polarity
+    detection, subframe assembly and time stamp."""
+    n_bits = n_ms // 20 + 2
+    first = (37, 161, 250, 96)
+    flip = (0, 1, 0, 1)
+    bits = [(1.0 - 2.0 * (lnav_bits(n_bits, first[k], seed + 2000 + k) ^ flip[k]).astype(np.float64)) for k in range(4)]
+    sats = [Sat(5, 912.5, 1600.0, 0.6, 0.3, bits[0]), Sat(14, 4037.0, 4000.0, 0.6, 1.1, bits[1]),
+            Sat(20, -1025.0, 9000.0, 0.6, 2.5, bits[2]), Sat(30, 2018.0, 13000.0, 0.6, 4.0, bits[3])]
+    return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+
+
 def cold_start_block(n_ms: int = 1, seed: int = 11, amp_scale: float = 1.0) -> np.ndarray:
     """Config 3/4 input: six satellites in view.  amp_scale = 1 gives the strong test signal
     (amplitudes 0.5-0.6 against U(-1, 1) noise, i.e. well above a real sky, so that single-millisecond peaks are

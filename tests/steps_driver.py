@@ -13,6 +13,8 @@ import numpy as np
 CH_SIZE = 1688          # sizeof(gps_ch_t) on LP64 (tests/test_abi_and_host.py checks the layout against the reference)
 N_CH = 4
 SNAP = 226              # acq_data (60) + tracking_data (152) + first 14 bytes of nav_data
+SNAP_FULL = 324         # ... + the whole of nav_data (112 bytes): word layer, polarity, subframe image and time stamp
+CHECKPOINT_MS = 500
 
 ACQ_DTYPE = np.dtype({"names": ["freq_index", "found_freq_offset_hz", "given_freq_offset_hz", "found_code_phase",
                                 "code_search_start", "code_search_stop", "code_hist_step", "state", "hist",
@@ -85,14 +87,23 @@ def preset_channel(steps: "StepsLib", prn: int, found_freq_hz: int, found_code_p
     return ch
 
 
-def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int, via_capture: bool = False):
+def _fnv1a32(buf: np.ndarray) -> int:
+    import zlib
+    return zlib.crc32(buf.tobytes()) & 0xFFFFFFFF   # (a CRC, despite the name of its callers' field: cheap and in the stdlib)
+
+
+def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int, via_capture: bool = False,
+                 digest: bool = False):
     """Cold boot exactly as PM/main.c does: memset the table, set PRN + Doppler hint, gps_channell_prepare, then the main
     loop: acquisition (one captured block per call) until every channel is GPS_ACQ_DONE, then 17-slot multiplexed
     tracking.  Returns uint8 snapshots [n_ms, 4, 226] taken after each millisecond's calls.
 
     via_capture (libgpsx only): the blocks arrive through the capture interface of PM/signal_capture.h -- pushed as the DMA
     interrupt would, fetched back with signal_capture_get_copy_buf (acquisition, PM/main.c:106-125,163-168) or
-    signal_capture_get_ready_buf (tracking, PM/main.c:134-137) -- instead of being handed over as numpy buffers."""
+    signal_capture_get_ready_buf (tracking, PM/main.c:134-137) -- instead of being handed over as numpy buffers.
+
+    digest: long runs -- instead of every snapshot, returns (crc[n_ms] of the 4 x 324-byte state after each millisecond,
+    full states every CHECKPOINT_MS, the final state), nav_data included in full."""
     lib = steps.lib
     if via_capture:
         assert not steps.is_reference
@@ -135,7 +146,9 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int,
                     _trk_set(table, i, "state", TRK_NEED_PRE)
         return need_acq
 
-    snaps = np.zeros((n_ms, N_CH, SNAP), np.uint8)
+    snaps = np.zeros((1 if digest else n_ms, N_CH, SNAP), np.uint8)
+    crcs = np.zeros(n_ms, np.uint32)
+    checkpoints = np.zeros((n_ms // CHECKPOINT_MS, N_CH, SNAP_FULL), np.uint8)
     steps.set_time(0)
     need_acq = master(0)
     for t in range(n_ms):
@@ -164,7 +177,15 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int,
             data = lib.signal_capture_get_ready_buf() if via_capture else blk.ctypes.data
             lib.gps_tracking_process(ch_ptr(sat), data, index)
             need_acq = master(index)
-        snaps[t] = snapshot(table)
+        if digest:
+            full = table[:, :SNAP_FULL]
+            crcs[t] = _fnv1a32(full)
+            if (t + 1) % CHECKPOINT_MS == 0:
+                checkpoints[(t + 1) // CHECKPOINT_MS - 1] = full
+        else:
+            snaps[t] = snapshot(table)
+    if digest:
+        return crcs, checkpoints, table[:, :SNAP_FULL].copy()
     return snaps
 
 
