@@ -4,7 +4,8 @@
 Metric (BASELINE.json): acquisition hypotheses / second (PRN x Doppler x code phase).
 Workload (BASELINE.json configs[2], SURVEY.md 8(d) "Config 3"): cold-start grid, all 32 PRN x 21 Doppler bins
 (+-5 kHz @ 500 Hz) x 16368 code phases (2046 byte offsets x 8 replica bit shifts), 1 ms coherent, synthetic
-16.368 Msps 1-bit IF with six satellites in view (each below the noise floor; --amp-scale).  One STEP = one gpsx_acq_grid_dev() call over a batch of
+16.368 Msps IF with six satellites in view (each below the noise floor; --amp-scale), by default as 2-bit sign/magnitude
+pairs (--if-format; the magnitude bit travels and is ignored, as in the reference).  One STEP = one gpsx_acq_grid_dev() call over a batch of
 `--searches` independent 1 ms captures per GPU, inputs already resident in HBM, results (per-hypothesis-unit peak
 triplets + packed peak keys) left in HBM.
 
@@ -113,6 +114,10 @@ def main():
     ap.add_argument("--n-ms", type=int, default=1,
                     help="blocks integrated non-coherently per search (BASELINE.json configs[3] uses 10); hypotheses are "
                          "then counted per block, as SURVEY.md 8(d) config 4 does")
+    ap.add_argument("--if-format", choices=["2bit", "1bit"], default="2bit",
+                    help="sample format of the captures in HBM: 2bit = MAX2769-style sign/magnitude pairs, 4092 bytes per ms, "
+                         "unpacked to the sign plane in LDS inside the kernels (the reference's correlator never looks at "
+                         "the magnitude bit either); 1bit = the 2046-byte sign stream the firmware's SPI delivers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -154,14 +159,20 @@ def main():
     n_search = args.searches * world
     # synthetic captures: consecutive milliseconds of one stream; identical on every rank (each rank reads all of it)
     n_ms = args.n_ms
-    blocks = synth.cold_start_block(n_search * n_ms, seed=11, amp_scale=args.amp_scale)
+    blocks = synth.cold_start_block(n_search * n_ms, seed=11, amp_scale=args.amp_scale)   # sign plane (CPU leg, checks)
+    two_bit = args.if_format == "2bit"
+    if two_bit:
+        dev_blocks = synth.cold_start_block(n_search * n_ms, seed=11, amp_scale=args.amp_scale, two_bit=True)
+        eng.set_if_format(capi.IF_2BIT_SM)
+    else:
+        dev_blocks = blocks
     prns = np.arange(1, N_PRN + 1, dtype=np.uint8)
     g = eng.grid_desc(prns, n_search=n_search, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=DOPP_MIN,
                       dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046),
                       shard=(rank, world))
     import ctypes as C
     with torch.cuda.stream(stream):
-        d_if = torch.from_numpy(np.concatenate([blocks.reshape(-1), np.zeros(2, np.uint8)])).to(dev)
+        d_if = torch.from_numpy(np.concatenate([dev_blocks.reshape(-1), np.zeros(2, np.uint8)])).to(dev)
         d_peaks = torch.zeros((n_search, N_PRN, N_DOPP, 8, 4), dtype=torch.int32, device=dev)
         # two key tables: the all-reduce of step k (RCCL's own stream) overlaps the grid kernel of step k + 1
         key_bufs = [torch.zeros((n_search, N_PRN, N_DOPP), dtype=torch.int64, device=dev) for _ in range(2)]
@@ -226,7 +237,7 @@ def main():
         for i in range(reps + 2):
             if i == 2:
                 tp = time.perf_counter()
-            rc = eng.lib.gpsx_acq_grid(eng.h, C.byref(g1), blocks.ctypes.data, n_search, h_peaks.ctypes.data,
+            rc = eng.lib.gpsx_acq_grid(eng.h, C.byref(g1), dev_blocks.ctypes.data, n_search, h_peaks.ctypes.data,
                                        h_keys.ctypes.data)
             assert rc == 0
         pcie = reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
@@ -277,10 +288,12 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u1 (bit planes; u32 popcount accumulators)",
-            "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11)",
+            "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11; "
+                    f"{'4092-byte 2-bit' if two_bit else '2046-byte 1-bit'} blocks)",
             "config": {
                 "workload": ("cold-start acquisition grid: 32 PRN x 21 Doppler (+-5 kHz @ 500 Hz) x 16368 code phases, "
-                             "1 ms coherent, 16.368 Msps 1-bit IF (BASELINE.json configs[2])") if n_ms == 1 else
+                             f"1 ms coherent, 16.368 Msps {'2-bit sign/magnitude' if two_bit else '1-bit'} IF "
+                             "(BASELINE.json configs[2])") if n_ms == 1 else
                             (f"32-PRN acquisition grid (21 Doppler x 16368 phases) with {n_ms} ms non-coherent integration "
                              "(BASELINE.json configs[3]); hypotheses counted per 1 ms block"),
                 "searches_per_gpu_per_step": args.searches,

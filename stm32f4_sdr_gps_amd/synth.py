@@ -185,11 +185,11 @@ def four_sv_with_lnav(n_ms: int, seed: int = 7) -> np.ndarray:
     return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
 
 
-def cold_start_block(n_ms: int = 1, seed: int = 11, amp_scale: float = 1.0) -> np.ndarray:
+def cold_start_block(n_ms: int = 1, seed: int = 11, amp_scale: float = 1.0, two_bit: bool = False) -> np.ndarray:
     """Config 3/4 input: six satellites in view.  amp_scale = 1 gives the strong test signal
     (amplitudes 0.5-0.6 against U(-1, 1) noise, i.e. well above a real sky, so that single-millisecond peaks are
     unmistakable); amp_scale ~ 0.25 is closer to a live antenna (each satellite below the noise)."""
     base = [(3, -3210.0, 777.0, 0.5, 0.7), (5, 912.5, 1600.0, 0.6, 0.3), (11, 4480.0, 12001.0, 0.5, 5.1),
             (14, 4037.0, 4000.0, 0.6, 1.1), (20, -1025.0, 9000.0, 0.6, 2.5), (30, 2018.0, 13000.0, 0.6, 4.0)]
     sats = [Sat(p, f, d, a * amp_scale, ph) for (p, f, d, a, ph) in base]
-    return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+    return make_if(n_ms, sats, noise_amp=1.0, seed=seed, two_bit=two_bit)   # same samples either way: same sign plane
