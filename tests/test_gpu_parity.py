@@ -690,9 +690,45 @@ def test_alternative_grid_kernels_match_the_default(eng, stream, algo, monkeypat
         prns = np.array([1, 5, 7, 14, 20, 25, 30, 31, 32, 3, 12], np.uint8)
         for kw in (dict(n_search=2, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21),
                    dict(n_search=1, dopp_min_hz=-6000, dopp_step_hz=250, n_dopp=45, win=(100, 1901)),
-                   dict(n_search=1, dopp_min_hz=-12000, dopp_step_hz=4000, n_dopp=7, win=(0, 3))):
-            want_pk, want_keys = eng.acq_grid(stream[:2], prns, **kw)
-            pk, keys = alt.acq_grid(stream[:2], prns, **kw)
+                   dict(n_search=1, dopp_min_hz=-12000, dopp_step_hz=4000, n_dopp=7, win=(0, 3)),
+                   dict(n_search=2, n_ms=3, search_stride_blocks=2, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)):
+            want_pk, want_keys = eng.acq_grid(stream[:5], prns, **kw)
+            pk, keys = alt.acq_grid(stream[:5], prns, **kw)
             assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys), (algo, kw)
     finally:
         alt.close()
+
+
+def test_bench_size_batch_equals_single_capture_launches_and_finds_the_satellites():
+    """BASELINE.json configs[2] at the size bench.py runs it (64 captures x 32 PRN x 21 Doppler x 16368 phases, 2-bit IF),
+    through properties that do not need the oracle at that size: every capture of the batch gets exactly the triplets
+    and keys it gets when launched alone (the batch runs the one-workgroup-per-chip form, a single capture the split
+    form with global atomics + k_acq_finalize), and in at least 52 of the 64 captures the strongest hypothesis of each
+    present PRN sits on that satellite's Doppler bin and, to two samples, on its code phase."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    e = capi.Engine(0)
+    try:
+        n = 64
+        blocks2 = synth.cold_start_block(n, seed=11, amp_scale=1.0, two_bit=True)
+        e.set_if_format(capi.IF_2BIT_SM)
+        prns = np.arange(1, 33, dtype=np.uint8)
+        kw = dict(dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
+        pk, keys = e.acq_grid(blocks2, prns, n_search=n, **kw)
+        for i in (0, 1, 17, 40, 63):
+            pk1, keys1 = e.acq_grid(blocks2[i:i + 1], prns, n_search=1, **kw)
+            assert np.array_equal(pk1[0], pk[i]) and np.array_equal(keys1[0], keys[i]), i
+        # (PRN, Doppler Hz, delay in samples) of synth.cold_start_block; code phase = samples into the block at which the
+        # code starts = delay mod 16368 (the stream is continuous: every capture sees the same alignment)
+        for prn, dopp, delay in ((3, -3210.0, 777.0), (5, 912.5, 1600.0), (11, 4480.0, 12001.0), (14, 4037.0, 4000.0),
+                                 (20, -1025.0, 9000.0), (30, 2018.0, 13000.0)):
+            k = keys[:, prn - 1, :]                                   # [capture, Doppler bin]
+            best_bin = np.argmax(k, axis=1)
+            fine = 16383 - (k[np.arange(n), best_bin] & 16383)        # 8 * byte offset + bit shift = sample offset
+            err = (fine.astype(np.int64) - int(delay) + 8184) % 16368 - 8184
+            # (not every capture: the reference's one-sided clip, quirk Q4, blanks a satellite whenever its carrier phase
+            #  puts I or Q negative over the millisecond, and a neighbouring bin or a noise peak then wins)
+            hit = (np.abs(best_bin - (dopp + 5000) / 500) <= 1.6) & (np.abs(err) <= 2)
+            assert hit.sum() >= 52, (prn, int(hit.sum()))
+            assert np.all((k[np.arange(n), best_bin] >> 14)[hit] > 400), prn
+    finally:
+        e.close()
