@@ -77,7 +77,15 @@ __device__ __forceinline__ int mag8_fast(int cnt_i, int cnt_q)
   int q = cnt_q - kHalf;
   i = i < 0 ? 0 : i;
   q = q < 0 ? 0 : q;
-  const float e = (float)__umul24((u32)i, (u32)i) + (float)__umul24((u32)q, (u32)q);
+  const u32 ii = __umul24((u32)i, (u32)i), qq = __umul24((u32)q, (u32)q);
+  // Whole wave below radius 1024 (the usual case: noise hypotheses sit at a few hundred): e = ii + qq < 2^20 is exact in
+  // float, sqrtf(e) truncates to isqrt(e), and isqrt(e) = trunc(s) for ANY s within 1 ulp of sqrt(e + 1/2): the true
+  // root of n^2 + r + 1/2 (0 <= r <= 2 n) keeps 1 / (4 (n + 1)) >= 2.4e-4 away from both integers around it, one ulp
+  // below 1024 is 1.2e-4 at most.  So the bare v_sqrt_f32 does, with no fix-up.  (gpsx_mag8 checks both paths against
+  // the generic one; tests/test_gpu_parity.py sweeps every pair of this domain.)
+  if (__builtin_amdgcn_ballot_w64((ii + qq) >= (1u << 20)) == 0)
+    return (int)__builtin_amdgcn_sqrtf((float)(ii + qq) + 0.5f);
+  const float e = (float)ii + (float)qq;
   float r = __builtin_amdgcn_sqrtf(e);
   const float r_dn = __uint_as_float(__float_as_uint(r) - 1u);
   const float r_up = __uint_as_float(__float_as_uint(r) + 1u);
@@ -127,6 +135,34 @@ __device__ __forceinline__ u32 wave_sum_u32(u32 v)
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1)
     v += (u32)__shfl_xor((int)v, m, 64);
+  return v;
+}
+
+// wave64 reductions on the DPP network (6 VALU ops each); the result is valid in lane 63
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ u32 dpp(u32 old, u32 v)
+{
+  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ u32 wave_max_to_lane63(u32 v)
+{
+  u32 o;
+  o = dpp<0xB1>(v, v); v = o > v ? o : v;            // quad_perm [1,0,3,2]
+  o = dpp<0x4E>(v, v); v = o > v ? o : v;            // quad_perm [2,3,0,1]
+  o = dpp<0x141>(v, v); v = o > v ? o : v;           // row_half_mirror
+  o = dpp<0x140>(v, v); v = o > v ? o : v;           // row_mirror: every lane holds its row's maximum
+  o = dpp<0x142, 0xA>(v, v); v = o > v ? o : v;      // row_bcast15 into rows 1, 3
+  o = dpp<0x143, 0xC>(v, v); v = o > v ? o : v;      // row_bcast31 into rows 2, 3
+  return v;
+}
+__device__ __forceinline__ u32 wave_sum_to_lane63(u32 v)
+{
+  v += dpp<0xB1>(0u, v);
+  v += dpp<0x4E>(0u, v);
+  v += dpp<0x141>(0u, v);
+  v += dpp<0x140>(0u, v);
+  v += dpp<0x142, 0xA>(0u, v);   // rows 1, 3 += lane 15 of the row before (masked rows read the old value, 0)
+  v += dpp<0x143, 0xC>(0u, v);   // rows 2, 3 += lane 31
   return v;
 }
 

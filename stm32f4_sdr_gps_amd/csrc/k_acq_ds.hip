@@ -166,33 +166,6 @@ __device__ __forceinline__ u32 cc_bits32(const u32 *cb, int s)
   return v;
 }
 
-// wave64 reductions on the DPP network (6 VALU ops each); the result is valid in lane 63
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ u32 dpp(u32 old, u32 v)
-{
-  return (u32)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ u32 wave_max_to_lane63(u32 v)
-{
-  u32 o;
-  o = dpp<0xB1>(v, v); v = o > v ? o : v;            // quad_perm [1,0,3,2]
-  o = dpp<0x4E>(v, v); v = o > v ? o : v;            // quad_perm [2,3,0,1]
-  o = dpp<0x141>(v, v); v = o > v ? o : v;           // row_half_mirror
-  o = dpp<0x140>(v, v); v = o > v ? o : v;           // row_mirror: every lane holds its row's maximum
-  o = dpp<0x142, 0xA>(v, v); v = o > v ? o : v;      // row_bcast15 into rows 1, 3
-  o = dpp<0x143, 0xC>(v, v); v = o > v ? o : v;      // row_bcast31 into rows 2, 3
-  return v;
-}
-__device__ __forceinline__ u32 wave_sum_to_lane63(u32 v)
-{
-  v += dpp<0xB1>(0u, v);
-  v += dpp<0x4E>(0u, v);
-  v += dpp<0x141>(0u, v);
-  v += dpp<0x140>(0u, v);
-  v += dpp<0x142, 0xA>(0u, v);   // rows 1, 3 += lane 15 of the row before (masked rows read the old value, 0)
-  v += dpp<0x143, 0xC>(0u, v);   // rows 2, 3 += lane 31
-  return v;
-}
 // value of lane + 1 (lane 63 keeps its own)
 __device__ __forceinline__ int from_next_lane(int v) { return (int)dpp<0x130>((u32)v, (u32)v); }   // wave_shl:1
 

@@ -170,9 +170,9 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
   // global atomics (k_acq_finalize converts the planes afterwards).
 #pragma unroll
   for (int p = 0; p < G; p++) {
-    const u32 k = wave_max_u32(best[p]);
-    const u32 t = wave_sum_u32(total[p]);
-    if (lane == 0 && p < n_valid) {
+    const u32 k = wave_max_to_lane63(best[p]);   // DPP network: 6 ops each, against 6 LDS permutes + 6 ops
+    const u32 t = wave_sum_to_lane63(total[p]);
+    if (lane == 63 && p < n_valid) {
       if (SEG == 16) {
         atomicMax(&sh.part[b][p][0], k);
         atomicAdd(&sh.part[b][p][1], t);

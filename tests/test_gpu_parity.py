@@ -153,6 +153,17 @@ def test_mag8_sqrt_is_correctly_rounded_everywhere_it_matters(eng):
             ok = (i <= 8184) & (q >= 0) & (q <= 8184)
             sets.append((8184 + i[ok], 8184 + q[ok]))
     sets.append((rng.integers(8184, 16369, 2_000_000), rng.integers(8184, 16369, 2_000_000)))
+    # the grid kernels' small-radius shortcut (whole wave below radius 1024: bare v_sqrt_f32 of e + 1/2): EVERY pair of
+    # that domain, in an order that keeps waves inside it, plus the same pairs interleaved with large ones (mixed waves
+    # must take the general path)
+    ii, qq = np.meshgrid(np.arange(1024, dtype=np.int64), np.arange(1024, dtype=np.int64), indexing="ij")
+    small = (ii * ii + qq * qq) < (1 << 20)
+    si, sq = 8184 + ii[small], 8184 + qq[small]
+    sets.append((si, sq))
+    mixed_i, mixed_q = si.copy(), sq.copy()
+    mixed_i[::7] = 16368 - (mixed_i[::7] - 8184) % 5000
+    sets.append((mixed_i, mixed_q))
+    sets.append((8184 - ii[small], sq))                       # negative I: clipped to zero
     for ci, cq in sets:
         got = eng.mag8(ci, cq)
         assert np.array_equal(got, want(ci, cq))
