@@ -71,6 +71,7 @@ __device__ __forceinline__ int mag8(int cnt_i, int cnt_q)
 //    correctly rounded root: with r- / r+ the floats next to r, pick r- if e - r-*r <= 0, r+ if e - r+*r > 0 (fused
 //    residuals are exact enough to decide, this is the fix-up LLVM itself emits for a correctly rounded f32 sqrt).
 //    e == 0: r = 0, r- is a NaN pattern, both tests fail, r stays 0.
+template <bool SHORTCUT = true>
 __device__ __forceinline__ int mag8_fast(int cnt_i, int cnt_q)
 {
   int i = cnt_i - kHalf;
@@ -83,7 +84,7 @@ __device__ __forceinline__ int mag8_fast(int cnt_i, int cnt_q)
   // root of n^2 + r + 1/2 (0 <= r <= 2 n) keeps 1 / (4 (n + 1)) >= 2.4e-4 away from both integers around it, one ulp
   // below 1024 is 1.2e-4 at most.  So the bare v_sqrt_f32 does, with no fix-up.  (gpsx_mag8 checks both paths against
   // the generic one; tests/test_gpu_parity.py sweeps every pair of this domain.)
-  if (__builtin_amdgcn_ballot_w64((ii + qq) >= (1u << 20)) == 0)
+  if (SHORTCUT && __builtin_amdgcn_ballot_w64((ii + qq) >= (1u << 20)) == 0)
     return (int)__builtin_amdgcn_sqrtf((float)(ii + qq) + 0.5f);
   const float e = (float)ii + (float)qq;
   float r = __builtin_amdgcn_sqrtf(e);

@@ -151,7 +151,7 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
         ci -= odd_tail ? (int)__popc(prev_i ^ r_last) : 0;
         cq -= odd_tail ? (int)__popc(prev_q ^ r_last) : 0;
       }
-      u32 val = in_win ? (u32)mag8_fast(ci, cq) : 0u;
+      u32 val = in_win ? (u32)mag8_fast<!MULTI>(ci, cq) : 0u;   // (MULTI: the shortcut's extra branch costs registers there)
       if (MULTI) {
         val += ms_first ? 0u : prev[MULTI ? p : 0];
         if (!ms_last)
