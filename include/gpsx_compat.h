@@ -144,8 +144,49 @@ typedef struct {
   uint8_t  new_subframe_flag;
   uint8_t  subframe_data[GPS_NAV_SUBFRAME_LENGTH_BYTES];   /* bit n of the subframe = bit (n & 7) of byte n >> 3 */
 } gps_nav_data_t;
-typedef struct { double opaque_[2]; }  gps_obs_data_t;
-typedef struct { double opaque_[40]; } sdreph_t;
+/* Observation of a channel (gps_misc.h:135-139); written by the pseudorange step, which this library does not have. */
+typedef struct {
+  double pseudorange_m;
+  double tow_s;
+} gps_obs_data_t;
+
+/* Broadcast ephemeris as the reference keeps it (gps_misc.h:141-182: RTKLIB's time and GPS ephemeris records inside
+ * GNSS-SDRLIB's per-channel wrapper), filled by gps_nav_data_decode_subframe from subframes 1-3. */
+#include <time.h>
+typedef struct {
+  time_t time;          /* s since the Unix epoch                                       */
+  double sec;           /* fraction of a second                                         */
+} gtime_t;
+typedef struct {
+  int     sat;          /* satellite (PRN)                                              */
+  int     iode, iodc;   /* issue of data, ephemeris / clock                             */
+  int     sva;          /* URA index                                                    */
+  int     svh;          /* health (0 = ok)                                              */
+  int     week;         /* GPS week, roll-over resolved                                 */
+  int     code;         /* codes on L2                                                  */
+  int     flag;         /* L2 P data flag                                               */
+  gtime_t toe, toc, ttr;
+  double  A, e, i0, OMG0, omg, M0, deln, OMGd, idot;      /* orbit: m, -, rad, rad/s    */
+  double  crc, crs, cuc, cus, cic, cis;                   /* harmonic corrections       */
+  double  toes;         /* toe, s of week                                               */
+  double  fit;          /* fit interval flag                                            */
+  double  f0, f1, f2;   /* clock polynomial                                             */
+  double  tgd[4];       /* tgd[0] = T_GD                                                */
+} eph_t;
+typedef struct {
+  eph_t    eph;
+  int      ctype;
+  double   tow_gpst;    /* time of week of the last decoded subframe's hand-over word   */
+  int      week_gpst;
+  int      cnt;         /* subframes 1-4 decoded                                        */
+  int      cntth;
+  int      update;
+  int      prn;
+  int      week_gst;
+  uint16_t sub_cnt;     /* subframes handed to the decoder                              */
+  uint8_t  received_mask;        /* bit n - 1: subframe n seen (cleared by the consumer) */
+  uint8_t  received_mask_proc;   /* the same, never cleared                             */
+} sdreph_t;
 
 typedef struct {
   gps_acq_t      acq_data;
@@ -223,8 +264,8 @@ void      gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data,
  *                                  and bit integration only, ending in gps_nav_data_words_detection
  *   gps_nav_data_words_detection   word layer (PM/GPS/nav_data.c:257-351): preamble search, parity, polarity detection,
  *                                  subframe assembly, ending in gps_nav_data_decode_subframe once per subframe
- *   gps_nav_data_decode_subframe   ephemeris decode (PM/GPS/nav_data_decode.c:34-52); default: returns the subframe ID
- *                                  from the hand-over word and decodes nothing (orbit data is out of scope) */
+ *   gps_nav_data_decode_subframe   ephemeris decode (PM/GPS/nav_data_decode.c:34-141): subframes 1-3 into
+ *                                  channel->eph_data (clock, orbit, times), 4-5 time of week only; returns the subframe ID */
 uint32_t signal_capture_get_packet_cnt(void);
 void     gps_nav_data_analyse_new_code(gps_ch_t *channel, uint8_t index, int16_t new_i);
 void     gps_nav_data_words_detection(gps_ch_t *channel, uint8_t new_bit);

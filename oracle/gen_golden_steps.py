@@ -106,3 +106,36 @@ def gen_lnav():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lnav":
     gen_lnav()
+
+
+def ephemeris_cases():
+    """Subframe images (38 bytes, bit n of the subframe = bit n & 7 of byte n >> 3) fed to gps_nav_data_decode_subframe one
+    after the other on ONE channel record (the decoder accumulates: subframe 2 uses subframe 1's week): random payloads
+    of every subframe ID incl. the IDs it ignores, all-ones and all-zeros fields."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    imgs = []
+    for rep in range(6):
+        for sub_id in (1, 2, 3, 4, 5, 0, 7, 3, 2, 1):
+            bits = rng.integers(0, 2, 304).astype(np.uint8)
+            if rep == 4:
+                bits[:] = 1
+            if rep == 5:
+                bits[:] = 0
+            bits[49:52] = [(sub_id >> 2) & 1, (sub_id >> 1) & 1, sub_id & 1]
+            imgs.append(np.packbits(bits, bitorder="little")[:38])
+    return np.array(imgs, np.uint8)
+
+
+def gen_ephemeris():
+    pyoracle.build_ref()
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_steps.so"))
+    imgs = ephemeris_cases()
+    ids, snaps = sd.run_ephemeris(lib, imgs)
+    path = os.path.join(ROOT, "tests", "golden", "f8_ephemeris.npz")
+    np.savez_compressed(path, imgs=imgs, ids=ids, snaps=snaps)
+    print("ephemeris", os.path.getsize(path), "bytes; ids", ids[:10], "eccentricity of case 1:",
+          snaps[1, 88:96].view("<f8")[0])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ephemeris":
+    gen_ephemeris()

@@ -24,6 +24,14 @@ static_assert(sizeof(gps_nav_data_t) == 112 && offsetof(gps_nav_data_t, inv_pola
                   offsetof(gps_nav_data_t, word_detection_timestamp) == 52 && offsetof(gps_nav_data_t, subframe_cnt) == 68 &&
                   offsetof(gps_nav_data_t, subframe_data) == 71,
               "gps_nav_data_t layout");
+static_assert(sizeof(gtime_t) == 16 && sizeof(eph_t) == 272 && offsetof(eph_t, toe) == 32 && offsetof(eph_t, A) == 80 &&
+                  offsetof(eph_t, crc) == 152 && offsetof(eph_t, toes) == 200 && offsetof(eph_t, f0) == 216 &&
+                  offsetof(eph_t, tgd) == 240,
+              "eph_t layout");
+static_assert(sizeof(sdreph_t) == 320 && offsetof(sdreph_t, tow_gpst) == 280 && offsetof(sdreph_t, cnt) == 292 &&
+                  offsetof(sdreph_t, sub_cnt) == 312 && offsetof(sdreph_t, received_mask) == 314 &&
+                  sizeof(gps_obs_data_t) == 16,
+              "sdreph_t layout");
 static_assert(offsetof(gps_ch_t, obs_data) == 328 && offsetof(gps_ch_t, eph_data) == 344, "gps_ch_t layout");
 static_assert(offsetof(gps_ch_t, prn) == 664 && offsetof(gps_ch_t, prn_code) == 665 && sizeof(gps_ch_t) == 1688,
               "gps_ch_t layout");

@@ -680,15 +680,6 @@ void stamp_subframe(gps_nav_data_t &n)
 
 }  // namespace
 
-__attribute__((weak)) uint8_t gps_nav_data_decode_subframe(gps_ch_t *channel)
-{
-  const uint8_t *sf = channel->nav_data.subframe_data;   // hand-over word, bits 20-22 = subframe bits 49..51, MSB first
-  uint8_t id = 0;
-  for (int bit = 49; bit < 52; bit++)
-    id = (uint8_t)((id << 1) | ((sf[bit >> 3] >> (bit & 7)) & 1u));
-  return id;
-}
-
 __attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *channel, uint8_t new_bit)
 {
   gps_nav_data_t &n = channel->nav_data;

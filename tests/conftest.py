@@ -37,3 +37,10 @@ def ref_pm():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def lib_path():
+    """Path of the built product library (hipcc cross-compiles without a GPU)."""
+    from stm32f4_sdr_gps_amd import build
+    return build.build()

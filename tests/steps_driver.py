@@ -13,7 +13,7 @@ import numpy as np
 CH_SIZE = 1688          # sizeof(gps_ch_t) on LP64 (tests/test_abi_and_host.py checks the layout against the reference)
 N_CH = 4
 SNAP = 226              # acq_data (60) + tracking_data (152) + first 14 bytes of nav_data
-SNAP_FULL = 324         # ... + the whole of nav_data (112 bytes): word layer, polarity, subframe image and time stamp
+SNAP_FULL = 664         # ... + all of nav_data (word layer, polarity, subframe image, time stamp), obs_data, eph_data
 CHECKPOINT_MS = 500
 
 ACQ_DTYPE = np.dtype({"names": ["freq_index", "found_freq_offset_hz", "given_freq_offset_hz", "found_code_phase",
@@ -102,7 +102,7 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int,
     interrupt would, fetched back with signal_capture_get_copy_buf (acquisition, PM/main.c:106-125,163-168) or
     signal_capture_get_ready_buf (tracking, PM/main.c:134-137) -- instead of being handed over as numpy buffers.
 
-    digest: long runs -- instead of every snapshot, returns (crc[n_ms] of the 4 x 324-byte state after each millisecond,
+    digest: long runs -- instead of every snapshot, returns (crc[n_ms] of the 4 x 664-byte state after each millisecond,
     full states every CHECKPOINT_MS, the final state), nav_data included in full."""
     lib = steps.lib
     if via_capture:
@@ -201,3 +201,19 @@ def summarize(snaps):
                          code_phase_fine=float(t[80:84].view("<f4")[0]), freq=float(t[4:8].view("<f4")[0]),
                          snr=float(t[132:136].view("<f4")[0]), bit_sync=int(last[i, 212])))
     return rows
+
+
+def run_ephemeris(lib: C.CDLL, imgs: np.ndarray, prn: int = 7):
+    """Feed 38-byte subframe images to gps_nav_data_decode_subframe one after the other on ONE channel record (the decoder
+    accumulates); returns the IDs it reported and the 320 bytes of eph_data after each call.  Host code in both libraries."""
+    lib.gps_nav_data_decode_subframe.argtypes = [C.c_void_p]
+    lib.gps_nav_data_decode_subframe.restype = C.c_uint8
+    ch = np.zeros(CH_SIZE, np.uint8)
+    ch[664] = prn
+    ids = np.zeros(len(imgs), np.uint8)
+    snaps = np.zeros((len(imgs), 320), np.uint8)
+    for i, img in enumerate(imgs):
+        ch[212 + 71:212 + 71 + 38] = img
+        ids[i] = lib.gps_nav_data_decode_subframe(ch.ctypes.data)
+        snaps[i] = ch[344:664]
+    return ids, snaps

@@ -11,12 +11,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib_path():
-    from stm32f4_sdr_gps_amd import build
-    return build.build()
-
-
 def _declared_functions(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)

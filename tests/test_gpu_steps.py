@@ -79,8 +79,8 @@ def test_word_layer_on_lnav_subframes_matches_reference(gpsx_lib):
     """15 s of the 4-SV table carrying parity-correct LNAV subframes (two satellites with inverted data polarity):
     preamble search, parity, polarity detection, subframe assembly and time stamp (PM/GPS/nav_data.c:257-451) on top of
     the GPU correlators must leave every channel in exactly the reference's state after every millisecond --
-    tests/golden/f7_steps_lnav.npz holds a CRC of acq_data + tracking_data + ALL of nav_data per millisecond, the full
-    state every 500 ms and the final state (oracle/gen_golden_steps.py lnav)."""
+    tests/golden/f7_steps_lnav.npz holds a CRC of acq_data + tracking_data + nav_data + obs_data + eph_data (the decoded
+    ephemeris) per millisecond, the full state every 500 ms and the final state (oracle/gen_golden_steps.py lnav)."""
     from stm32f4_sdr_gps_amd import synth
     g = load("f7_steps_lnav.npz")
     n_ms = int(g["n_ms"])
@@ -96,6 +96,7 @@ def test_word_layer_on_lnav_subframes_matches_reference(gpsx_lib):
                              f"{tuple(int(x) for x in cp[0]) if len(cp) else None}")
     assert np.array_equal(checkpoints, g["checkpoints"]) and np.array_equal(final, g["final"])
     nav = final[:, 212:324]
+    assert final[0, 344 + 312:344 + 314].view("<u2")[0] == 1 and final[0, 344 + 315] == 2   # PRN 5: ephemeris decoder ran on a subframe 2
     assert int(nav[0, 68:70].view("<u2")[0]) == 1 and nav[0, 14] == 1          # PRN 5: a whole subframe, polarity known
     assert nav[3, 13] == 1 and nav[3, 14] == 1                                  # PRN 30: inverted polarity found and confirmed
     assert int(nav[0, 60:64].view("<u4")[0]) == 11260                           # the subframe's bit-edge time stamp
