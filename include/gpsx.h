@@ -187,6 +187,18 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
 static inline uint32_t gpsx_key_energy(int64_t key) { return (uint32_t)(key >> 14); }
 static inline uint32_t gpsx_key_fine_phase(int64_t key) { return 16383u - (uint32_t)(key & 16383); }
 
+/* ---- the sharded sweep inside ONE process (a C host has no torch.distributed): a group of contexts, one per GPU,
+ *      joined by RCCL communicators (ncclCommInitAll; librccl is loaded when the first group is created).
+ *      gpsx_acq_grid_sharded = what each rank of `bench.py --gpus N` does, for all the group's devices at once:
+ *      context i sweeps the grid units with unit % n == i (g's own shard fields are ignored) on its own copy of the
+ *      captures, then ONE all-reduce(MAX) of the packed keys leaves the merged table in every d_keys[i].  Everything is
+ *      enqueued on the contexts' streams; synchronize the contexts (or read through gpsx_memcpy_d2h) before using it. */
+typedef struct gpsx_group gpsx_group;
+int  gpsx_group_create(gpsx_ctx *const *ctxs, int n, gpsx_group **group);   /* n >= 1 contexts on n DIFFERENT devices */
+void gpsx_group_destroy(gpsx_group *group);
+int  gpsx_acq_grid_sharded(gpsx_group *group, const gpsx_acq_grid_t *g, const void *const *d_if_blocks, int n_blocks,
+                           gpsx_peak_t *const *d_peaks, int64_t *const *d_keys);
+
 /* ---- K2+K3+K5: Early/Prompt/Late tracking correlators  (replaces the correlator part of
  *      gps_tracking_data_process, PM/GPS/tracking.c:115-138, for n_ch channels at once) ------------------------- */
 

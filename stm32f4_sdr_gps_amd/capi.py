@@ -83,6 +83,12 @@ def load_library() -> C.CDLL:
     lib.gpsx_if_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gpsx_mag8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
+    # in-process multi-GPU group
+    lib.gpsx_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+    lib.gpsx_group_destroy.argtypes = [C.c_void_p]
+    lib.gpsx_group_destroy.restype = None
+    lib.gpsx_acq_grid_sharded.argtypes = [C.c_void_p, C.POINTER(AcqGrid), C.POINTER(C.c_void_p), C.c_int,
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     # capture ring (IF ingest)
     lib.gpsx_capture_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.gpsx_capture_destroy.argtypes = [C.c_void_p]

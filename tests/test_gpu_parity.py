@@ -743,3 +743,37 @@ def test_bench_size_batch_equals_single_capture_launches_and_finds_the_satellite
             assert np.all((k[np.arange(n), best_bin] >> 14)[hit] > 400), prn
     finally:
         e.close()
+
+
+def test_in_process_group_sharded_sweep_over_rccl(eng, stream):
+    """gpsx_group_* / gpsx_acq_grid_sharded: the C host's multi-GPU sweep (RCCL communicators inside one process).  One
+    GPU here, so a group of one: the launch with shard (0, 1) followed by a real ncclAllReduce(MAX) over a 1-rank
+    communicator must give the plain sweep's keys; two contexts on one device are refused."""
+    from stm32f4_sdr_gps_amd import capi
+    lib = eng.lib
+    prns = np.array([5, 14, 20, 30, 1, 2, 3], np.uint8)
+    kw = dict(n_search=2, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
+    want_pk, want_keys = eng.acq_grid(stream[:2], prns, **kw)
+    g = eng.grid_desc(prns, **kw)
+    n_pk, n_keys = want_pk.size, want_keys.size
+    d_if, d_pk, d_keys = eng.malloc(2 * 2046 + 2), eng.malloc(n_pk * 16), eng.malloc(n_keys * 8)
+    eng.h2d(d_if, np.concatenate([stream[:2].reshape(-1), np.zeros(2, np.uint8)]))
+    grp = C.c_void_p()
+    ctxs = (C.c_void_p * 1)(eng.h)
+    eng._chk(lib.gpsx_group_create(ctxs, 1, C.byref(grp)), "gpsx_group_create")
+    try:
+        ifs, pks, ks = (C.c_void_p * 1)(d_if), (C.c_void_p * 1)(d_pk), (C.c_void_p * 1)(d_keys)
+        eng._chk(lib.gpsx_acq_grid_sharded(grp, C.byref(g), ifs, 2, pks, ks), "gpsx_acq_grid_sharded")
+        keys = np.zeros_like(want_keys)
+        pk = np.zeros_like(want_pk)
+        eng.d2h(keys, d_keys)
+        eng.d2h(pk, d_pk)
+        assert np.array_equal(keys, want_keys) and np.array_equal(pk, want_pk)
+    finally:
+        lib.gpsx_group_destroy(grp)
+    other = capi.Engine(0)
+    try:
+        two = (C.c_void_p * 2)(eng.h, other.h)
+        assert lib.gpsx_group_create(two, 2, C.byref(grp)) == -22
+    finally:
+        other.close()
