@@ -2,8 +2,6 @@
 // Host code only; every computation named in the header happens in the kernels of k_*.hip.  No CPU fallback.
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
-
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -12,149 +10,12 @@
 #include <string>
 #include <vector>
 
-#include "gpsx_kernels.hpp"
+#include "gpsx_ctx.hpp"
 
 using namespace gpsx;
-
-// IF ingest ring (include/gpsx.h "capture ring"): pinned host slots + HBM mirror.  Blocks are 2 KB: their copies go on the
-// context's own stream (measured: a separate copy stream costs two more events per block than it can ever win back),
-// so readers enqueued later need no synchronisation object at all; one event per slot tells the producer when a slot's
-// pinned bytes have left.
-struct gpsx_capture {
-  gpsx_ctx *ctx = nullptr;
-  int n_slots = 0;
-  size_t block_bytes = 0;
-  uint8_t *h_ring = nullptr;           // [n_slots][block_bytes], hipHostMalloc
-  uint8_t *d_ring = nullptr;           // [n_slots][block_bytes] + 2
-  uint8_t *d_window = nullptr;         // [n_slots][block_bytes] + 2: windows that wrap are gathered here
-  std::vector<hipEvent_t> sent;        // per slot: its host bytes have been read by the copy engine
-  std::vector<uint8_t> mirrored;       // per slot: HBM mirror matches the host slot (cleared when handed out for writing)
-  int write_slot = 0;
-  int ready_slot = -1;
-  uint32_t packet_cnt = 0;
-};
-
-struct gpsx_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  std::string err;
-  hipDeviceProp_t prop;
-
-  // tables for every PRN, slot == prn (slot 0 is the empty code): K1 output
-  uint8_t *d_chips_all = nullptr;    // [211][1024]
-  uint32_t *d_bits_all = nullptr;    // [211][32]
-  uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
-  uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
-  int if_format = GPSX_IF_1BIT;
-  int algo = kAlgoPoly;              // $GPSX_ACQ_ALGO = poly (default) | dot8 | sad, for A/B measurements
-  uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
-  size_t acc_entries = 0;
-  uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
-  size_t energy_bytes = 0;
-  // Doppler-shared kernel: boundary tables of the last Doppler grid, per-(search, Doppler) prepared data (grow-only)
-  int ds_grid[3] = {0, 0, 0};        // dopp_min_hz, dopp_step_hz, n_dopp the tables were built for
-  bool ds_ok = false;
-  uint32_t *d_ds_tables = nullptr;
-  size_t ds_rows_off = 0, ds_cst0_off = 0;
-  uint32_t *d_ds_work = nullptr;
-  size_t ds_work_dwords = 0;
-
-  // grouped tables for the PRN list of the last grid call
-  std::vector<uint8_t> grid_prns;
-  int grid_slots = 0;
-  uint8_t *d_grid_prns = nullptr;
-  uint8_t *d_grid_chips = nullptr;
-  uint32_t *d_grid_bits = nullptr;
-  uint32_t *d_grid_cw = nullptr;
-  uint32_t *d_grid_cw8 = nullptr;
-
-  std::vector<gpsx_capture *> captures;   // IF ingest rings opened on this context
-
-  // grow-only scratch arena for the host-pointer entry points
-  char *d_arena = nullptr;
-  size_t arena_bytes = 0;
-  size_t arena_used = 0;
-};
+using namespace gpsx_host;
 
 namespace {
-
-int fail(gpsx_ctx *ctx, int code, const std::string &msg)
-{
-  if (ctx)
-    ctx->err = msg;
-  return code;
-}
-
-#define HIPCHK(ctx, call)                                                                        \
-  do {                                                                                           \
-    hipError_t e_ = (call);                                                                      \
-    if (e_ != hipSuccess)                                                                        \
-      return fail((ctx), GPSX_EIO, std::string(#call) + ": " + hipGetErrorString(e_));          \
-  } while (0)
-
-#define LAUNCHCHK(ctx, what)                                                                     \
-  do {                                                                                           \
-    hipError_t e_ = hipGetLastError();                                                           \
-    if (e_ != hipSuccess)                                                                        \
-      return fail((ctx), GPSX_EIO, std::string(what) + " launch: " + hipGetErrorString(e_));     \
-  } while (0)
-
-int arena_reset(gpsx_ctx *ctx, size_t need)
-{
-  ctx->arena_used = 0;
-  if (need <= ctx->arena_bytes)
-    return GPSX_OK;
-  if (ctx->d_arena) {
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipFree(ctx->d_arena));
-    ctx->d_arena = nullptr;
-    ctx->arena_bytes = 0;
-  }
-  const size_t want = std::max(need, (size_t)1 << 20);
-  if (hipMalloc((void **)&ctx->d_arena, want) != hipSuccess)
-    return fail(ctx, GPSX_ENOMEM, "hipMalloc(arena) failed");
-  ctx->arena_bytes = want;
-  return GPSX_OK;
-}
-
-template <typename T>
-T *arena_take(gpsx_ctx *ctx, size_t count)
-{
-  const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
-  T *p = reinterpret_cast<T *>(ctx->d_arena + ctx->arena_used);
-  ctx->arena_used += bytes;
-  return p;
-}
-
-size_t arena_size(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
-
-int use_device(gpsx_ctx *ctx)
-{
-  if (!ctx)
-    return GPSX_EINVAL;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  return GPSX_OK;
-}
-
-// A host pointer that lies in a committed, unmodified part of one of the context's capture rings has an HBM mirror:
-// returns the mirror (and makes the compute stream wait for the ring's copies), or nullptr -> the caller copies.
-const uint8_t *capture_mirror(gpsx_ctx *ctx, const uint8_t *host, size_t bytes)
-{
-  for (gpsx_capture *cap : ctx->captures) {
-    const size_t ring_bytes = (size_t)cap->n_slots * cap->block_bytes;
-    if (host < cap->h_ring || host >= cap->h_ring + ring_bytes || bytes == 0 || bytes > ring_bytes)
-      continue;
-    const size_t off = (size_t)(host - cap->h_ring);
-    if (off % cap->block_bytes || bytes % cap->block_bytes || off + bytes > ring_bytes)
-      return nullptr;
-    for (size_t slot = off / cap->block_bytes; slot < (off + bytes) / cap->block_bytes; slot++)
-      if (!cap->mirrored[slot])
-        return nullptr;
-    return cap->d_ring + off;   // the copies were enqueued on this very stream: ordered before any reader
-  }
-  return nullptr;
-}
 
 int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
 {
@@ -931,275 +792,3 @@ int gpsx_corr_search(gpsx_ctx *ctx, const uint16_t *replica, const uint16_t *dat
 }
 
 }  // extern "C"
-
-/* ---- IF ingest: capture ring ---------------------------------------------------------------------------------- */
-
-int gpsx_capture_create(gpsx_ctx *ctx, int n_slots, gpsx_capture **out)
-{
-  if (int rc = use_device(ctx)) return rc;
-  if (!out || n_slots < 1 || n_slots > 4096)
-    return fail(ctx, GPSX_EINVAL, "capture ring: 1 <= n_slots <= 4096");
-  gpsx_capture *cap = new (std::nothrow) gpsx_capture;
-  if (!cap)
-    return fail(ctx, GPSX_ENOMEM, "out of host memory");
-  cap->ctx = ctx;
-  cap->n_slots = n_slots;
-  cap->block_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
-  cap->mirrored.assign(n_slots, 0);
-  cap->sent.assign(n_slots, nullptr);
-  const size_t ring_bytes = (size_t)n_slots * cap->block_bytes;
-  bool ok = hipHostMalloc((void **)&cap->h_ring, ring_bytes, hipHostMallocDefault) == hipSuccess &&
-            hipMalloc((void **)&cap->d_ring, ring_bytes + 2) == hipSuccess &&
-            hipMalloc((void **)&cap->d_window, ring_bytes + 2) == hipSuccess &&
-            hipMemsetAsync(cap->d_ring, 0, ring_bytes + 2, ctx->stream) == hipSuccess &&
-            hipMemsetAsync(cap->d_window, 0, ring_bytes + 2, ctx->stream) == hipSuccess;
-  for (int i = 0; ok && i < n_slots; i++)
-    ok = hipEventCreateWithFlags(&cap->sent[i], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
-  ctx->captures.push_back(cap);
-  if (!ok) {
-    const hipError_t e = hipGetLastError();
-    gpsx_capture_destroy(cap);
-    return fail(ctx, GPSX_ENOMEM, std::string("capture ring allocation: ") + hipGetErrorString(e));
-  }
-  std::memset(cap->h_ring, 0, ring_bytes);
-  *out = cap;
-  return GPSX_OK;
-}
-
-void gpsx_capture_destroy(gpsx_capture *cap)
-{
-  if (!cap)
-    return;
-  gpsx_ctx *ctx = cap->ctx;
-  (void)hipSetDevice(ctx->device);
-  if (ctx->stream)
-    (void)hipStreamSynchronize(ctx->stream);   // pending copies, and launches that read the mirror
-  ctx->captures.erase(std::remove(ctx->captures.begin(), ctx->captures.end(), cap), ctx->captures.end());
-  for (hipEvent_t e : cap->sent)
-    if (e) (void)hipEventDestroy(e);
-  if (cap->d_ring) (void)hipFree(cap->d_ring);
-  if (cap->d_window) (void)hipFree(cap->d_window);
-  if (cap->h_ring) (void)hipHostFree(cap->h_ring);
-  delete cap;
-}
-
-uint8_t *gpsx_capture_write_slot(gpsx_capture *cap)
-{
-  if (!cap)
-    return nullptr;
-  if (cap->mirrored[cap->write_slot]) {
-    // the slot's previous block may not have left the pinned buffer yet: the producer must not overwrite it
-    (void)hipSetDevice(cap->ctx->device);
-    (void)hipEventSynchronize(cap->sent[cap->write_slot]);
-    cap->mirrored[cap->write_slot] = 0;
-  }
-  return cap->h_ring + (size_t)cap->write_slot * cap->block_bytes;
-}
-
-int gpsx_capture_commit(gpsx_capture *cap)
-{
-  if (!cap)
-    return GPSX_EINVAL;
-  gpsx_ctx *ctx = cap->ctx;
-  if (int rc = use_device(ctx)) return rc;
-  const int slot = cap->write_slot;
-  // stream order does the rest: earlier launches that read this device slot finish first, later ones see the new block
-  HIPCHK(ctx, hipMemcpyAsync(cap->d_ring + (size_t)slot * cap->block_bytes, cap->h_ring + (size_t)slot * cap->block_bytes,
-                             cap->block_bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(cap->sent[slot], ctx->stream));
-  cap->mirrored[slot] = 1;
-  cap->ready_slot = slot;
-  cap->write_slot = (slot + 1) % cap->n_slots;
-  cap->packet_cnt++;
-  return GPSX_OK;
-}
-
-int gpsx_capture_push(gpsx_capture *cap, const uint8_t *block)
-{
-  if (!cap || !block)
-    return GPSX_EINVAL;
-  std::memcpy(gpsx_capture_write_slot(cap), block, cap->block_bytes);
-  return gpsx_capture_commit(cap);
-}
-
-const uint8_t *gpsx_capture_ready_buf(const gpsx_capture *cap)
-{
-  return cap && cap->ready_slot >= 0 ? cap->h_ring + (size_t)cap->ready_slot * cap->block_bytes : nullptr;
-}
-
-int gpsx_capture_window_dev(gpsx_capture *cap, int n_blocks, const void **d_blocks)
-{
-  if (!cap || !d_blocks)
-    return GPSX_EINVAL;
-  gpsx_ctx *ctx = cap->ctx;
-  if (int rc = use_device(ctx)) return rc;
-  if (n_blocks < 1 || n_blocks > cap->n_slots || (uint32_t)n_blocks > cap->packet_cnt)
-    return fail(ctx, GPSX_EINVAL, "capture window: more blocks than the ring holds / has received");
-  const int first = (cap->ready_slot - (n_blocks - 1) + cap->n_slots) % cap->n_slots;   // oldest block of the window
-  if (first + n_blocks <= cap->n_slots) {
-    *d_blocks = cap->d_ring + (size_t)first * cap->block_bytes;
-    return GPSX_OK;
-  }
-  // the window wraps: gather its two pieces (device to device, on the stream) into the window buffer
-  const int head = cap->n_slots - first;
-  HIPCHK(ctx, hipMemcpyAsync(cap->d_window, cap->d_ring + (size_t)first * cap->block_bytes, (size_t)head * cap->block_bytes,
-                             hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(cap->d_window + (size_t)head * cap->block_bytes, cap->d_ring,
-                             (size_t)(n_blocks - head) * cap->block_bytes, hipMemcpyDeviceToDevice, ctx->stream));
-  *d_blocks = cap->d_window;
-  return GPSX_OK;
-}
-
-uint32_t gpsx_capture_packet_cnt(const gpsx_capture *cap) { return cap ? cap->packet_cnt : 0; }
-size_t gpsx_capture_block_bytes(const gpsx_capture *cap) { return cap ? cap->block_bytes : 0; }
-
-long gpsx_capture_replay_file(gpsx_capture *cap, const char *path, long first_block, long max_blocks,
-                              gpsx_capture_block_fn on_block, void *user)
-{
-  if (!cap || !path || first_block < 0)
-    return GPSX_EINVAL;
-  gpsx_ctx *ctx = cap->ctx;
-  std::FILE *f = std::fopen(path, "rb");
-  if (!f)
-    return fail(ctx, GPSX_EIO, std::string("cannot open ") + path);
-  long done = 0;
-  int rc = GPSX_OK;
-  if (fseeko(f, (off_t)first_block * (off_t)cap->block_bytes, SEEK_SET) != 0)
-    rc = fail(ctx, GPSX_EIO, "seek past the end of the IF file");
-  while (rc == GPSX_OK && (max_blocks < 0 || done < max_blocks)) {
-    uint8_t *slot = gpsx_capture_write_slot(cap);
-    if (std::fread(slot, 1, cap->block_bytes, f) != cap->block_bytes)
-      break;   // end of the recording (a trailing partial block is dropped, as a 1 ms DMA transfer would never complete)
-    rc = gpsx_capture_commit(cap);
-    if (rc != GPSX_OK)
-      break;
-    done++;
-    if (on_block && on_block(user, cap, first_block + done - 1) != 0)
-      break;
-  }
-  std::fclose(f);
-  return rc == GPSX_OK ? done : rc;
-}
-
-
-/* ---- multi-GPU group: RCCL inside one process ------------------------------------------------------------------- */
-
-namespace {
-
-// the handful of RCCL entry points used, resolved at run time so that libgpsx.so itself does not depend on librccl
-// (a process that drives the ranks through torch.distributed already carries its own copy)
-struct Rccl {
-  typedef void *comm_t;
-  int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
-  int (*CommDestroy)(comm_t) = nullptr;
-  int (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
-  static constexpr int kInt64 = 4, kMax = 2;   // ncclInt64, ncclMax (rccl.h)
-  bool ok = false;
-};
-
-Rccl &rccl()
-{
-  static Rccl r;
-  static bool tried = false;
-  if (tried)
-    return r;
-  tried = true;
-  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!h)
-    h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!h)
-    return r;
-  r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
-  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
-  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
-  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
-  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd && r.GetErrorString;
-  return r;
-}
-
-}  // namespace
-
-struct gpsx_group {
-  std::vector<gpsx_ctx *> ctxs;
-  std::vector<Rccl::comm_t> comms;
-};
-
-int gpsx_group_create(gpsx_ctx *const *ctxs, int n, gpsx_group **out)
-{
-  if (!ctxs || !out || n < 1 || n > 64)
-    return GPSX_EINVAL;
-  gpsx_ctx *c0 = ctxs[0];
-  std::vector<int> devs(n);
-  for (int i = 0; i < n; i++) {
-    if (!ctxs[i])
-      return GPSX_EINVAL;
-    devs[i] = ctxs[i]->device;
-    for (int j = 0; j < i; j++)
-      if (devs[j] == devs[i])
-        return fail(c0, GPSX_EINVAL, "group: two contexts on the same device (RCCL wants one rank per GPU)");
-  }
-  Rccl &r = rccl();
-  if (!r.ok)
-    return fail(c0, GPSX_EIO, "group: librccl.so could not be loaded");
-  gpsx_group *grp = new (std::nothrow) gpsx_group;
-  if (!grp)
-    return fail(c0, GPSX_ENOMEM, "out of host memory");
-  grp->ctxs.assign(ctxs, ctxs + n);
-  grp->comms.assign(n, nullptr);
-  const int rc = r.CommInitAll(grp->comms.data(), n, devs.data());
-  if (rc != 0) {
-    delete grp;
-    return fail(c0, GPSX_EIO, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
-  }
-  *out = grp;
-  return GPSX_OK;
-}
-
-void gpsx_group_destroy(gpsx_group *grp)
-{
-  if (!grp)
-    return;
-  for (size_t i = 0; i < grp->ctxs.size(); i++) {
-    (void)hipSetDevice(grp->ctxs[i]->device);
-    (void)hipStreamSynchronize(grp->ctxs[i]->stream);
-    if (grp->comms[i])
-      (void)rccl().CommDestroy(grp->comms[i]);
-  }
-  delete grp;
-}
-
-int gpsx_acq_grid_sharded(gpsx_group *grp, const gpsx_acq_grid_t *g, const void *const *d_if_blocks, int n_blocks,
-                          gpsx_peak_t *const *d_peaks, int64_t *const *d_keys)
-{
-  if (!grp || !g || !d_if_blocks || !d_peaks || !d_keys)
-    return GPSX_EINVAL;
-  const int n = (int)grp->ctxs.size();
-  gpsx_acq_grid_t gi = *g;
-  gi.shard_count = n;
-  for (int i = 0; i < n; i++) {
-    gi.shard_index = i;
-    if (!d_keys[i])
-      return fail(grp->ctxs[i], GPSX_EINVAL, "sharded sweep: the key table is what gets merged, it cannot be NULL");
-    if (int rc = gpsx_acq_grid_dev(grp->ctxs[i], &gi, d_if_blocks[i], n_blocks, d_peaks[i], d_keys[i], nullptr, nullptr,
-                                   nullptr))
-      return rc;
-  }
-  // the one exchange step of the path: max over ranks of (energy << 14 | 16383 - phase), entries of foreign units are 0
-  Rccl &r = rccl();
-  const size_t n_keys = gpsx_acq_keys_count(g);
-  int rc = r.GroupStart();
-  for (int i = 0; i < n && rc == 0; i++) {
-    (void)hipSetDevice(grp->ctxs[i]->device);
-    rc = r.AllReduce(d_keys[i], d_keys[i], n_keys, Rccl::kInt64, Rccl::kMax, grp->comms[i], grp->ctxs[i]->stream);
-  }
-  const int rc_end = r.GroupEnd();
-  if (rc != 0 || rc_end != 0)
-    return fail(grp->ctxs[0], GPSX_EIO, std::string("ncclAllReduce: ") + r.GetErrorString(rc != 0 ? rc : rc_end));
-  return GPSX_OK;
-}

@@ -1,0 +1,138 @@
+// gpsx_ctx.hpp -- internals shared by the host-side translation units of libgpsx.so (gpsx_api.hip, gpsx_capture.hip,
+// gpsx_group.hip): the context record, the capture ring record, error plumbing, the scratch arena.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "gpsx_kernels.hpp"
+
+// IF ingest ring (include/gpsx.h "capture ring"): pinned host slots + HBM mirror.  Blocks are 2 KB: their copies go on the
+// context's own stream (measured: a separate copy stream costs two more events per block than it can ever win back),
+// so readers enqueued later need no synchronisation object at all; one event per slot tells the producer when a slot's
+// pinned bytes have left.
+struct gpsx_capture {
+  gpsx_ctx *ctx = nullptr;
+  int n_slots = 0;
+  size_t block_bytes = 0;
+  uint8_t *h_ring = nullptr;           // [n_slots][block_bytes], hipHostMalloc
+  uint8_t *d_ring = nullptr;           // [n_slots][block_bytes] + 2
+  uint8_t *d_window = nullptr;         // [n_slots][block_bytes] + 2: windows that wrap are gathered here
+  std::vector<hipEvent_t> sent;        // per slot: its host bytes have been read by the copy engine
+  std::vector<uint8_t> mirrored;       // per slot: HBM mirror matches the host slot (cleared when handed out for writing)
+  int write_slot = 0;
+  int ready_slot = -1;
+  uint32_t packet_cnt = 0;
+};
+
+struct gpsx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // tables for every PRN, slot == prn (slot 0 is the empty code): K1 output
+  uint8_t *d_chips_all = nullptr;    // [211][1024]
+  uint32_t *d_bits_all = nullptr;    // [211][32]
+  uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
+  uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
+  int if_format = GPSX_IF_1BIT;
+  int algo = gpsx::kAlgoPoly;              // $GPSX_ACQ_ALGO = poly (default) | dot8 | sad, for A/B measurements
+  uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
+  size_t acc_entries = 0;
+  uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
+  size_t energy_bytes = 0;
+  // Doppler-shared kernel: boundary tables of the last Doppler grid, per-(search, Doppler) prepared data (grow-only)
+  int ds_grid[3] = {0, 0, 0};        // dopp_min_hz, dopp_step_hz, n_dopp the tables were built for
+  bool ds_ok = false;
+  uint32_t *d_ds_tables = nullptr;
+  size_t ds_rows_off = 0, ds_cst0_off = 0;
+  uint32_t *d_ds_work = nullptr;
+  size_t ds_work_dwords = 0;
+
+  // grouped tables for the PRN list of the last grid call
+  std::vector<uint8_t> grid_prns;
+  int grid_slots = 0;
+  uint8_t *d_grid_prns = nullptr;
+  uint8_t *d_grid_chips = nullptr;
+  uint32_t *d_grid_bits = nullptr;
+  uint32_t *d_grid_cw = nullptr;
+  uint32_t *d_grid_cw8 = nullptr;
+
+  std::vector<gpsx_capture *> captures;   // IF ingest rings opened on this context
+
+  // grow-only scratch arena for the host-pointer entry points
+  char *d_arena = nullptr;
+  size_t arena_bytes = 0;
+  size_t arena_used = 0;
+};
+
+namespace gpsx_host {
+
+
+inline int fail(gpsx_ctx *ctx, int code, const std::string &msg)
+{
+  if (ctx)
+    ctx->err = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((ctx), GPSX_EIO, std::string(#call) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+#define LAUNCHCHK(ctx, what)                                                                     \
+  do {                                                                                           \
+    hipError_t e_ = hipGetLastError();                                                           \
+    if (e_ != hipSuccess)                                                                        \
+      return fail((ctx), GPSX_EIO, std::string(what) + " launch: " + hipGetErrorString(e_));     \
+  } while (0)
+
+inline int arena_reset(gpsx_ctx *ctx, size_t need)
+{
+  ctx->arena_used = 0;
+  if (need <= ctx->arena_bytes)
+    return GPSX_OK;
+  if (ctx->d_arena) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(ctx->d_arena));
+    ctx->d_arena = nullptr;
+    ctx->arena_bytes = 0;
+  }
+  const size_t want = std::max(need, (size_t)1 << 20);
+  if (hipMalloc((void **)&ctx->d_arena, want) != hipSuccess)
+    return fail(ctx, GPSX_ENOMEM, "hipMalloc(arena) failed");
+  ctx->arena_bytes = want;
+  return GPSX_OK;
+}
+
+template <typename T>
+inline T *arena_take(gpsx_ctx *ctx, size_t count)
+{
+  const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+  T *p = reinterpret_cast<T *>(ctx->d_arena + ctx->arena_used);
+  ctx->arena_used += bytes;
+  return p;
+}
+
+inline size_t arena_size(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+inline int use_device(gpsx_ctx *ctx)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return GPSX_OK;
+}
+
+// A host pointer that lies in a committed, unmodified part of one of the context's capture rings has an HBM mirror:
+// returns the mirror, or nullptr -> the caller copies (gpsx_capture.hip).
+const uint8_t *capture_mirror(gpsx_ctx *ctx, const uint8_t *host, size_t bytes);
+
+}  // namespace gpsx_host
