@@ -54,6 +54,17 @@ def _ref_prn_slice(ref, blk, prn_list, deadline):
     return done
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return f"{line.split(':', 1)[1].strip()} ({os.cpu_count()} logical CPUs)"
+    except OSError:
+        pass
+    return f"unknown ({os.cpu_count()} logical CPUs)"
+
+
 def cpu_baseline(blocks, budget_s=20.0):
     """Time the CPU path on a bounded sample of the same workload (capture 0 of the batch, the bench's own grid).
     Preferred: the reference's own C (oracle/_ref/libref_pm.so, built in place from the reference tree with gcc -O2) --
@@ -72,6 +83,7 @@ def cpu_baseline(blocks, budget_s=20.0):
         done = _ref_prn_slice(ref, blk, range(1, N_PRN + 1), t0 + 0.6 * budget_s)
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": done / dt, "unit": "hypotheses/s", "cores": 1, "kind": "reference",
+                               "cpu": _cpu_model(),
                                "sample": f"{done} of the {HYP_PER_SEARCH} hypotheses of capture 0 in {dt:.1f} s; {what}"}
         threads = max(1, min(32, (os.cpu_count() or 2) // 2))
         reps = 4
@@ -81,6 +93,7 @@ def cpu_baseline(blocks, budget_s=20.0):
             done = sum(ex.map(lambda sl: _ref_prn_slice(ref, blk, sl, t0 + 0.4 * budget_s), slices))
         dt = time.perf_counter() - t0
         out["cpu_baseline_allcores"] = {"value": done / dt, "unit": "hypotheses/s", "cores": threads, "kind": "reference",
+                                        "cpu": _cpu_model(),
                                         "sample": f"{done} hypotheses ({reps} passes over capture 0's grid) in {dt:.1f} s "
                                                   f"on {threads} threads; {what}"}
         return out
@@ -96,6 +109,7 @@ def cpu_baseline(blocks, budget_s=20.0):
             break
     dt = time.perf_counter() - t0
     out["cpu_baseline"] = {"value": reps * HYP_PER_SEARCH / dt, "unit": "hypotheses/s", "cores": threads, "kind": "port",
+                           "cpu": _cpu_model(),
                            "sample": f"{reps} full grids of capture 0 in {dt:.1f} s: oracle/gpsx_oracle.c, OpenMP over "
                                      "(PRN, Doppler) pairs"}
     return out
