@@ -520,9 +520,9 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
       if (reduce_now) {
 #pragma unroll
         for (int p = 0; p < G; p++) {
-          const u32 k = wave_max_u32(best[p]);
-          const u32 t = wave_sum_u32(total[p]);
-          if (lane == 0) {
+          const u32 k = wave_max_to_lane63(best[p]);   // DPP network, result in lane 63
+          const u32 t = wave_sum_to_lane63(total[p]);
+          if (lane == 63) {
             sh.red[wave][p][0] = k;
             sh.red[wave][p][1] = t;
           }
@@ -573,9 +573,9 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
           k = key > k ? key : k;
           t += in_win ? e : 0u;
         }
-      k = wave_max_u32(k);
-      t = wave_sum_u32(t);
-      if (lane == 0) {
+      k = wave_max_to_lane63(k);
+      t = wave_sum_to_lane63(t);
+      if (lane == 63) {
         sh.red[wave][p][0] = k;
         sh.red[wave][p][1] = t;
       }
