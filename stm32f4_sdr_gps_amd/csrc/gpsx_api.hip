@@ -121,6 +121,8 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     delete ctx;
     return GPSX_ENODEV;
   }
+  if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
+    ctx->ms_mode = std::strcmp(m, "walk") == 0 ? 1 : (std::strcmp(m, "blocks") == 0 ? 2 : 0);
   if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
     ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad
                 : std::strcmp(a, "dot8") == 0 ? kAlgoDot8
@@ -474,10 +476,19 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     }
   }
   bool poly = fine;
+  bool block_parallel = false;
   if (poly && g->n_ms > 1) {
-    // the multi-block form keeps 64 KB of running sums per (PRN, Doppler) pair of this shard in HBM; when that cannot
-    // be had (it is 2.7 GB for 64 simultaneous cold-start searches) the register-resident dot8 kernel does the job
-    const size_t need = acq_poly_energy_bytes(local_units);
+    // Scratch in HBM between blocks.  Many searches: each workgroup walks the blocks of its unit and keeps 64 KB of
+    // running sums per (PRN, Doppler) pair of this shard (2.7 GB for 64 simultaneous cold-start searches).  Fewer
+    // searches (fewer workgroups than six rounds of the chip's 768 slots): a workgroup per (unit, block) instead, all
+    // blocks' magnitudes as u16 (32 KB per pair and block), summed and searched by a second small kernel -- a single
+    // 10-block cold-start search then takes 0.84 ms instead of 2.8, and the form stays ahead up to ~40 searches.
+    // When the scratch cannot be had, the register-resident dot8 kernel does the job.
+    block_parallel = ctx->ms_mode ? ctx->ms_mode == 2
+                                  : local_units * kSuperGroups < 6 * 768 &&
+                                        acq_poly_vals_bytes(g->n_search, g->n_ms, g->n_prn, g->n_dopp) <= ((size_t)8 << 30);
+    const size_t need = block_parallel ? acq_poly_vals_bytes(g->n_search, g->n_ms, g->n_prn, g->n_dopp)
+                                       : acq_poly_energy_bytes(local_units);
     if (need > ctx->energy_bytes) {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       if (ctx->d_energy)
@@ -507,7 +518,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     }
     launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
                     ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1,
-                    ctx->d_energy);
+                    ctx->d_energy, block_parallel);
     LAUNCHCHK(ctx, "k_acq_poly");
   } else {
     const int algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;

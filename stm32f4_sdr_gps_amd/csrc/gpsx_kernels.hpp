@@ -66,7 +66,12 @@ void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqP
 // is split into two 8-offset workgroups per chip; the one-workgroup-per-chip form writes d_peaks directly.
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy);
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel);
+// scratch of the block-parallel multi-block form: every block's magnitudes, u16 per hypothesis
+inline size_t acq_poly_vals_bytes(int n_search, int n_ms, int n_prn, int n_dopp)
+{
+  return (size_t)n_search * n_ms * n_prn * n_dopp * 16 * 1024 * sizeof(uint16_t);
+}
 inline size_t acq_poly_energy_bytes(long local_units)
 {
   return (size_t)local_units * kSuperGroups * kAcqGroup * 16 * 1024 * sizeof(uint32_t);

@@ -20,6 +20,9 @@
 // running energy of every hypothesis it owns sits in a private 64 KB-per-PRN slice of an HBM scratch buffer (read-add-
 // write per block, dword per lane, coalesced; the last block searches on the sums instead of writing them back).
 //
+// (MODE kPolyMulti).  When the launch has few searches the blocks are spread over workgroups instead (kPolyStore): a
+// workgroup per (unit, block) writes its magnitudes as u16, k_acq_vals_search sums the blocks and searches.
+//
 // Lane l owns q = 4 l .. 4 l + 3; X_t0(4 l + 4) is lane l + 1's first value, exchanged through LDS.
 #include <cstdlib>
 
@@ -35,6 +38,7 @@ constexpr int kNibDwords = 264;   // 4-bit block sums, 2046 + pad nibbles (circu
 constexpr int kFullWords = 68;    // bit plane of saturated windows
 constexpr int kPlaneWords = 66;   // one polyphase bit plane: 1023 bits + circular copy
 constexpr int kMaxSegment = 16;   // sample offsets per workgroup: 8 (two workgroups per chip) or 16 (one)
+constexpr int kPolySingle = 0, kPolyMulti = 1, kPolyStore = 2;   // k_acq_poly's MODE
 constexpr int kPH = 8;            // PRNs per X pass (all of the group: X and M registers together still fit 168 VGPRs)
 
 template <int G, int SEG>
@@ -62,7 +66,7 @@ __device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
 // MULTI (non-coherent integration over several blocks): the per-hypothesis energies live in HBM between blocks --
 // energy[workgroup][PRN of the group][t0][i][tid] (q = 4 tid + i), 64 KB per PRN; every access is one dword per lane,
 // 256 B contiguous per wave.  ms_first: nothing to read yet; ms_last: search on the sums instead of writing them back.
-template <int G, int SEG, bool MULTI>
+template <int G, int SEG, int MODE>
 __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int tid, int lane, int t0, const u32 (&m_i)[4][G],
                                                    const u32 (&m_q)[4][G], int win_start, int win_stop,
                                                    const u32 *__restrict__ chipbits_g, int n_valid, size_t out0,
@@ -70,6 +74,7 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
                                                    gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
                                                    size_t energy_pair0, bool ms_first, bool ms_last)
 {
+  constexpr bool MULTI = MODE == kPolyMulti, STORE = MODE == kPolyStore;
   const int b = t0 & 7, half = t0 >> 3;
   const u32 low_mask = (1u << b) - 1u;
   const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;
@@ -152,6 +157,15 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
         cq -= odd_tail ? (int)__popc(prev_q ^ r_last) : 0;
       }
       u32 val = in_win ? (u32)mag8_fast<!MULTI>(ci, cq) : 0u;   // (MULTI: the shortcut's extra branch costs registers there)
+      if (STORE) {
+        // one block of a multi-block search handled as a workgroup of its own: the magnitudes go out as they are (u16,
+        // [t0][i][tid] like the energy slices: 128 B contiguous per wave), k_acq_vals_search sums and searches them
+        uint16_t *v = reinterpret_cast<uint16_t *>(energy) + (energy_pair0 + (size_t)p * out_pstride * (16 * 1024 / 8)) +
+                      (size_t)(t0 * 1024 + i * 256 + tid_e);
+        if (p < n_valid)
+          *v = (uint16_t)val;
+        continue;
+      }
       if (MULTI) {
         val += ms_first ? 0u : prev[MULTI ? p : 0];
         if (!ms_last)
@@ -163,7 +177,7 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (MULTI && !ms_last)
+  if (STORE || (MULTI && !ms_last))
     return;
   // Wave reduction, then merge.  SEG == 16: the workgroup sees both offsets of every bit shift, so the merge stays in
   // LDS and the finished triplet is written once; SEG == 8: the other offset belongs to another workgroup, merge through
@@ -199,23 +213,26 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
 
 }  // namespace
 
-template <int G, int SEG, bool MULTI>
+template <int G, int SEG, int MODE>
 __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ cw8, const u32 *__restrict__ chipbits,
                                                           u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
                                                           gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy)
 {
+  constexpr bool MULTI = MODE == kPolyMulti, STORE = MODE == kPolyStore;
   __shared__ PolyShared<G, SEG> sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
 
-  // ---- decode: (sharding unit = search x 16-PRN super group x Doppler) x group x segment ---------------------------
+  // ---- decode: (sharding unit = search x 16-PRN super group x Doppler) x group x segment [x block, STORE] -------------
   constexpr int kSegs = kMaxSegment / SEG;   // workgroups per chip
   int id = blockIdx.x;
   const int seg = id % kSegs;
   id /= kSegs;
   const int gsel = id % kSuperGroups;
-  const int unit_local = id / kSuperGroups;
+  id /= kSuperGroups;
+  const int ms_store = STORE ? id % prm.n_ms : 0;
+  const int unit_local = STORE ? id / prm.n_ms : id;
   const int unit = prm.shard_index + unit_local * prm.shard_count;
   const int dopp = unit % prm.n_dopp;
   const int t = unit / prm.n_dopp;
@@ -240,7 +257,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     sh.chipbits[p][w] = w < 32 ? chipbits_g[p * 32 + w] : 0u;
   }
 
-  const size_t energy_pair0 = (size_t)blockIdx.x * G;   // this workgroup's private slices, one per PRN of its group
+  // MULTI: this workgroup's private slices, one per PRN of its group (u32 units).  STORE: the (block, PRN, Doppler)
+  // plane of this workgroup's first PRN in the magnitude buffer (u16 units), PRN stride n_dopp planes
+  const size_t energy_pair0 = STORE ? ((size_t)((search * prm.n_ms + ms_store) * prm.n_prn + slot0) * prm.n_dopp + dopp) * (16 * 1024)
+                                    : (size_t)blockIdx.x * G;
   for (int i = tid; i < 8 * G * 2; i += kThreads)
     (&sh.part[0][0][0])[i] = 0;
 
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
   __syncthreads();   // the previous block's readers of the LDS arrays are done
   // ---- A1 / A2: capture -> LDS, carrier wipe-off (as k_acq) ---------------------------------------------------------
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
-  const uint8_t *blk = if_blocks + (size_t)(search * prm.search_stride_blocks + ms) * block_bytes;
+  const uint8_t *blk = if_blocks + (size_t)(search * prm.search_stride_blocks + ms + ms_store) * block_bytes;
   for (int i = tid; i < 1024; i += kThreads)
     sh.x[i] = i < kWords16 ? load_sign16(blk, i, prm.if_format) : (uint16_t)0;
   for (int i = tid; i < 2 * kFullWords; i += kThreads)
@@ -395,7 +415,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
       }
     }
   }
-  poly_finish_offset<G, SEG, MULTI>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
+  poly_finish_offset<G, SEG, MODE>(sh, tid, lane, t0_first, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g, n_valid,
                                     out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0, ms_first, ms_last);
 
   // ---- B1..B7: one sample further each: M += X(q + 1) - X(q), X = AND + popcount against the polyphase plane ----------
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
         m_q[3][pp] += right_q - x_q[3][p];
       }
     }
-    poly_finish_offset<G, SEG, MULTI>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g,
+    poly_finish_offset<G, SEG, MODE>(sh, tid, lane, t0_first + st + 1, m_i, m_q, prm.win_start, prm.win_stop, chipbits_g,
                                       n_valid, out0, out_pstride, keyacc, sumacc, peaks, energy, energy_pair0,
                                       ms_first, ms_last);
   }
@@ -501,6 +521,66 @@ __global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__rest
   peaks[idx] = pk;
 }
 
+// Multi-block searches handled block-parallel (k_acq_poly<.., kPolyStore> wrote every block's magnitudes): sum over the
+// blocks, then correlation_search's max / first argmax / sum over the window, per replica bit shift.  One workgroup per
+// (search, PRN, Doppler) this shard owns; 32 KB per block read once, coalesced.
+__global__ __launch_bounds__(kThreads) void k_acq_vals_search(const AcqParams prm, const uint16_t *__restrict__ vals,
+                                                              gpsx_peak_t *__restrict__ peaks)
+{
+  __shared__ u32 red[4][8][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int id = blockIdx.x;
+  const int dopp = id % prm.n_dopp;
+  id /= prm.n_dopp;
+  const int prn = id % prm.n_prn;
+  const int search = id / prm.n_prn;
+  const int n_super = (prm.n_groups + kSuperGroups - 1) / kSuperGroups;
+  const int unit = (search * n_super + prn / (kAcqGroup * kSuperGroups)) * prm.n_dopp + dopp;
+  if (unit % prm.shard_count != prm.shard_index)
+    return;
+  const size_t plane = (size_t)prm.n_prn * prm.n_dopp * (16 * 1024);                      // one block's magnitudes
+  const uint16_t *v0 = vals + ((size_t)(search * prm.n_ms) * prm.n_prn * prm.n_dopp + (size_t)prn * prm.n_dopp + dopp) * (16 * 1024);
+#pragma unroll 1
+  for (int b = 0; b < 8; b++) {
+    u32 best = 0, total = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int t0 = b + 8 * half;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int q = 4 * tid + i, o = 2 * q + half;
+        const bool in_win = q < kChips && o >= prm.win_start && o < prm.win_stop;
+        u32 e = 0;
+        for (int ms = 0; ms < prm.n_ms; ms++)
+          e += v0[(size_t)ms * plane + (size_t)(t0 * 1024 + i * 256 + tid)];
+        const u32 key = in_win ? (e << 11) | (u32)(2047 - o) : 0u;
+        best = key > best ? key : best;
+        total += in_win ? e : 0u;
+      }
+    }
+    best = wave_max_to_lane63(best);
+    total = wave_sum_to_lane63(total);
+    if (lane == 63) {
+      red[wave][b][0] = best;
+      red[wave][b][1] = total;
+    }
+  }
+  __syncthreads();
+  if (tid < 8) {
+    u32 k = 0, t = 0;
+    for (int w = 0; w < 4; w++) {
+      k = red[w][tid][0] > k ? red[w][tid][0] : k;
+      t += red[w][tid][1];
+    }
+    gpsx_peak_t pk;
+    pk.max_val = k >> 11;
+    pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+    pk.sum = t;
+    pk.avr = t / (2u * kChips);
+    peaks[((size_t)(search * prm.n_prn + prn) * prm.n_dopp + dopp) * 8 + tid] = pk;
+  }
+}
+
 void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks)
 {
@@ -510,14 +590,29 @@ void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t
 
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy)
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel)
 {
   if (local_units <= 0 || n_peaks == 0)
     return;
+  if (prm.n_ms > 1 && block_parallel) {
+    // Few multi-block searches: a workgroup per (unit, block) instead of per unit walking its blocks, the blocks'
+    // magnitudes through HBM (d_energy holds them as u16), one more small kernel to sum and search them.  Eight-offset
+    // workgroups when that is still a small launch: no merge is needed here, every hypothesis is stored on its own.
+    const long wg16 = local_units * kSuperGroups * prm.n_ms;
+    if (wg16 >= 6 * 768)
+      hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, kPolyStore>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                         d_chipbits, d_keyacc, d_sumacc, d_peaks, d_energy);
+    else
+      hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8, kPolyStore>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if,
+                         d_cw8, d_chipbits, d_keyacc, d_sumacc, d_peaks, d_energy);
+    hipLaunchKernelGGL(k_acq_vals_search, dim3((unsigned)(n_peaks / 8)), dim3(kThreads), 0, s, prm,
+                       reinterpret_cast<const uint16_t *>(d_energy), d_peaks);
+    return;
+  }
   if (prm.n_ms > 1) {
     // Non-coherent integration: always one workgroup per chip -- the energies of a (PRN, Doppler) pair then have one
     // owner, which walks the blocks itself and keeps the running sums in its own 64 KB-per-PRN slice of d_energy.
-    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, true>), dim3((unsigned)(local_units * kSuperGroups)), dim3(kThreads), 0,
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, kPolyMulti>), dim3((unsigned)(local_units * kSuperGroups)), dim3(kThreads), 0,
                        s, prm, d_if, d_cw8, d_chipbits, d_keyacc, d_sumacc, d_peaks, d_energy);
     return;
   }
@@ -529,11 +624,11 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
   const bool seg16 = force ? force[0] == '1' : wg16 >= 6 * 768;
   if (seg16) {
     (void)peaks_are_zero;   // units of other shards keep whatever the caller zeroed
-    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, false>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, kPolySingle>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
   } else {
     (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
-    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8, false>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8, kPolySingle>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
     hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
                        n_peaks, d_peaks);

@@ -777,3 +777,35 @@ def test_in_process_group_sharded_sweep_over_rccl(eng, stream):
         assert lib.gpsx_group_create(two, 2, C.byref(grp)) == -22
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("mode", ["walk", "blocks"])
+def test_both_multi_block_forms_match_the_oracle(oracle, stream, mode, monkeypatch):
+    """n_ms > 1 on the polyphase kernel has two forms, picked by launch size: `walk` (a workgroup walks the blocks of its
+    unit, running sums in an HBM slice) for many searches, `blocks` (a workgroup per (unit, block), all magnitudes
+    through HBM as u16, k_acq_vals_search sums and searches) for few.  $GPSX_ACQ_MS_MODE forces one: both must give the
+    oracle's triplets -- windows, stride, a PRN count off the group size, sharded halves included."""
+    from stm32f4_sdr_gps_amd import capi
+    monkeypatch.setenv("GPSX_ACQ_MS_MODE", mode)
+    e = capi.Engine(0)
+    monkeypatch.delenv("GPSX_ACQ_MS_MODE")
+    try:
+        prns = np.array([1, 5, 7, 14, 20, 25, 30, 31, 32, 3, 12], np.uint8)
+        for n_search, n_ms, stride, win in ((1, 10, 10, (0, 2046)), (2, 3, 4, (101, 1900)), (3, 2, 2, (0, 1))):
+            kw = dict(n_search=n_search, n_ms=n_ms, search_stride_blocks=stride, dopp_min_hz=-1000, dopp_step_hz=500,
+                      n_dopp=5, win=win)
+            peaks, keys = e.acq_grid(stream, prns, **kw)
+            for s_ in range(n_search):
+                blk = stream[s_ * stride:s_ * stride + n_ms]
+                for p in (0, 4, 10):
+                    for d in (0, 3):
+                        for b in (0, 5):
+                            pk, _, _ = oracle.search_job(blk, n_ms, oracle.ca_code(int(prns[p])),
+                                                         float(IF_HZ - 1000 + 500 * d), b, win[0], win[1])
+                            assert _peak_tuple(peaks[s_, p, d, b]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), \
+                                (mode, kw, s_, p, d, b)
+            halves = [e.acq_grid(stream, prns, shard=(r, 2), **kw) for r in range(2)]
+            assert np.array_equal(np.maximum(halves[0][1], halves[1][1]), keys)
+            assert np.array_equal(halves[0][0]["max_val"] + halves[1][0]["max_val"], peaks["max_val"])
+    finally:
+        e.close()
