@@ -326,7 +326,7 @@ def main():
                 "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": {"poly": "gpsx::k_acq_poly<8,16,false>", "dot8": "gpsx::k_acq<8,false,dot8>", "sad": "gpsx::k_acq<8,false,sad>", "ds": "gpsx::k_acq_ds<21>"}.get(os.environ.get("GPSX_ACQ_ALGO", "poly"), "gpsx::k_acq_poly<8,16,false>"),
+                "kernel": {"poly": "gpsx::k_acq_poly<8,16,0>", "dot8": "gpsx::k_acq<8,false,dot8>", "sad": "gpsx::k_acq<8,false,sad>", "ds": "gpsx::k_acq_ds<21>"}.get(os.environ.get("GPSX_ACQ_ALGO", "poly"), "gpsx::k_acq_poly<8,16,0>"),
                 "kernel_ms": launch_ms,
                 "note": "algorithmic bytes = 6138 B/hypothesis as the reference streams its operands (SURVEY.md 8(d)); "
                         "the kernel stages the 2 KB capture in LDS, so real HBM traffic is ~0 and frac may exceed 1; "
