@@ -109,3 +109,14 @@ def test_sharding_partition_and_key_packing():
     for world in (1, 2, 4, 8):
         counts = [int(sharding.owned_mask(16 * world, 32, 21, r, world)[:, ::16, :].sum()) for r in range(world)]
         assert len(set(counts)) == 1 and counts[0] == 16 * 2 * 21
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """include/*.h are the drop-in boundary of a C code base: strict C99 and C++11 must both take them, warnings as errors."""
+    src = tmp_path / "hdr_check.c"
+    src.write_text('#include "gpsx.h"\n#include "gpsx_compat.h"\n'
+                   "int main(void) { gpsx_acq_grid_t g; gps_ch_t c; (void)g; (void)c; return (int)sizeof(gpsx_peak_t) - 16; }\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only",
+                           "-x", "c++", str(src)])
