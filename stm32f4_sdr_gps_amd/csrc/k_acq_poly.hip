@@ -25,6 +25,7 @@
 //
 // Lane l owns q = 4 l .. 4 l + 3; X_t0(4 l + 4) is lane l + 1's first value, exchanged through LDS.
 #include <cstdlib>
+#include <type_traits>
 
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
@@ -427,14 +428,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
     const u32 shb = 4u * (u32)(tid_m & 7);
 #pragma unroll
     for (int ph = 0; ph < G / kPH; ph++) {   // unrolled: ph indexes the M registers
-      u32 x_i[4][kPH], x_q[4][kPH];
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int p = 0; p < kPH; p++) {
-          x_i[i][p] = 0;
-          x_q[i][p] = 0;
-        }
+      u32 x_i[4][kPH], x_q[4][kPH];   // defined by the first word's popcounts (no zeroing pass: 64 fewer ops per step)
       const u32 *pi = sh.plane[0][st] + wbase;
       const u32 *pq = sh.plane[1][st] + wbase;
       u32 cur_i = pi[0], cur_q = pq[0];
@@ -442,8 +436,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
       // hoisting all 128 chip words into SGPRs makes the compiler spill them through v_readlane, which costs more VALU
       // issue slots than the correlation itself).  The popcount accumulates in the instruction (v_bcnt_u32_b32 d, s, d);
       // written as asm because the optimiser otherwise reassociates the sums into bcnt + v_add3 chains.
-#pragma unroll 1
-      for (int w4 = 0; w4 < 8; w4++) {
+      auto trip = [&](int w4, auto first_trip) {
         u32 c32[kPH][4];
 #pragma unroll
         for (int p = 0; p < kPH; p++) {
@@ -466,14 +459,23 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
             for (int p = 0; p < kPH; p++) {
               const u32 ai = wi & c32[p][ww];
               const u32 aq = wq & c32[p][ww];
-              asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x_i[i][p]) : "v"(ai));
-              asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x_q[i][p]) : "v"(aq));
+              if (decltype(first_trip)::value && ww == 0) {
+                asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(x_i[i][p]) : "v"(ai));
+                asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(x_q[i][p]) : "v"(aq));
+              } else {
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x_i[i][p]) : "v"(ai));
+                asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x_q[i][p]) : "v"(aq));
+              }
             }
           }
           cur_i = nxt_i;
           cur_q = nxt_q;
         }
-      }
+      };
+      trip(0, std::true_type{});
+#pragma unroll 1
+      for (int w4 = 1; w4 < 8; w4++)
+        trip(w4, std::false_type{});
       // X(4 tid + 4) is the right neighbour's first value; lane 255's is X(1024) = X(1) = lane 0's second... not needed:
       // lane 255 owns q = 1020..1023 and only q <= 1022 exist, so its i = 3 result is never used.
       __syncthreads();   // previous readers of xch are done
