@@ -291,7 +291,8 @@ def main():
         if os.path.exists(tr_file):
             with open(tr_file) as f:
                 tr = json.load(f)
-            if tr.get("searches_per_launch") == args.searches and n_ms == 1:
+            if (tr.get("searches_per_launch") == args.searches and n_ms == 1
+                    and os.environ.get("GPSX_ACQ_ALGO", "poly") == "poly"):   # measured for the default kernel only
                 traffic = tr.get("hbm_bytes_per_launch")
         line = {
             "metric": "acquisition hypotheses/sec (PRN x Doppler x phase)",
