@@ -121,6 +121,10 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     delete ctx;
     return GPSX_ENODEV;
   }
+  if (const char *sg = std::getenv("GPSX_ACQ_SEG")) {
+    const int v = std::atoi(sg);
+    ctx->seg_force = (v == 4 || v == 8 || v == 16) ? v : 0;
+  }
   if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
     ctx->ms_mode = std::strcmp(m, "walk") == 0 ? 1 : (std::strcmp(m, "blocks") == 0 ? 2 : 0);
   if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
@@ -518,7 +522,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     }
     launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
                     ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1,
-                    ctx->d_energy, block_parallel);
+                    ctx->d_energy, block_parallel, ctx->seg_force);
     LAUNCHCHK(ctx, "k_acq_poly");
   } else {
     const int algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;

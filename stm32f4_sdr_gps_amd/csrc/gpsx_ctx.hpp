@@ -43,6 +43,7 @@ struct gpsx_ctx {
   int algo = gpsx::kAlgoPoly;              // $GPSX_ACQ_ALGO = poly (default) | dot8 | sad, for A/B measurements
   uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
   size_t acc_entries = 0;
+  int seg_force = 0;                 // $GPSX_ACQ_SEG = 4 | 8 | 16: force the polyphase kernel's offsets per workgroup (tests, A/B)
   int ms_mode = 0;                   // $GPSX_ACQ_MS_MODE = walk | blocks: force one multi-block form (tests, A/B); 0 = by size
   uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
   size_t energy_bytes = 0;

@@ -66,7 +66,8 @@ void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqP
 // is split into two 8-offset workgroups per chip; the one-workgroup-per-chip form writes d_peaks directly.
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel);
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel,
+                     int seg_force);
 // scratch of the block-parallel multi-block form: every block's magnitudes, u16 per hypothesis
 inline size_t acq_poly_vals_bytes(int n_search, int n_ms, int n_prn, int n_dopp)
 {

@@ -592,7 +592,8 @@ void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t
 
 void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel)
+                     gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel,
+                     int seg_force)
 {
   if (local_units <= 0 || n_peaks == 0)
     return;
@@ -619,22 +620,26 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
     return;
   }
   // One workgroup per chip (16 offsets: one direct step + 15 recurrence steps; results merged in LDS and written once)
-  // when that still leaves several waves of workgroups per CU slot; otherwise two (8 offsets each, merged through
-  // global atomics on two scratch planes and converted by k_acq_finalize) for balance.
-  static const char *force = std::getenv("GPSX_ACQ_SEG");   // "8" / "16": A/B measurements
+  // when that still leaves several waves of workgroups per CU slot; otherwise two (8 offsets each) or, for launches of
+  // a capture or two, four (4 offsets each), merged through global atomics on two scratch planes and converted by
+  // k_acq_finalize -- balance and latency against the extra direct steps.
   const long wg16 = local_units * kSuperGroups;
-  const bool seg16 = force ? force[0] == '1' : wg16 >= 6 * 768;
-  if (seg16) {
+  const int seg = seg_force ? seg_force : (wg16 >= 6 * 768 ? 16 : (wg16 >= 768 ? 8 : 4));   // ($GPSX_ACQ_SEG forces one)
+  if (seg == 16) {
     (void)peaks_are_zero;   // units of other shards keep whatever the caller zeroed
     hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, kPolySingle>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
-  } else {
-    (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
+    return;
+  }
+  (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
+  if (seg == 4)
+    hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 4, kPolySingle>), dim3((unsigned)(wg16 * 4)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
+                       d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
+  else
     hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8, kPolySingle>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
-    hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
-                       n_peaks, d_peaks);
-  }
+  hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
+                     d_peaks);
 }
 
 }  // namespace gpsx

@@ -687,16 +687,17 @@ def test_capture_replay_of_a_recorded_if_file(eng, stream, tmp_path):
 
 # ---- the alternative grid kernels stay bit-identical to the default ($GPSX_ACQ_ALGO, read when a context is created) --
 
-@pytest.mark.parametrize("algo", ["ds", "dot8", "sad"])
+@pytest.mark.parametrize("algo", ["ds", "dot8", "sad", "seg4", "seg8", "seg16"])
 def test_alternative_grid_kernels_match_the_default(eng, stream, algo, monkeypatch):
     """ds = the Doppler-shared polyphase form (k_acq_ds.hip: prefix popcounts shared by all Doppler bins, carrier sign
     changes from host-built tables), dot8 / sad = the direct forms.  Windows, a PRN count that is not a multiple of the
     group, a Doppler count that is not a multiple of the ds kernel's chunk, and for ds a grid too wide for its tables
     (|Doppler| >= 8 kHz: two sign changes in one 32-chip word) that must fall back without a trace."""
     from stm32f4_sdr_gps_amd import capi
-    monkeypatch.setenv("GPSX_ACQ_ALGO", algo)
+    var, val = ("GPSX_ACQ_SEG", algo[3:]) if algo.startswith("seg") else ("GPSX_ACQ_ALGO", algo)   # seg*: the polyphase
+    monkeypatch.setenv(var, val)                       # kernel with 4 / 8 / 16 sample offsets per workgroup, whatever the size
     alt = capi.Engine(0)
-    monkeypatch.delenv("GPSX_ACQ_ALGO")
+    monkeypatch.delenv(var)
     try:
         prns = np.array([1, 5, 7, 14, 20, 25, 30, 31, 32, 3, 12], np.uint8)
         for kw in (dict(n_search=2, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21),
