@@ -707,6 +707,16 @@ def test_alternative_grid_kernels_match_the_default(eng, stream, algo, monkeypat
             want_pk, want_keys = eng.acq_grid(stream[:5], prns, **kw)
             pk, keys = alt.acq_grid(stream[:5], prns, **kw)
             assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys), (algo, kw)
+        # and on 2-bit sign/magnitude captures (each kernel has its own unpack on the way into LDS)
+        from stm32f4_sdr_gps_amd import synth
+        two = synth.make_if(3, [synth.Sat(5, 912.5, 1600.0, 0.6, 0.3), synth.Sat(30, 2018.0, 13000.0, 0.6, 4.0)], seed=21,
+                            two_bit=True)
+        one_pk, one_keys = eng.acq_grid(synth.make_if(3, [synth.Sat(5, 912.5, 1600.0, 0.6, 0.3),
+                                                          synth.Sat(30, 2018.0, 13000.0, 0.6, 4.0)], seed=21),
+                                        prns, n_search=3, dopp_min_hz=0, dopp_step_hz=500, n_dopp=6)
+        alt.set_if_format(capi.IF_2BIT_SM)
+        pk, keys = alt.acq_grid(two, prns, n_search=3, dopp_min_hz=0, dopp_step_hz=500, n_dopp=6)
+        assert np.array_equal(pk, one_pk) and np.array_equal(keys, one_keys), algo
     finally:
         alt.close()
 
