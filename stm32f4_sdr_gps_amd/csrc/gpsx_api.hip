@@ -16,6 +16,10 @@ using namespace gpsx;
 using namespace gpsx_host;
 
 namespace {
+void track_graph_release(gpsx_ctx *ctx);
+}
+
+namespace {
 
 int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
 {
@@ -175,6 +179,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   (void)hipSetDevice(ctx->device);
   while (!ctx->captures.empty())
     gpsx_capture_destroy(ctx->captures.back());
+  track_graph_release(ctx);
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
@@ -638,6 +643,69 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   return GPSX_OK;
 }
 
+namespace {
+
+constexpr int kTrackGraphMaxCh = 65536;   // measured: beyond ~100k channels the host copies into / out of staging cost more than they save
+
+void track_graph_release(gpsx_ctx *ctx)
+{
+  gpsx_ctx::TrackGraph &t = ctx->trk_graph;
+  if (t.exec) (void)hipGraphExecDestroy(t.exec);
+  if (t.h_in) (void)hipHostFree(t.h_in);
+  if (t.h_out) (void)hipHostFree(t.h_out);
+  if (t.d_buf) (void)hipFree(t.d_buf);
+  const bool unusable = t.unusable;
+  t = gpsx_ctx::TrackGraph{};
+  t.unusable = unusable;
+}
+
+// H2D(block + states) -> k_track_epl -> D2H(states + accumulators), captured once per (channel count, format)
+bool track_graph_prepare(gpsx_ctx *ctx, int n_ch, size_t blk_bytes)
+{
+  gpsx_ctx::TrackGraph &t = ctx->trk_graph;
+  if (t.unusable)
+    return false;
+  if (t.exec && t.n_ch == n_ch && t.if_format == ctx->if_format)
+    return true;
+  (void)hipStreamSynchronize(ctx->stream);
+  track_graph_release(ctx);
+  t.blk_off = 0;
+  t.st_off = (blk_bytes + 2 + 255) & ~(size_t)255;
+  t.in_bytes = t.st_off + (size_t)n_ch * sizeof(gpsx_trk_state_t);
+  t.out_bytes = (size_t)n_ch * (sizeof(gpsx_trk_state_t) + 12);
+  bool ok = hipHostMalloc((void **)&t.h_in, t.in_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void **)&t.h_out, t.out_bytes, hipHostMallocDefault) == hipSuccess &&
+            hipMalloc((void **)&t.d_buf, t.in_bytes + (size_t)n_ch * 12) == hipSuccess;
+  hipGraph_t graph = nullptr;
+  if (ok) {
+    std::memset(t.h_in, 0, t.in_bytes);
+    gpsx_trk_state_t *d_st = reinterpret_cast<gpsx_trk_state_t *>(t.d_buf + t.st_off);
+    int16_t *d_iq = reinterpret_cast<int16_t *>(t.d_buf + t.in_bytes);   // right behind the states: one copy back
+    ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      ok = hipMemcpyAsync(t.d_buf, t.h_in, t.in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+      launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, d_st, n_ch, ctx->d_chips_all, d_iq);
+      ok = ok && hipGetLastError() == hipSuccess &&
+           hipMemcpyAsync(t.h_out, d_st, t.out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+      ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;
+    }
+    ok = ok && hipGraphInstantiate(&t.exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph)
+      (void)hipGraphDestroy(graph);
+  }
+  if (!ok) {
+    (void)hipGetLastError();
+    track_graph_release(ctx);
+    ctx->trk_graph.unusable = true;   // this runtime / stream cannot capture: keep to the plain path
+    return false;
+  }
+  t.n_ch = n_ch;
+  t.if_format = ctx->if_format;
+  return true;
+}
+
+}  // namespace
+
 int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out)
 {
   if (int rc = use_device(ctx)) return rc;
@@ -647,6 +715,18 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
     if (st[i].prn < 1 || st[i].prn > GPSX_MAX_PRN)
       return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
+  // The real-time shape (a few channels to a few thousand, every millisecond): the whole step is ONE graph launch
+  // between two small host copies into / out of pinned staging, instead of two copies in, a launch, two copies out.
+  if (n_ch <= kTrackGraphMaxCh && track_graph_prepare(ctx, n_ch, blk_bytes)) {
+    gpsx_ctx::TrackGraph &t = ctx->trk_graph;
+    std::memcpy(t.h_in + t.blk_off, if_block, blk_bytes);
+    std::memcpy(t.h_in + t.st_off, st, (size_t)n_ch * sizeof(gpsx_trk_state_t));
+    HIPCHK(ctx, hipGraphLaunch(t.exec, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(st, t.h_out, (size_t)n_ch * sizeof(gpsx_trk_state_t));
+    std::memcpy(iq_out, t.h_out + (size_t)n_ch * sizeof(gpsx_trk_state_t), (size_t)n_ch * 12);
+    return GPSX_OK;
+  }
   if (int rc = arena_reset(ctx, arena_size(blk_bytes + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
                                     arena_size((size_t)n_ch * 12)))
     return rc;
