@@ -647,28 +647,43 @@ namespace {
 
 constexpr int kTrackGraphMaxCh = 65536;   // measured: beyond ~100k channels the host copies into / out of staging cost more than they save
 
-void track_graph_release(gpsx_ctx *ctx)
+constexpr size_t kTrackGraphShapes = 4;
+
+void track_graph_free(gpsx_ctx::TrackGraph &t)
 {
-  gpsx_ctx::TrackGraph &t = ctx->trk_graph;
   if (t.exec) (void)hipGraphExecDestroy(t.exec);
   if (t.h_in) (void)hipHostFree(t.h_in);
   if (t.h_out) (void)hipHostFree(t.h_out);
   if (t.d_buf) (void)hipFree(t.d_buf);
-  const bool unusable = t.unusable;
   t = gpsx_ctx::TrackGraph{};
-  t.unusable = unusable;
 }
 
-// H2D(block + states) -> k_track_epl -> D2H(states + accumulators), captured once per (channel count, format)
-bool track_graph_prepare(gpsx_ctx *ctx, int n_ch, size_t blk_bytes)
+void track_graph_release(gpsx_ctx *ctx)
 {
-  gpsx_ctx::TrackGraph &t = ctx->trk_graph;
-  if (t.unusable)
-    return false;
-  if (t.exec && t.n_ch == n_ch && t.if_format == ctx->if_format)
-    return true;
+  for (gpsx_ctx::TrackGraph &t : ctx->trk_graphs)
+    track_graph_free(t);
+  ctx->trk_graphs.clear();
+}
+
+// H2D(block + states) -> k_track_epl -> D2H(states + accumulators), captured once per (channel count, format) shape;
+// returns the shape's graph (moved to the front of the small cache) or nullptr -> plain path
+gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch, size_t blk_bytes)
+{
+  if (ctx->trk_graph_unusable)
+    return nullptr;
+  std::vector<gpsx_ctx::TrackGraph> &cache = ctx->trk_graphs;
+  for (size_t i = 0; i < cache.size(); i++)
+    if (cache[i].n_ch == n_ch && cache[i].if_format == ctx->if_format) {
+      if (i)
+        std::rotate(cache.begin(), cache.begin() + i, cache.begin() + i + 1);
+      return &cache[0];
+    }
   (void)hipStreamSynchronize(ctx->stream);
-  track_graph_release(ctx);
+  if (cache.size() >= kTrackGraphShapes) {
+    track_graph_free(cache.back());
+    cache.pop_back();
+  }
+  gpsx_ctx::TrackGraph t;
   t.blk_off = 0;
   t.st_off = (blk_bytes + 2 + 255) & ~(size_t)255;
   t.in_bytes = t.st_off + (size_t)n_ch * sizeof(gpsx_trk_state_t);
@@ -695,13 +710,14 @@ bool track_graph_prepare(gpsx_ctx *ctx, int n_ch, size_t blk_bytes)
   }
   if (!ok) {
     (void)hipGetLastError();
-    track_graph_release(ctx);
-    ctx->trk_graph.unusable = true;   // this runtime / stream cannot capture: keep to the plain path
-    return false;
+    track_graph_free(t);
+    ctx->trk_graph_unusable = true;   // this runtime / stream cannot capture: keep to the plain path
+    return nullptr;
   }
   t.n_ch = n_ch;
   t.if_format = ctx->if_format;
-  return true;
+  cache.insert(cache.begin(), t);
+  return &cache[0];
 }
 
 }  // namespace
@@ -717,8 +733,9 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
   // The real-time shape (a few channels to a few thousand, every millisecond): the whole step is ONE graph launch
   // between two small host copies into / out of pinned staging, instead of two copies in, a launch, two copies out.
-  if (n_ch <= kTrackGraphMaxCh && track_graph_prepare(ctx, n_ch, blk_bytes)) {
-    gpsx_ctx::TrackGraph &t = ctx->trk_graph;
+  gpsx_ctx::TrackGraph *tg = n_ch <= kTrackGraphMaxCh ? track_graph_prepare(ctx, n_ch, blk_bytes) : nullptr;
+  if (tg) {
+    gpsx_ctx::TrackGraph &t = *tg;
     std::memcpy(t.h_in + t.blk_off, if_block, blk_bytes);
     std::memcpy(t.h_in + t.st_off, st, (size_t)n_ch * sizeof(gpsx_trk_state_t));
     HIPCHK(ctx, hipGraphLaunch(t.exec, ctx->stream));

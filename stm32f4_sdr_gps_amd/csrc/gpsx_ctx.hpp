@@ -65,14 +65,15 @@ struct gpsx_ctx {
   uint32_t *d_grid_cw8 = nullptr;
 
   // the per-millisecond tracking step as a captured graph (one launch instead of five runtime calls), for the last
-  // (channel count, sample format) it was called with; pinned staging on both sides
+  // (channel count, sample format) shapes it was called with; pinned staging on both sides
   struct TrackGraph {
     int n_ch = 0, if_format = -1;
-    bool unusable = false;
     hipGraphExec_t exec = nullptr;
     uint8_t *h_in = nullptr, *h_out = nullptr, *d_buf = nullptr;
     size_t blk_off = 0, st_off = 0, in_bytes = 0, out_bytes = 0;
-  } trk_graph;
+  };
+  std::vector<TrackGraph> trk_graphs;   // a few shapes (per-channel calls and batch calls alternate), most recent first
+  bool trk_graph_unusable = false;
 
   std::vector<gpsx_capture *> captures;   // IF ingest rings opened on this context
 
