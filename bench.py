@@ -17,7 +17,8 @@ Prints one JSON line on rank 0.  `roofline` is priced the way SURVEY.md 8(d) pre
 (6138 operand bytes per hypothesis as the reference streams them); the kernel itself keeps its operands in LDS and is
 bound by integer VALU issue, which `roofline_valu` prices (2048 lane-ops per hypothesis in the reference's XOR/popcount
 formulation; the polyphase kernel issues ~9x fewer).  `cpu_baseline` times the reference's own C (oracle/_ref, built in
-place from the reference tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.
+place from the reference tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.  `tracking`
+is BASELINE.json's second metric, bounded to a few hundred steps per channel count (N = 1 only).
 """
 import argparse
 import json
@@ -63,6 +64,37 @@ def _cpu_model():
     except OSError:
         pass
     return f"unknown ({os.cpu_count()} logical CPUs)"
+
+
+def tracking_channels(eng_cls, dev_index, steps=400):
+    """BASELINE.json's second metric, bounded: the largest channel count of a fixed ladder whose per-millisecond E/P/L step
+    (gpsx_track_epl_batch: block + states in, one launch, states + accumulators out) keeps its p99 under 1 ms."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    eng = eng_cls(dev_index)
+    stream = synth.default_four_sv(8, seed=7)
+    rows, best = [], None
+    for n in (256, 4096, 65536, 131072, 196608, 212992):
+        st = np.zeros(n, capi.TRK_DTYPE)
+        st["prn"] = (np.arange(n) % 32) + 1
+        st["code_phase_fine"] = (61 * np.arange(n) % 16368).astype(np.float32)
+        st["if_freq_offset_hz"] = (-5000 + 39 * (np.arange(n) % 256)).astype(np.float32)
+        for k in range(20):
+            eng.track_epl(stream[k % 8], st)
+        lat = np.zeros(steps)
+        for k in range(steps):
+            t0 = time.perf_counter()
+            eng.track_epl(stream[k % 8], st)
+            lat[k] = time.perf_counter() - t0
+        p50, p99 = float(np.percentile(lat, 50) * 1e6), float(np.percentile(lat, 99) * 1e6)
+        rows.append({"channels": n, "p50_us": p50, "p99_us": p99})
+        if p99 < 1000.0:
+            best = n
+        else:
+            break
+    eng.close()
+    return {"metric": "real-time tracking channels (p99 of the E/P/L step per ms < 1 ms, host round trip included)",
+            "value": best, "steps_per_count": steps, "ladder": rows,
+            "note": "10000-step measurements and the closed-loop figure are in profiles/r01_tracking_*.json"}
 
 
 def cpu_baseline(blocks, budget_s=20.0):
@@ -133,6 +165,8 @@ def main():
                          "unpacked to the sign plane in LDS inside the kernels (the reference's correlator never looks at "
                          "the magnitude bit either); 1bit = the 2046-byte sign stream the firmware's SPI delivers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracking", action="store_true",
+                    help="skip the secondary metric (real-time tracking channels: E/P/L steps of growing channel counts)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -348,6 +382,8 @@ def main():
         if pcie is not None:
             line["pcie_inclusive"] = {"value": pcie, "unit": "hypotheses/s",
                                       "note": "gpsx_acq_grid() with host buffers: H2D captures + launch + D2H peaks/keys"}
+        if not args.no_tracking and world == 1:
+            line["tracking"] = tracking_channels(capi.Engine, dev_index)
         if not args.no_cpu_baseline and world == 1:
             line.update(cpu_baseline(blocks, args.cpu_budget_s))
             line["cpu_host"] = {"logical_cpus": os.cpu_count()}
