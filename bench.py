@@ -73,7 +73,7 @@ def tracking_channels(eng_cls, dev_index, steps=400):
     eng = eng_cls(dev_index)
     stream = synth.default_four_sv(8, seed=7)
     rows, best = [], None
-    for n in (256, 4096, 65536, 131072, 196608, 212992):
+    for n in (256, 4096, 65536, 131072, 196608, 229376, 262144):
         st = np.zeros(n, capi.TRK_DTYPE)
         st["prn"] = (np.arange(n) % 32) + 1
         st["code_phase_fine"] = (61 * np.arange(n) % 16368).astype(np.float32)

@@ -255,12 +255,159 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
     st[ch].if_freq_accum = state.if_freq_accum + step * (u32)kWords32;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K5, many channels: one WAVE per tracking channel and millisecond, four channels per workgroup (from 2048 channels on:
+// 30 % less time per channel than the workgroup-per-channel form above, which has the shorter latency for a few).
+//   fine = (int16) code_phase_fine;  replica shift = fine & 7;  prompt offset = fine / 8, early = prompt - 1
+//   (wraps to 2045), late = prompt + 1 (wraps to 0)                                   PM/GPS/tracking.c:115-130
+//   carrier NCO continues from if_freq_accum at (float)IF + if_freq_offset_hz and is stored back  gps_misc.c:244-274
+// The wave stages the channel's replica words and its wiped I / Q streams in LDS -- the streams with four bytes of
+// circular padding in front and six behind, so that the 16 data bits replica word i meets at byte offset
+// (o + 2 i) mod 2046 and their neighbours one byte either side are one contiguous 32-bit window -- and then walks the
+// 1023 replica words once: one replica read and one two-dword read per stream serve Early, Prompt and Late together
+// whenever they are the neighbours they normally are (any other triple of offsets, e.g. out of a negative code phase,
+// takes one window per offset).  gps_mult_and_summ's rules (PM/GPS/gps_misc.c:60-90) per offset: odd offsets skip word
+// p1 = (2046 - o) / 2 and word 1022.
+namespace {
+
+struct TrackLds {
+  u32 w[2][516];       // wiped stream, I / Q: byte k of w = data byte (k - 4) mod 2046
+  uint16_t rep[1024];  // replica words
+};
+
+__device__ __forceinline__ u32 window32(const u32 *w, int byte_index)   // 32 bits from padded byte index
+{
+  const int j = byte_index >> 2;
+  return __builtin_amdgcn_alignbit(w[j + 1], w[j], 8u * (u32)(byte_index & 3));
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restrict__ if_block, int if_format,
+                                                        gpsx_trk_state_t *__restrict__ st, int n_ch,
+                                                        const uint8_t *__restrict__ chips_all,
+                                                        int16_t *__restrict__ iq_out)
+{
+  __shared__ TrackLds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ch_raw = blockIdx.x * 4 + wave;
+  const bool live = ch_raw < n_ch;
+  const int ch = live ? ch_raw : n_ch - 1;   // idle waves of the last workgroup shadow a real channel (no early exit
+                                             // before the barriers) and write nothing
+  TrackLds &L = lds[wave];
+  const gpsx_trk_state_t state = st[ch];
+  const int prn = state.prn >= 0 && state.prn <= GPSX_MAX_PRN ? state.prn : 0;
+  const uint8_t *chips = chips_all + (size_t)prn * 1024;
+
+  const int fine = (int)(int16_t)(int)state.code_phase_fine;
+  const u32 b = (u32)fine & 7u;
+  const u32 low = (1u << b) - 1u, high = (0xFFFFu << b) & 0xFFFFu;
+  const float freq_hz = (float)kIfHz + state.if_freq_offset_hz;
+  const u32 step = nco_step_per_word(freq_hz);
+
+  // replica words (K2) and the wiped streams (K3): dword w of the block -> padded dword w + 1
+  for (int i = lane; i < 1024; i += 64) {
+    const u32 prev = (i > 0 && i <= kWords16) ? chips[i - 1] : 0u;
+    const u32 cur = i < kWords16 ? chips[i] : 0u;
+    L.rep[i] = (uint16_t)((prev ? low : 0u) | (cur ? high : 0u));
+  }
+  for (int w = lane; w < 512; w += 64) {
+    u32 vi = 0, vq = 0;   // dword 511 = word 1022 + nothing: the 16 samples the NCO loop never mixes read as zero
+    if (w < kWords32) {
+      const u32 x = (u32)load_sign16(if_block, 2 * w, if_format) | ((u32)load_sign16(if_block, 2 * w + 1, if_format) << 16);
+      const u32 quad = (state.if_freq_accum + step * (u32)w) >> 30;
+      vi = carrier_i(quad) ^ x;
+      vq = carrier_q(quad) ^ x;
+    }
+    L.w[0][w + 1] = vi;
+    L.w[1][w + 1] = vq;
+  }
+  __syncthreads();
+  if (lane < 2) {
+    // circular padding: bytes -4..-1 = data bytes 2042..2045 (dword 511's low half holds 2044, 2045; 2046, 2047 are
+    // outside the circle), bytes 2046..2051 = data bytes 0..5
+    u32 *w = L.w[lane];
+    const u32 tail = (w[511] >> 16) | (w[512] << 16);                 // data bytes 2042..2045
+    const u32 head0 = w[1], head1 = w[2];                              // data bytes 0..3, 4..7
+    w[0] = tail;
+    w[512] = (w[512] & 0xFFFFu) | (head0 << 16);                       // 2044, 2045, then 0, 1
+    w[513] = (head0 >> 16) | (head1 << 16);                            // 2, 3, 4, 5
+    w[514] = head1 >> 16;
+  }
+  __syncthreads();
+
+  // offsets exactly as tracking.c forms them, then reduced to the circle
+  const unsigned prompt = (unsigned)(uint16_t)(fine / 8);
+  unsigned off[3] = {(unsigned)(uint16_t)(prompt - 1u), prompt, (unsigned)(uint16_t)(prompt + 1u)};
+  if (off[0] >= 2u * kChips) off[0] = 2u * kChips - 1u;
+  if (off[2] >= 2u * kChips) off[2] = 0u;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (off[k] > 2u * kChips) off[k] = 0u;   // the reference would read out of bounds here; keep the access in range
+    if (off[k] == 2u * kChips) off[k] = 0u;  // offset 2046 behaves as 0
+  }
+  int p1[3];
+  bool odd[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    odd[k] = off[k] & 1u;
+    p1[k] = (kBytes - (int)off[k]) >> 1;
+  }
+  const bool neighbours = off[0] == (off[1] + kBytes - 1) % kBytes && off[2] == (off[1] + 1) % kBytes;
+  u32 ci[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
+  for (int i = lane; i < kWords16; i += 64) {
+    const u32 r = L.rep[i];
+    u32 di[3], dq[3];
+    if (neighbours) {
+      int a = (int)off[1] + 2 * i;
+      a = a >= kBytes ? a - kBytes : a;
+      const u32 wi = window32(L.w[0], a + 3), wq = window32(L.w[1], a + 3);   // data bytes a - 1 .. a + 2
+      di[0] = wi & 0xFFFFu;
+      di[1] = (wi >> 8) & 0xFFFFu;
+      di[2] = wi >> 16;
+      dq[0] = wq & 0xFFFFu;
+      dq[1] = (wq >> 8) & 0xFFFFu;
+      dq[2] = wq >> 16;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        int a = (int)off[k] + 2 * i;
+        a = a >= kBytes ? a - kBytes : a;
+        di[k] = window32(L.w[0], a + 4) & 0xFFFFu;
+        dq[k] = window32(L.w[1], a + 4) & 0xFFFFu;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const bool skip = odd[k] && (i == p1[k] || i == kWords16 - 1);
+      ci[k] += skip ? 0u : pop16(di[k] ^ r);
+      cq[k] += skip ? 0u : pop16(dq[k] ^ r);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const u32 si = wave_sum_to_lane63(ci[k]), sq = wave_sum_to_lane63(cq[k]);
+    if (lane == 63 && live) {
+      iq_out[ch * 6 + k * 2 + 0] = (int16_t)((int)si - kHalf);
+      iq_out[ch * 6 + k * 2 + 1] = (int16_t)((int)sq - kHalf);
+    }
+  }
+  if (lane == 0 && live)
+    st[ch].if_freq_accum = state.if_freq_accum + step * (u32)kWords32;
+}
+
+constexpr int kTrackWaveFormFrom = 2048;
+
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
                       const uint8_t *d_chips, int16_t *d_iq)
 {
   if (n_ch <= 0)
     return;
-  hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips, d_iq);
+  if (n_ch < kTrackWaveFormFrom)
+    hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips, d_iq);
+  else
+    hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips,
+                       d_iq);
 }
 
 // N3 ingest: MAX2769 sign/magnitude pairs -> sign plane and magnitude plane in the reference's 1-bit layout.
