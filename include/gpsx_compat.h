@@ -46,64 +46,47 @@ extern "C" {
 #define TRACKING_FLL1_C1           (200.0f)
 #define TRACKING_FLL1_C2           (2000.0f)
 
+/* Channel state machines.  The member names and their order are the reference's (a host reads and writes them, and the
+ * step logic is checked byte for byte against the reference's records), so the enumerators and the structure members
+ * below cannot differ from gps_misc.h:20-99; same-typed neighbours are declared together. */
 typedef enum {
-  GPS_ACQ_NEED_FREQ_SEARCH = 0,
-  GPS_ACQ_FREQ_SEARCH_RUN,
-  GPS_ACQ_FREQ_SEARCH_DONE,
-  GPS_ACQ_CODE_PHASE_SEARCH1,
-  GPS_ACQ_CODE_PHASE_SEARCH1_DONE,
-  GPS_ACQ_CODE_PHASE_SEARCH2,
-  GPS_ACQ_CODE_PHASE_SEARCH2_DONE,
-  GPS_ACQ_CODE_PHASE_SEARCH3,
-  GPS_ACQ_CODE_PHASE_SEARCH3_DONE,
+  GPS_ACQ_NEED_FREQ_SEARCH = 0, GPS_ACQ_FREQ_SEARCH_RUN, GPS_ACQ_FREQ_SEARCH_DONE,      /* Doppler sweep                  */
+  GPS_ACQ_CODE_PHASE_SEARCH1, GPS_ACQ_CODE_PHASE_SEARCH1_DONE,                           /* coarse phase histogram         */
+  GPS_ACQ_CODE_PHASE_SEARCH2, GPS_ACQ_CODE_PHASE_SEARCH2_DONE,                           /* narrowed window                */
+  GPS_ACQ_CODE_PHASE_SEARCH3, GPS_ACQ_CODE_PHASE_SEARCH3_DONE,                           /* all channels together          */
   GPS_ACQ_DONE
 } gps_acq_state_t;
 
-typedef enum {
-  GPS_TRACKNG_IDLE = 0,
-  GPS_NEED_PRE_TRACK,
-  GPS_PRE_TRACK_RUN,
-  GPS_PRE_TRACK_DONE,
-  GPS_TRACKING_RUN
-} gps_tracking_state_t;
+typedef enum { GPS_TRACKNG_IDLE = 0, GPS_NEED_PRE_TRACK, GPS_PRE_TRACK_RUN, GPS_PRE_TRACK_DONE, GPS_TRACKING_RUN } gps_tracking_state_t;
 
-/* acquisition state of one channel (gps_misc.h:43-60) */
+/* acquisition state of one channel (60 bytes) */
 typedef struct {
-  uint8_t  freq_index;             /* Doppler bin under test: -7000 Hz + index * 500 Hz            */
-  int16_t  found_freq_offset_hz;
-  int16_t  given_freq_offset_hz;   /* user hint; non-zero skips the frequency search               */
-  uint16_t found_code_phase;       /* byte offsets, 0 .. 2046                                      */
-  uint16_t code_search_start;
-  uint16_t code_search_stop;
-  uint16_t code_hist_step;
+  uint8_t  freq_index;                                     /* Doppler bin under test: -7000 Hz + index * 500 Hz          */
+  int16_t  found_freq_offset_hz, given_freq_offset_hz;     /* result; user hint (non-zero skips the frequency search)    */
+  uint16_t found_code_phase, code_search_start, code_search_stop, code_hist_step;   /* byte offsets, 0 .. 2046         */
   gps_acq_state_t state;
   uint8_t  code_phase_histogram[ACQ_PHASE1_HIST_SIZE];
-  uint32_t start_timestamp;
+  uint32_t start_timestamp;                                /* 1 ms ticks                                                 */
   float    hist_ratio;
 } gps_acq_t;
 
-/* tracking state of one channel (gps_misc.h:62-99, ENABLE_CODE_FILTER == 1) */
+/* tracking state of one channel (152 bytes; the reference built with ENABLE_CODE_FILTER == 1) */
 typedef struct {
-  uint16_t code_search_start;
-  uint16_t code_search_stop;
-  float    if_freq_offset_hz;      /* Doppler estimate the carrier NCO runs at                     */
-  uint32_t if_freq_accum;          /* carrier NCO accumulator carried across milliseconds          */
+  uint16_t code_search_start, code_search_stop;            /* pre-tracking window, byte offsets                          */
+  float    if_freq_offset_hz;                              /* Doppler estimate the carrier NCO runs at                   */
+  uint32_t if_freq_accum;                                  /* carrier NCO accumulator carried across milliseconds        */
   uint16_t pre_track_phases[PRE_TRACK_POINTS_MAX_CNT];
   uint8_t  pre_track_count;
   uint32_t prev_track_timestamp;
-  float    code_phase_fine;        /* samples, 0 .. 16368                                          */
-  float    old_code_phase_fine;
+  float    code_phase_fine, old_code_phase_fine;           /* samples, 0 .. 16368                                        */
   uint8_t  code_phase_swap_flag;
-  float    dll_code_err;
-  float    pll_code_err;
-  int16_t  fll_old_i;
-  int16_t  fll_old_q;
+  float    dll_code_err, pll_code_err;                     /* loop filter memories                                       */
+  int16_t  fll_old_i, fll_old_q;
   float    fll_err;
-  int16_t  pll_check_buf[TRACKING_CH_LENGTH];
+  int16_t  pll_check_buf[TRACKING_CH_LENGTH];              /* false-lock detector                                        */
   uint8_t  pll_bad_state_cnt;
   uint16_t pll_bad_state_master_cnt;
-  uint32_t i_part_summ;
-  uint32_t q_part_summ;
+  uint32_t i_part_summ, q_part_summ;                       /* SNR estimator                                              */
   uint16_t snr_summ_cnt;
   float    snr_value;
   uint32_t filt_start_time_ms;
@@ -120,29 +103,21 @@ typedef struct {
 #define GPS_NAV_WORD_LENGTH           30   /* bits */
 #define GPS_NAV_SUBFRAME_LENGTH_BYTES 38   /* 300 bits */
 typedef struct {
-  uint8_t  period_sync_ok_flag;    /* 20 ms bit period found                                       */
-  uint8_t  right_period_cnt;
-  uint32_t old_swap_time;          /* ms tick of the last sign change                              */
+  uint8_t  period_sync_ok_flag, right_period_cnt;          /* 20 ms bit period found / confidence counter                */
+  uint32_t old_swap_time;                                  /* ms tick of the last sign change                            */
   uint8_t  old_reminder;
-  uint8_t  accurate_swap_time;     /* 0..19                                                        */
-  uint8_t  accurate_swap_ok;
-  uint8_t  last_bit_pos_cnt;
-  uint8_t  last_bit_neg_cnt;
-  uint8_t  inv_polarity_flag;      /* the Costas loop locked 180 degrees off: bits are inverted    */
-  uint8_t  polarity_found;         /* a word passed parity with the current polarity               */
-  uint8_t  inv_preabmle_cnt;       /* inverted preambles seen while hunting                        */
-  uint8_t  word_buf[GPS_NAV_WORD_LENGTH];   /* one bit per byte: the word being collected          */
-  uint8_t  word_cnt;               /* words of the current subframe received (0 = hunting)         */
-  uint8_t  word_bit_cnt;
-  uint8_t  old_D29;                /* last two bits of the previous word, for the parity equations */
-  uint8_t  old_D30;
-  uint32_t word_detection_timestamp;        /* ms tick of the last word that passed parity         */
-  uint32_t word_cnt_test;
-  uint32_t last_subframe_time;     /* ms tick of the bit edge that began the current subframe      */
-  uint32_t first_subframe_time;
+  uint8_t  accurate_swap_time, accurate_swap_ok;           /* bit edge inside the 20 ms grid, 0..19 / valid              */
+  uint8_t  last_bit_pos_cnt, last_bit_neg_cnt;             /* votes for the bit being integrated                         */
+  uint8_t  inv_polarity_flag, polarity_found;              /* Costas loop 180 degrees off / confirmed by a good word     */
+  uint8_t  inv_preabmle_cnt;                               /* inverted preambles seen while hunting                      */
+  uint8_t  word_buf[GPS_NAV_WORD_LENGTH];                  /* one bit per byte: the word being collected                 */
+  uint8_t  word_cnt, word_bit_cnt;                         /* words of the subframe received (0 = hunting) / bits        */
+  uint8_t  old_D29, old_D30;                               /* last two bits of the previous word (parity equations)      */
+  uint32_t word_detection_timestamp, word_cnt_test;        /* ms tick of the last good word / good words so far          */
+  uint32_t last_subframe_time, first_subframe_time;        /* ms tick of the bit edge that began the subframe            */
   uint16_t subframe_cnt;
   uint8_t  new_subframe_flag;
-  uint8_t  subframe_data[GPS_NAV_SUBFRAME_LENGTH_BYTES];   /* bit n of the subframe = bit (n & 7) of byte n >> 3 */
+  uint8_t  subframe_data[GPS_NAV_SUBFRAME_LENGTH_BYTES];   /* bit n of the subframe = bit (n & 7) of byte n >> 3         */
 } gps_nav_data_t;
 /* Observation of a channel (gps_misc.h:135-139); written by the pseudorange step, which this library does not have. */
 typedef struct {
@@ -158,20 +133,14 @@ typedef struct {
   double sec;           /* fraction of a second                                         */
 } gtime_t;
 typedef struct {
-  int     sat;          /* satellite (PRN)                                              */
-  int     iode, iodc;   /* issue of data, ephemeris / clock                             */
-  int     sva;          /* URA index                                                    */
-  int     svh;          /* health (0 = ok)                                              */
-  int     week;         /* GPS week, roll-over resolved                                 */
-  int     code;         /* codes on L2                                                  */
-  int     flag;         /* L2 P data flag                                               */
-  gtime_t toe, toc, ttr;
-  double  A, e, i0, OMG0, omg, M0, deln, OMGd, idot;      /* orbit: m, -, rad, rad/s    */
-  double  crc, crs, cuc, cus, cic, cis;                   /* harmonic corrections       */
-  double  toes;         /* toe, s of week                                               */
-  double  fit;          /* fit interval flag                                            */
-  double  f0, f1, f2;   /* clock polynomial                                             */
-  double  tgd[4];       /* tgd[0] = T_GD                                                */
+  int     sat;                                             /* satellite (PRN)                                            */
+  int     iode, iodc, sva, svh;                            /* issues of data, URA index, health (0 = ok)                 */
+  int     week, code, flag;                                /* GPS week (roll-over resolved), codes on L2, L2 P data flag */
+  gtime_t toe, toc, ttr;                                   /* ephemeris / clock reference epochs, transmission time      */
+  double  A, e, i0, OMG0, omg, M0, deln, OMGd, idot;       /* Keplerian set: m, -, rad, rad/s                            */
+  double  crc, crs, cuc, cus, cic, cis;                    /* harmonic corrections                                       */
+  double  toes, fit;                                       /* toe as s of week, fit interval flag                        */
+  double  f0, f1, f2, tgd[4];                              /* clock polynomial, group delay (tgd[0] = T_GD)              */
 } eph_t;
 typedef struct {
   eph_t    eph;
