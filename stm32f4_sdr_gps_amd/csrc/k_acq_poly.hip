@@ -10,7 +10,7 @@
 // and X is a correlation of two BIT vectors of length 1023: 32 words of v_and_b32 + v_bcnt_u32_b32 (accumulating) per
 // hypothesis and stream -- 64 instructions against the 128 v_dot8_u32_u4 of the direct form (and 2046 XOR/popcount
 // pairs in the reference).  d_t0 is the t0-th polyphase component of the wiped stream (every 16th sample).
-// A workgroup owns 1024 chip offsets q x G PRNs x I,Q for a SEGMENT of 8 or 16 consecutive t0: the first is computed
+// A workgroup owns 1024 chip offsets q x G PRNs x I,Q for a SEGMENT of 4, 8 or 16 consecutive t0: the first is computed
 // directly (4-bit block sums, v_dot8_u32_u4, exact saturation pass -- as in k_acq), the others by the recurrence.
 // Per-(PRN, bit shift) search results are merged across even / odd byte offsets (t0 = b and b + 8) and the four waves:
 // in LDS when the workgroup walks all 16 offsets (the triplet is then written once), through atomicMax / atomicAdd on
@@ -38,7 +38,7 @@ constexpr int kThreads = 256;
 constexpr int kNibDwords = 264;   // 4-bit block sums, 2046 + pad nibbles (circular copy appended)
 constexpr int kFullWords = 68;    // bit plane of saturated windows
 constexpr int kPlaneWords = 66;   // one polyphase bit plane: 1023 bits + circular copy
-constexpr int kMaxSegment = 16;   // sample offsets per workgroup: 8 (two workgroups per chip) or 16 (one)
+constexpr int kMaxSegment = 16;   // sample offsets per workgroup: 16 (one workgroup per chip), 8 (two) or 4 (four)
 constexpr int kPolySingle = 0, kPolyMulti = 1, kPolyStore = 2;   // k_acq_poly's MODE
 constexpr int kPH = 8;            // PRNs per X pass (all of the group: X and M registers together still fit 168 VGPRs)
 
