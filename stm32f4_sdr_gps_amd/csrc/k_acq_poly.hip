@@ -172,7 +172,9 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
         if (!ms_last)
           (e_grp + p * (16 * 1024))[e_off] = val;
       }
-      const u32 key = in_win ? (val << 11) | key_lo : 0u;
+      // val is already 0 outside the window: such a key is below every key with val > 0, and if nothing exceeds 0 the
+      // reported phase is 0 whatever the low bits say -- no second select needed
+      const u32 key = (val << 11) | key_lo;
       best[p] = key > best[p] ? key : best[p];
       total[p] += val;
     }
