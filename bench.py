@@ -361,6 +361,10 @@ def main():
                 "unit": "GB/s",
                 "frac": ach_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # what the chip's memory system actually moved (rocprofv3 FETCH_SIZE + WRITE_SIZE of this kernel and
+                # launch size, profiles/hbm_traffic.json), as a rate over this run's launch time and against the peak
+                "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_frac_of_peak": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "kernel": {"poly": "gpsx::k_acq_poly<8,16,0>", "dot8": "gpsx::k_acq<8,false,dot8>", "sad": "gpsx::k_acq<8,false,sad>", "ds": "gpsx::k_acq_ds<21>"}.get(os.environ.get("GPSX_ACQ_ALGO", "poly"), "gpsx::k_acq_poly<8,16,0>"),
                 "kernel_ms": launch_ms,
                 "note": "algorithmic bytes = 6138 B/hypothesis as the reference streams its operands (SURVEY.md 8(d)); "
