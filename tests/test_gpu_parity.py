@@ -454,6 +454,37 @@ def test_track_epl_wave_form_for_many_channels(eng, oracle, stream):
         assert np.array_equal(iq_big[n + c], want) and int(big["if_freq_accum"][n + c]) == acc, c
 
 
+def test_track_epl_graph_cache_alternating_shapes_and_formats(oracle, stream):
+    """The per-millisecond step runs as a captured graph per (channel count, sample format), a few shapes cached: calls
+    alternating between more shapes than the cache holds, and between 1-bit and 2-bit blocks, must keep giving the
+    oracle's accumulators (and must not leak state from one shape's staging buffers into another's)."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    e = capi.Engine(0)
+    try:
+        sats = [synth.Sat(5, 912.5, 1600.0, 0.6, 0.3), synth.Sat(30, 2018.0, 13000.0, 0.6, 4.0)]
+        one = synth.make_if(2, sats, seed=21)
+        two = synth.make_if(2, sats, seed=21, two_bit=True)
+        rng = np.random.default_rng(3)
+        for trial in range(24):
+            n = (1, 4, 2, 7, 1, 33, 4, 300)[trial % 8]              # eight shapes, cache of four
+            two_bit = trial % 3 == 0
+            e.set_if_format(capi.IF_2BIT_SM if two_bit else capi.IF_1BIT)
+            st = np.zeros(n, capi.TRK_DTYPE)
+            st["prn"] = rng.choice([5, 30], n)
+            st["code_phase_fine"] = rng.uniform(0, 16368, n).astype(np.float32)
+            st["if_freq_offset_hz"] = rng.uniform(-4000, 4000, n).astype(np.float32)
+            st["if_freq_accum"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+            before = st.copy()
+            iq = e.track_epl((two if two_bit else one)[trial & 1], st)
+            for c in range(0, n, max(1, n // 5)):
+                want, acc = oracle.track_epl(one[trial & 1], oracle.ca_code(int(before["prn"][c])),
+                                             float(before["code_phase_fine"][c]), float(before["if_freq_offset_hz"][c]),
+                                             int(before["if_freq_accum"][c]))
+                assert np.array_equal(iq[c], want) and int(st["if_freq_accum"][c]) == acc, (trial, n, c)
+    finally:
+        e.close()
+
+
 def test_track_epl_four_sv_default_table_locks_on_signal(eng, stream):
     """BASELINE.json configs[1]: the reference's 4-SV table (PM/main.c:59-73).  With the true code phase and a
     Doppler within tens of Hz, the prompt correlator must dominate early/late and carry most of the power."""
