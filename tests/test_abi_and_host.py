@@ -77,6 +77,8 @@ int main(void){
  printf("%zu %zu %zu %zu %zu ", offsetof(gps_ch_t,tracking_data), offsetof(gps_ch_t,nav_data), offsetof(gps_ch_t,obs_data), offsetof(gps_ch_t,eph_data), offsetof(gps_ch_t,prn_code));
  printf("%zu %zu %zu %zu %zu %zu ", offsetof(gps_acq_t,found_code_phase), offsetof(gps_acq_t,state), offsetof(gps_acq_t,code_phase_histogram), offsetof(gps_acq_t,start_timestamp), offsetof(gps_acq_t,hist_ratio), offsetof(gps_acq_t,given_freq_offset_hz));
  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(gps_tracking_t,if_freq_offset_hz), offsetof(gps_tracking_t,if_freq_accum), offsetof(gps_tracking_t,pre_track_phases), offsetof(gps_tracking_t,prev_track_timestamp), offsetof(gps_tracking_t,code_phase_fine), offsetof(gps_tracking_t,fll_old_i), offsetof(gps_tracking_t,pll_check_buf), offsetof(gps_tracking_t,snr_value), offsetof(gps_tracking_t,state));
+ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(gps_nav_data_t), offsetof(gps_nav_data_t,old_swap_time), offsetof(gps_nav_data_t,inv_polarity_flag), offsetof(gps_nav_data_t,word_buf), offsetof(gps_nav_data_t,word_cnt), offsetof(gps_nav_data_t,old_D30), offsetof(gps_nav_data_t,word_detection_timestamp), offsetof(gps_nav_data_t,first_subframe_time), offsetof(gps_nav_data_t,new_subframe_flag), offsetof(gps_nav_data_t,subframe_data));
+ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(eph_t), sizeof(sdreph_t), sizeof(gps_obs_data_t), offsetof(eph_t,week), offsetof(eph_t,toc), offsetof(eph_t,M0), offsetof(eph_t,cus), offsetof(eph_t,fit), offsetof(eph_t,f2), offsetof(sdreph_t,week_gpst), offsetof(sdreph_t,sub_cnt), offsetof(sdreph_t,received_mask_proc));
  return 0; }
 '''
     import tempfile
@@ -84,7 +86,7 @@ int main(void){
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "p.c")
         open(src, "w").write(probe)
-        for hdr, inc in (('"gps_misc.h"', [f"-I{ref}", f"-I{ref}/GPS"]), ('"gpsx_compat.h"', [f"-I{ROOT}/include"])):
+        for hdr, inc in (('"gps_misc.h"', [f"-I{ref}", f"-I{ref}/GPS", f"-I{ref}/GPS/RTK"]), ('"gpsx_compat.h"', [f"-I{ROOT}/include"])):
             exe = os.path.join(td, "p")
             subprocess.check_call(["gcc", "-w", f"-DHDR={hdr}", *inc, src, "-o", exe])
             outs.append(subprocess.check_output([exe], text=True))
