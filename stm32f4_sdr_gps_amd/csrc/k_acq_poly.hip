@@ -52,7 +52,8 @@ struct PolyShared {
   u32 ones[2];                             // pop(D) per stream
   u32 plane[2][SEG - 1][kPlaneWords];      // d_t0 for the SEG - 1 recurrence steps, I / Q
   u32 chipbits[G][34];
-  u32 xch[2 * kPH][kThreads];              // first X value of every lane, for its left neighbour
+  u32 xch[2][2 * kPH][kThreads];           // first X value of every lane, for its left neighbour (two buffers, by step
+                                           // parity: the readers of one step never meet the writers of the next)
   u32 part[8][G][2];                       // SEG == 16: (packed best key, sum) per bit shift and PRN, merged over the
                                            // four waves and the two offsets (t0 = b: even byte offsets, b + 8: odd)
 };
@@ -480,18 +481,17 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
         trip(w4, std::false_type{});
       // X(4 tid + 4) is the right neighbour's first value; lane 255's is X(1024) = X(1) = lane 0's second... not needed:
       // lane 255 owns q = 1020..1023 and only q <= 1022 exist, so its i = 3 result is never used.
-      __syncthreads();   // previous readers of xch are done
 #pragma unroll
       for (int p = 0; p < kPH; p++) {
-        sh.xch[2 * p][tid] = x_i[0][p];
-        sh.xch[2 * p + 1][tid] = x_q[0][p];
+        sh.xch[st & 1][2 * p][tid] = x_i[0][p];
+        sh.xch[st & 1][2 * p + 1][tid] = x_q[0][p];
       }
       __syncthreads();
       const int nb = tid < kThreads - 1 ? tid + 1 : tid;
 #pragma unroll
       for (int p = 0; p < kPH; p++) {
-        const u32 right_i = sh.xch[2 * p][nb];
-        const u32 right_q = sh.xch[2 * p + 1][nb];
+        const u32 right_i = sh.xch[st & 1][2 * p][nb];
+        const u32 right_q = sh.xch[st & 1][2 * p + 1][nb];
         const int pp = ph * kPH + p;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
