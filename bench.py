@@ -2,23 +2,31 @@
 """bench.py -- headline benchmark of the MI355X GPS L1 C/A correlator engine.
 
 Metric (BASELINE.json): acquisition hypotheses / second (PRN x Doppler x code phase).
-Workload (BASELINE.json configs[2], SURVEY.md 8(d) "Config 3"): cold-start grid, all 32 PRN x 21 Doppler bins
-(+-5 kHz @ 500 Hz) x 16368 code phases (2046 byte offsets x 8 replica bit shifts), 1 ms coherent, synthetic
-16.368 Msps IF with six satellites in view (each below the noise floor; --amp-scale), by default as 2-bit sign/magnitude
-pairs (--if-format; the magnitude bit travels and is ignored, as in the reference).  One STEP = one gpsx_acq_grid_dev() call over a batch of
-`--searches` independent 1 ms captures per GPU, inputs already resident in HBM, results (per-hypothesis-unit peak
-triplets + packed peak keys) left in HBM.
+Workload, N = 1 (BASELINE.json configs[2], SURVEY.md 8(d) "Config 3"): cold-start grid, all 32 PRN x 21 Doppler bins
+(+-5 kHz @ 500 Hz) x 16368 code phases (2046 byte offsets x 8 replica bit shifts), 1 ms coherent, synthetic 16.368 Msps
+IF with six satellites in view (each below the noise floor; --amp-scale), by default as 2-bit sign/magnitude pairs
+(--if-format; the magnitude bit travels and is ignored, as in the reference).  One STEP = one gpsx_acq_grid_dev() call
+over a batch of `--searches` independent captures per GPU, inputs already resident in HBM when the timed region starts
+(the bench contract), results (per-hypothesis-unit peak triplets + packed peak keys) left in HBM.  The same sweep fed
+from and returned to pinned host buffers (SURVEY.md 8(d)'s wording of the metric: H2D + launch + D2H) is reported
+beside it as `pcie_inclusive`.
 
-N GPUs (torchrun, one rank per GPU): the job holds N x searches captures; every capture's (PRN group, Doppler) grid
-units are dealt round-robin to the ranks (per-GPU work is constant: weak scaling) and ONE all-reduce(MAX) of the packed
-(energy, phase) key table over RCCL merges the peaks -- the only collective on the path.
+N > 1 (torchrun, one rank per GPU; BASELINE.json configs[3]): the same grid with 10 ms NON-COHERENT integration
+(--n-ms defaults to 10 there, 1 at N = 1; hypotheses are counted per 1 ms block, SURVEY.md 8(d) "Config 4").  The job
+holds N x searches ten-block searches; the (search, 8-PRN group, Doppler) units are dealt round-robin to the ranks
+(84 units per search; per-GPU work is constant: weak scaling) and ONE all-reduce(MAX) of the packed (energy, phase) key
+table over RCCL merges the peaks -- the only collective on the path.  `single_search` adds configs[3]'s literal shape:
+ONE ten-block search sharded over the N ranks, latency per search.
 
-Prints one JSON line on rank 0.  `roofline` is priced the way SURVEY.md 8(d) prescribes for a bytes-based roofline
-(6138 operand bytes per hypothesis as the reference streams them); the kernel itself keeps its operands in LDS and is
-bound by integer VALU issue, which `roofline_valu` prices (2048 lane-ops per hypothesis in the reference's XOR/popcount
-formulation; the polyphase kernel issues ~9x fewer).  `cpu_baseline` times the reference's own C (oracle/_ref, built in
-place from the reference tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.  `tracking`
-is BASELINE.json's second metric, bounded to a few hundred steps per channel count (N = 1 only).
+Prints one JSON line on rank 0.  `roofline`: the grid kernel is bound by integer VALU issue (operands live in LDS;
+HBM traffic is ~0 by construction), so `achieved` is the ISSUED integer lane-operations per second -- SQ_INSTS_VALU per
+launch from the committed rocprofv3 PMC summary of this kernel and launch shape (profiles/kernel_counters.json) x 64
+lanes / this run's launch time -- against the micro-benchmarked issue peak (profiles/r01_valu_rates_microbench.txt:
+one wave64 integer op per 4 cycles per SIMD = 64 lanes/clk/CU); `frac` is therefore a true fraction (<= 1).  The
+reference-equivalent operand stream (6138 B/hypothesis as the reference re-reads its operands) is kept
+as information only.  `cpu_baseline` times the reference's own C (oracle/_ref, built in place from the reference tree)
+-- or the CPU oracle port when that build is absent -- on a bounded sample.  `tracking` is BASELINE.json's second
+metric, bounded to a few hundred steps per channel count (N = 1 only).
 """
 import argparse
 import json
@@ -34,9 +42,14 @@ sys.path.insert(0, ROOT)
 N_PRN, N_DOPP, DOPP_MIN, DOPP_STEP, N_PHASE = 32, 21, -5000, 500, 16368
 HYP_PER_SEARCH = N_PRN * N_DOPP * N_PHASE          # 10 999 296
 BYTES_PER_HYP = 6138                                 # I + Q + replica, 3 x 2046 B per hypothesis
-LANE_OPS_PER_HYP = 2048                              # 1024 xor + 1024 bcnt
+LANE_OPS_PER_HYP_REF = 2048                          # 1024 xor + 1024 bcnt (the reference's formulation)
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_INT_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12         # 39.3 T lane-ops/s: 64 int lanes/clk/CU measured (tools/microbench)
+# Lower bound of the polyphase formulation itself, lane-ops per hypothesis: 2 streams x 32 words x
+# (v_and + accumulating v_bcnt) = 128 for the bit-plane correlation, 4 for the recurrence M += X(q+1) - X(q), and the
+# cheapest epilogue that still yields the reference's integers (2 centre/scale, 2 clips, 2 squares+add, 4 issue slots of
+# quarter-rate v_sqrt_f32, 1 truncate, 3 for key/max/sum) = 14
+LANE_OPS_PER_HYP_MIN_MODEL = 146
 
 
 def _ref_prn_slice(ref, blk, prn_list, deadline):
@@ -94,14 +107,14 @@ def tracking_channels(eng_cls, dev_index, steps=400):
     eng.close()
     return {"metric": "real-time tracking channels (p99 of the E/P/L step per ms < 1 ms, host round trip included)",
             "value": best, "steps_per_count": steps, "ladder": rows,
-            "note": "10000-step measurements and the closed-loop figure are in profiles/r01_tracking_*.json"}
+            "note": "10000-step measurements and the closed-loop figure are in profiles/r0N_tracking_*.json"}
 
 
 def cpu_baseline(blocks, budget_s=20.0):
     """Time the CPU path on a bounded sample of the same workload (capture 0 of the batch, the bench's own grid).
     Preferred: the reference's own C (oracle/_ref/libref_pm.so, built in place from the reference tree with gcc -O2) --
-    on one core (`cpu_baseline`) and on many cores (`cpu_baseline_allcores`: threads calling the same library, which
-    only shares its read-only popcount table).  Without that build: the CPU oracle port (OpenMP)."""
+    on one core (`cpu_baseline`) and on every physical core (`cpu_baseline_multicore`: threads calling the same
+    library, which only shares its read-only popcount table; `cores` says how many).  Without that build: the CPU oracle port (OpenMP)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
     pyoracle.build()
@@ -117,14 +130,14 @@ def cpu_baseline(blocks, budget_s=20.0):
         out["cpu_baseline"] = {"value": done / dt, "unit": "hypotheses/s", "cores": 1, "kind": "reference",
                                "cpu": _cpu_model(),
                                "sample": f"{done} of the {HYP_PER_SEARCH} hypotheses of capture 0 in {dt:.1f} s; {what}"}
-        threads = max(1, min(32, (os.cpu_count() or 2) // 2))
-        reps = 4
+        threads = max(1, min(128, (os.cpu_count() or 2) // 2))     # one thread per physical core (SMT pairs share one)
+        reps = max(4, -(-2 * threads // N_PRN))                    # at least two PRN slices per thread
         slices = [[(i % N_PRN) + 1 for i in range(t, N_PRN * reps, threads)] for t in range(threads)]
         t0 = time.perf_counter()
         with ThreadPoolExecutor(threads) as ex:
             done = sum(ex.map(lambda sl: _ref_prn_slice(ref, blk, sl, t0 + 0.4 * budget_s), slices))
         dt = time.perf_counter() - t0
-        out["cpu_baseline_allcores"] = {"value": done / dt, "unit": "hypotheses/s", "cores": threads, "kind": "reference",
+        out["cpu_baseline_multicore"] = {"value": done / dt, "unit": "hypotheses/s", "cores": threads, "kind": "reference",
                                         "cpu": _cpu_model(),
                                         "sample": f"{done} hypotheses ({reps} passes over capture 0's grid) in {dt:.1f} s "
                                                   f"on {threads} threads; {what}"}
@@ -157,9 +170,9 @@ def main():
                     help="scale of the six synthetic satellites' amplitudes: 0.25 (default) puts each satellite below the "
                          "noise like a live antenna; 1.0 is the strong test signal, whose long runs of saturated block sums "
                          "take the kernel's exact-correction pass far more often (reported in profiles/ as the slow case)")
-    ap.add_argument("--n-ms", type=int, default=1,
-                    help="blocks integrated non-coherently per search (BASELINE.json configs[3] uses 10); hypotheses are "
-                         "then counted per block, as SURVEY.md 8(d) config 4 does")
+    ap.add_argument("--n-ms", type=int, default=None,
+                    help="blocks integrated non-coherently per search; default 1 at --gpus 1 (BASELINE.json configs[2]) and "
+                         "10 at --gpus N > 1 (configs[3]); hypotheses are counted per block, as SURVEY.md 8(d) config 4 does")
     ap.add_argument("--if-format", choices=["2bit", "1bit"], default="2bit",
                     help="sample format of the captures in HBM: 2bit = MAX2769-style sign/magnitude pairs, 4092 bytes per ms, "
                          "unpacked to the sign plane in LDS inside the kernels (the reference's correlator never looks at "
@@ -169,6 +182,8 @@ def main():
                     help="skip the secondary metric (real-time tracking channels: E/P/L steps of growing channel counts)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
+    if args.n_ms is None:
+        args.n_ms = 1 if args.gpus == 1 else 10
 
     import torch
     import torch.distributed as dist
@@ -276,25 +291,47 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
 
-    # PCIe-inclusive rate of the host-buffer entry point (H2D of the captures + launch + D2H of peaks and keys); reported
-    # as an extra, never as `value`
+    # PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
+    # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Two contexts (two streams) take the calls
+    # alternately through gpsx_acq_grid_async, so one call's transfers overlap the other's sweep -- what a host streaming
+    # captures through the engine does.  `serial` is the one-context, synchronous gpsx_acq_grid() loop of round 1.
     pcie = None
     if world == 1 and n_ms == 1:
         g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
                            dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
-        # host buffers in pinned memory, as SURVEY.md 8(d) defines the metric (torch only provides the pinned pages)
-        pin_pk = torch.zeros(n_search * N_PRN * N_DOPP * 8 * capi.PEAK_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-        pin_keys = torch.zeros(n_search * N_PRN * N_DOPP, dtype=torch.int64).pin_memory()
-        pin_if = torch.from_numpy(dev_blocks.reshape(-1).copy()).pin_memory()
-        h_peaks, h_keys, h_if = pin_pk.numpy(), pin_keys.numpy(), pin_if.numpy()
-        reps = 10
-        for i in range(reps + 2):
-            if i == 2:
-                tp = time.perf_counter()
-            rc = eng.lib.gpsx_acq_grid(eng.h, C.byref(g1), h_if.ctypes.data, n_search, h_peaks.ctypes.data,
-                                       h_keys.ctypes.data)
-            assert rc == 0
-        pcie = reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
+        engs = [capi.Engine(dev_index), capi.Engine(dev_index)]     # own non-blocking streams
+        pins = []
+        for e2 in engs:
+            if two_bit:
+                e2.set_if_format(capi.IF_2BIT_SM)
+            # torch only provides the pinned pages
+            pin_pk = torch.zeros(n_search * N_PRN * N_DOPP * 8 * capi.PEAK_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+            pin_keys = torch.zeros(n_search * N_PRN * N_DOPP, dtype=torch.int64).pin_memory()
+            pin_if = torch.from_numpy(dev_blocks.reshape(-1).copy()).pin_memory()
+            pins.append((pin_if, pin_pk, pin_keys))
+        reps = 12
+
+        def pcie_loop(n_ctx):
+            for i in range(reps + 2):
+                if i == 2:
+                    for e2 in engs[:n_ctx]:
+                        e2.synchronize()
+                    tp = time.perf_counter()
+                e2 = engs[i % n_ctx]
+                pin_if, pin_pk, pin_keys = pins[i % n_ctx]
+                e2.synchronize()            # the buffers of this context's previous call are the caller's again
+                rc = e2.lib.gpsx_acq_grid_async(e2.h, C.byref(g1), pin_if.data_ptr(), n_search, pin_pk.data_ptr(),
+                                                pin_keys.data_ptr())
+                assert rc == 0, e2.lib.gpsx_last_error(e2.h)
+            for e2 in engs[:n_ctx]:
+                e2.synchronize()
+            return reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
+
+        pcie_serial = pcie_loop(1)
+        pcie = pcie_loop(2)
+        assert torch.equal(pins[0][2], pins[1][2]) and int(pins[0][2].min()) > 0     # both contexts returned the key table
+        for e2 in engs:
+            e2.close()
 
     # sanity outside the timed region: the merged key table must hold the six synthetic satellites' peaks
     d_keys = key_bufs[(step_no[0] - 1) & 1]
@@ -316,21 +353,81 @@ def main():
         if rank == 0:
             print("VERIFY sharded == unsharded", flush=True)
 
+    # BASELINE.json configs[3] as written: ONE ten-block cold-start search, its 84 (PRN group, Doppler) units dealt to the
+    # N ranks, one all-reduce(MAX) of 672 keys; latency per search (outside the headline's timed region)
+    single = None
+    if use_dist and n_ms > 1:
+        g_one = eng.grid_desc(prns, n_search=1, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=DOPP_MIN,
+                              dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046),
+                              shard=(rank, world))
+        with torch.cuda.stream(stream):
+            one_keys = torch.zeros((1, N_PRN, N_DOPP), dtype=torch.int64, device=dev)
+            reps1 = 30
+            for i in range(reps1 + 3):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    ts = time.perf_counter()
+                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_one), d_if.data_ptr(), n_ms, d_peaks.data_ptr(),
+                                               one_keys.data_ptr(), None, None, None)
+                assert rc == 0
+                dist.all_reduce(one_keys, op=dist.ReduceOp.MAX)
+                torch.cuda.synchronize()       # a receiver acts on each search's result before it starts the next
+            dist.barrier()
+            dt1 = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt1, op=dist.ReduceOp.MAX)
+        single = {"ms_per_search": float(dt1.item()) / reps1 * 1e3,
+                  "value": reps1 * n_ms * HYP_PER_SEARCH / float(dt1.item()), "unit": "hypotheses/s",
+                  "note": f"one {n_ms}-block search (32 PRN x 21 Doppler x 16368 phases) sharded over {world} ranks, "
+                          "84 units round-robin, all-reduce(MAX) of 672 keys, synchronised per search"}
+
     if rank == 0:
         total_hyp = float(args.steps) * n_search * n_ms * HYP_PER_SEARCH
         value = total_hyp / elapsed_s
         launch_ms = gpu_ms / args.steps                   # HIP events on the engine's stream around the K launches
         hyp_per_launch = args.searches * n_ms * HYP_PER_SEARCH   # per GPU
-        ach_gbs = hyp_per_launch * BYTES_PER_HYP / (launch_ms * 1e-3) / 1e9
-        ach_tops = hyp_per_launch * LANE_OPS_PER_HYP / (launch_ms * 1e-3) / 1e12
-        traffic = None
-        tr_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tr_file):
-            with open(tr_file) as f:
-                tr = json.load(f)
-            if (tr.get("searches_per_launch") == args.searches and n_ms == 1
-                    and os.environ.get("GPSX_ACQ_ALGO", "poly") == "poly"):   # measured for the default kernel only
-                traffic = tr.get("hbm_bytes_per_launch")
+        kernel = eng.lib.gpsx_last_kernel(eng.h).decode()
+        # counters of this kernel and launch shape, from the committed rocprofv3 PMC summaries (tools/summarize_profile.py)
+        counters = None
+        kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
+        if os.path.exists(kc_file):
+            with open(kc_file) as f:
+                for ent in json.load(f):
+                    if (ent.get("kernel") == kernel and ent.get("searches_per_launch") == args.searches
+                            and ent.get("n_ms") == n_ms and ent.get("world", 1) == 1):
+                        counters = ent
+        if counters and counters.get("SQ_INSTS_VALU"):
+            issued = counters["SQ_INSTS_VALU"] * 64.0                       # lane-ops per launch
+            ach = issued / (launch_ms * 1e-3) / 1e12
+            roof = {"bound": "valu-int-issue", "achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
+                    "frac": ach / VALU_INT_PEAK_TOPS,
+                    "ops_per_hyp_issued": issued / hyp_per_launch,
+                    "ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
+                    "useful_frac": LANE_OPS_PER_HYP_MIN_MODEL * hyp_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
+                    "ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF,
+                    "counter_source": counters.get("source")}
+        else:
+            # no committed counters for this kernel / shape: price the formulation's own lower bound instead (<= issued)
+            ach = LANE_OPS_PER_HYP_MIN_MODEL * hyp_per_launch / (launch_ms * 1e-3) / 1e12
+            roof = {"bound": "valu-int-issue", "achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
+                    "frac": ach / VALU_INT_PEAK_TOPS, "ops_per_hyp_issued": None,
+                    "ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
+                    "ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF, "counter_source": None}
+        traffic = counters.get("hbm_bytes_per_launch") if counters else None
+        roof.update({
+            # what the chip's memory system actually moved per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, corrected as
+            # MI355X_MICROARCH.md prescribes), as a rate over this run's launch time and against the HBM peak
+            "traffic": traffic,
+            "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac_of_hbm_peak": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "reference_equivalent_stream_gbs": hyp_per_launch * BYTES_PER_HYP / (launch_ms * 1e-3) / 1e9,
+            "kernel": "gpsx::" + kernel,
+            "kernel_ms": launch_ms,
+            "note": "operands stay in LDS, HBM traffic is ~0 by construction: the binding resource is integer VALU issue. "
+                    "achieved = issued lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
+                    "time); peak = 256 CU x 64 lanes/clk x 2.4 GHz (micro-benchmarked); reference_equivalent_stream_gbs is "
+                    "6138 B/hypothesis as the reference re-reads its operands -- information, not a fraction of anything",
+        })
         line = {
             "metric": "acquisition hypotheses/sec (PRN x Doppler x phase)",
             "value": value,
@@ -354,41 +451,21 @@ def main():
                 "searches_per_gpu_per_step": args.searches,
                 "hypotheses_per_step": n_search * n_ms * HYP_PER_SEARCH,
                 "blocks_per_search": n_ms,
-                "parallelism": f"grid units dealt round-robin to {world} rank(s); one all-reduce(MAX) of packed peak keys"
-                               if world > 1 else "single GPU",
+                "parallelism": f"(search, 8-PRN group, Doppler) units dealt round-robin to {world} rank(s); one "
+                               "all-reduce(MAX) of packed peak keys" if world > 1 else "single GPU",
+                "inputs": "resident in HBM when the timed region starts; results left in HBM (pcie_inclusive: host to host)",
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": ach_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": ach_gbs / HBM_PEAK_GBS,
-                "traffic": traffic,
-                # what the chip's memory system actually moved (rocprofv3 FETCH_SIZE + WRITE_SIZE of this kernel and
-                # launch size, profiles/hbm_traffic.json), as a rate over this run's launch time and against the peak
-                "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
-                "traffic_frac_of_peak": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "kernel": {"poly": "gpsx::k_acq_poly<8,16,0>", "dot8": "gpsx::k_acq<8,false,dot8>", "sad": "gpsx::k_acq<8,false,sad>", "ds": "gpsx::k_acq_ds<21>"}.get(os.environ.get("GPSX_ACQ_ALGO", "poly"), "gpsx::k_acq_poly<8,16,0>"),
-                "kernel_ms": launch_ms,
-                "note": "algorithmic bytes = 6138 B/hypothesis as the reference streams its operands (SURVEY.md 8(d)); "
-                        "the kernel stages the 2 KB capture in LDS, so real HBM traffic is ~0 and frac may exceed 1; "
-                        "the binding resource is integer VALU issue, see roofline_valu",
-            },
-            "roofline_valu": {
-                "bound": "valu-int",
-                "achieved": ach_tops,
-                "peak": VALU_INT_PEAK_TOPS,
-                "unit": "Tlane-op/s",
-                "frac": ach_tops / VALU_INT_PEAK_TOPS,
-                "note": "algorithmic lane-ops = 2048/hypothesis (reference XOR+popcount formulation); the polyphase "
-                        "kernel issues ~210/hypothesis, so frac > 1; issued-op efficiency (VALU issue saturated) is in "
-                        "profiles/",
-            },
+            "roofline": roof,
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }
         if pcie is not None:
-            line["pcie_inclusive"] = {"value": pcie, "unit": "hypotheses/s",
-                                      "note": "gpsx_acq_grid() with pinned host buffers: H2D captures + launch + D2H peaks/keys"}
+            line["pcie_inclusive"] = {"value": pcie, "unit": "hypotheses/s", "serial": pcie_serial,
+                                      "frac_of_value": pcie / value,
+                                      "note": "SURVEY.md 8(d)'s wording of the metric: pinned host buffers, H2D captures + "
+                                              "sweep + D2H peaks/keys; two contexts alternate through gpsx_acq_grid_async "
+                                              "(`serial`: one context, synchronous gpsx_acq_grid)"}
+        if single is not None:
+            line["single_search"] = single
         if not args.no_tracking and world == 1:
             line["tracking"] = tracking_channels(capi.Engine, dev_index)
         if not args.no_cpu_baseline and world == 1:

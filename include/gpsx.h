@@ -66,6 +66,8 @@ void        gpsx_destroy(gpsx_ctx *ctx);
 int         gpsx_synchronize(gpsx_ctx *ctx);
 const char *gpsx_last_error(const gpsx_ctx *ctx);   /* text of the last failure on this context */
 const char *gpsx_strerror(int code);
+/* name of the dominant kernel the last gpsx_acq_grid* call launched (which form of the grid kernel the size picked) */
+const char *gpsx_last_kernel(const gpsx_ctx *ctx);
 int         gpsx_version(void);
 /* name / CU count / clock of the device behind the context (for bench reports) */
 int         gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *compute_units, int *clock_khz);
@@ -167,6 +169,12 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
 /* Host-buffer convenience: copies the blocks in, runs, copies peaks (and keys if non-NULL) out. */
 int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks,
                   gpsx_peak_t *peaks, int64_t *keys);
+/* The same, enqueued only: copy in, sweep and copies out are put on the context's stream and the call returns; the
+ * host buffers (pinned memory, or the copies are not asynchronous) belong to the engine until gpsx_synchronize(ctx).
+ * Two contexts used alternately overlap one call's PCIe transfers with the other's sweep -- how a host that streams
+ * captures through the engine reaches the HBM-resident rate (bench.py `pcie_inclusive`). */
+int gpsx_acq_grid_async(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks,
+                        gpsx_peak_t *peaks, int64_t *keys);
 
 /* Explicit job list: one search per job, each with its own PRN, carrier frequency, replica shift and window --
  * what acquisition_process() needs for the reference's 4-channel table with per-channel Doppler hints

@@ -4,7 +4,7 @@
  * A C program written against the reference header links against libgpsx.so unchanged: same function names,
  * argument meaning and (silent) error behaviour; the channel structures below keep the reference's field names
  * and, on LP64 x86-64, its exact layout (gps_misc.h:43-99,184-193; checked by static asserts in gpsx_compat.cpp
- * and against the reference header by tests/test_compat_layout.py).  Every call runs on the GPU through the
+ * and against the reference header by tests/test_abi_and_host.py::test_compat_struct_layout_matches_reference_header_when_present).  Every call runs on the GPU through the
  * process-wide default context (device $GPSX_DEVICE, default 0); if no gfx950 device can be opened the first call
  * prints a diagnostic and aborts -- there is no CPU path.
  *

@@ -51,6 +51,8 @@ def load_library() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.gpsx_last_error.restype = C.c_char_p
     lib.gpsx_strerror.restype = C.c_char_p
+    lib.gpsx_last_kernel.restype = C.c_char_p
+    lib.gpsx_last_kernel.argtypes = [C.c_void_p]
     lib.gpsx_acq_peaks_count.restype = C.c_size_t
     lib.gpsx_acq_keys_count.restype = C.c_size_t
     lib.gpsx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
@@ -71,6 +73,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_acq_grid_dev.argtypes = [C.c_void_p, C.POINTER(AcqGrid), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gpsx_acq_grid.argtypes = [C.c_void_p, C.POINTER(AcqGrid), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gpsx_acq_grid_async.argtypes = lib.gpsx_acq_grid.argtypes
     lib.gpsx_acq_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gpsx_track_epl_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_track_epl_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

@@ -28,14 +28,16 @@ int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
   const int slots = (n_prn + kAcqGroup - 1) / kAcqGroup * kAcqGroup;
   if (slots > ctx->grid_slots) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->d_grid_prns) {
-      (void)hipFree(ctx->d_grid_prns);
-      (void)hipFree(ctx->d_grid_chips);
-      (void)hipFree(ctx->d_grid_bits);
-      (void)hipFree(ctx->d_grid_cw);
-      (void)hipFree(ctx->d_grid_cw8);
+    // free + null first: a failed hipMalloc below must not leave dangling members for the next call / gpsx_destroy
+    void **members[] = {(void **)&ctx->d_grid_prns, (void **)&ctx->d_grid_chips, (void **)&ctx->d_grid_bits,
+                        (void **)&ctx->d_grid_cw, (void **)&ctx->d_grid_cw8};
+    for (void **m : members) {
+      if (*m)
+        (void)hipFree(*m);
+      *m = nullptr;
     }
     ctx->grid_slots = 0;
+    ctx->grid_prns.clear();
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_prns, slots));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_chips, (size_t)slots * 1024));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_bits, (size_t)slots * 32 * 4));
@@ -74,6 +76,12 @@ int check_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, int n_blocks)
   for (int i = 0; i < g->n_prn; i++)
     if (g->prns[i] < 1 || g->prns[i] > GPSX_MAX_PRN)
       return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
+  if (g->n_dopp > 1 && g->dopp_step_hz <= 0)
+    return fail(ctx, GPSX_EINVAL, "dopp_step_hz must be positive when n_dopp > 1");
+  // the kernels index units, keys and peaks with 32-bit integers
+  const long long n_keys = (long long)g->n_search * g->n_prn * g->n_dopp;
+  if (n_keys * 8 > 0x7FFFFFFFLL)
+    return fail(ctx, GPSX_EINVAL, "n_search * n_prn * n_dopp too large for one call (split the searches)");
   const long f_lo = (long)GPSX_IF_HZ + g->dopp_min_hz;
   const long f_hi = f_lo + (long)(g->n_dopp - 1) * g->dopp_step_hz;
   if (f_lo <= 0 || f_hi <= 0 || f_lo >= 16368000 || f_hi >= 16368000)
@@ -100,6 +108,8 @@ const char *gpsx_strerror(int code)
 }
 
 const char *gpsx_last_error(const gpsx_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char *gpsx_last_kernel(const gpsx_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int gpsx_create(gpsx_ctx **out, int device, void *stream)
 {
@@ -134,7 +144,6 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
   if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
     ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad
                 : std::strcmp(a, "dot8") == 0 ? kAlgoDot8
-                : std::strcmp(a, "ds") == 0   ? kAlgoDs
                                               : kAlgoPoly;
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
@@ -183,7 +192,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
-                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc, ctx->d_energy, ctx->d_ds_tables, ctx->d_ds_work};
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc, ctx->d_energy};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
@@ -281,6 +290,8 @@ int gpsx_memcpy_d2h(gpsx_ctx *ctx, void *dst, const void *src, size_t bytes)
 int gpsx_event_create(gpsx_ctx *ctx, void **event)
 {
   if (int rc = use_device(ctx)) return rc;
+  if (!event)
+    return fail(ctx, GPSX_EINVAL, "null event pointer");
   hipEvent_t e;
   HIPCHK(ctx, hipEventCreate(&e));
   *event = e;
@@ -356,75 +367,6 @@ int ensure_acc(gpsx_ctx *ctx, size_t n_peaks)
   return GPSX_OK;
 }
 
-// The Doppler-shared kernel.  Returns false when this grid cannot use it (the caller falls through to k_acq_poly);
-// true with *rc set otherwise.
-bool acq_grid_ds(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const AcqParams &prm, const uint8_t *d_if, gpsx_peak_t *d_peaks,
-                 int *rc)
-{
-  auto run = [&]() -> int {
-    if (ctx->ds_grid[0] != g->dopp_min_hz || ctx->ds_grid[1] != g->dopp_step_hz || ctx->ds_grid[2] != g->n_dopp ||
-        !ctx->d_ds_tables) {
-      std::vector<uint32_t> rows;
-      std::vector<int32_t> cst0;
-      ctx->ds_ok = build_ds_tables(g->dopp_min_hz, g->dopp_step_hz, g->n_dopp, rows, cst0);
-      ctx->ds_grid[0] = g->dopp_min_hz;
-      ctx->ds_grid[1] = g->dopp_step_hz;
-      ctx->ds_grid[2] = g->n_dopp;
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->d_ds_tables)
-        (void)hipFree(ctx->d_ds_tables);
-      ctx->d_ds_tables = nullptr;
-      if (!ctx->ds_ok)
-        return GPSX_OK;
-      ctx->ds_rows_off = 0;
-      ctx->ds_cst0_off = rows.size();
-      std::vector<uint32_t> blob(rows);
-      for (int32_t v : cst0)
-        blob.push_back((uint32_t)v);
-      HIPCHK(ctx, hipMalloc((void **)&ctx->d_ds_tables, blob.size() * 4));
-      HIPCHK(ctx, hipMemcpy(ctx->d_ds_tables, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
-    }
-    if (!ctx->ds_ok)
-      return GPSX_OK;
-    const size_t pairs = (size_t)g->n_search * g->n_dopp;
-    const size_t hdr_dw = pairs * 4, rec_dw = pairs * 2 * kDsRecDwords, xpl_dw = (size_t)g->n_search * 16 * 32;
-    const size_t etab_dw = pairs * 16 * 4;
-    if (hdr_dw + rec_dw + xpl_dw + etab_dw > ctx->ds_work_dwords) {
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->d_ds_work)
-        (void)hipFree(ctx->d_ds_work);
-      ctx->d_ds_work = nullptr;
-      ctx->ds_work_dwords = 0;
-      HIPCHK(ctx, hipMalloc((void **)&ctx->d_ds_work, (hdr_dw + rec_dw + xpl_dw + etab_dw) * 4));
-      ctx->ds_work_dwords = hdr_dw + rec_dw + xpl_dw + etab_dw;
-    }
-    const size_t n_peaks = gpsx_acq_peaks_count(g);
-    if (int e = ensure_acc(ctx, n_peaks)) return e;
-    DsParams P{};
-    P.n_search = g->n_search;
-    P.n_prn = g->n_prn;
-    P.n_dopp = g->n_dopp;
-    P.n_chunks = (g->n_dopp + kDsDopplersPerWave - 1) / kDsDopplersPerWave;
-    P.win_start = g->win_start;
-    P.win_stop = g->win_stop;
-    P.rows = ctx->d_ds_tables + ctx->ds_rows_off;
-    P.cst0 = reinterpret_cast<const int32_t *>(ctx->d_ds_tables + ctx->ds_cst0_off);
-    P.hdr = ctx->d_ds_work;
-    P.rec = ctx->d_ds_work + hdr_dw;
-    P.xpl = ctx->d_ds_work + hdr_dw + rec_dw;
-    P.etab = reinterpret_cast<uint4 *>(ctx->d_ds_work + hdr_dw + rec_dw + xpl_dw);   // 16-byte aligned: all sizes are multiples of 4 dwords
-    P.chipbits = ctx->d_grid_bits;
-    P.keyacc = ctx->d_acc;
-    P.sumacc = ctx->d_acc + n_peaks;
-    launch_acq_ds(ctx->stream, P, d_if, prm.if_format, prm.search_stride_blocks, g->dopp_min_hz, g->dopp_step_hz, n_peaks,
-                  d_peaks);
-    LAUNCHCHK(ctx, "k_acq_ds");
-    return GPSX_OK;
-  };
-  *rc = run();
-  return *rc != GPSX_OK || ctx->ds_ok;
-}
-
 }  // namespace
 
 int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_blocks, int n_blocks,
@@ -470,20 +412,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.energy = d_energy;
   prm.cnt = d_cnt;
   const bool inspect = d_per_ms || d_energy || d_cnt;
-  const bool fine = (ctx->algo == kAlgoPoly || ctx->algo == kAlgoDs) && n_bits == 8 && !inspect;
-  if (fine && ctx->algo == kAlgoDs && g->n_ms == 1 && shard_count == 1) {
-    int rc = GPSX_OK;
-    if (acq_grid_ds(ctx, g, prm, static_cast<const uint8_t *>(d_if_blocks), d_peaks, &rc)) {
-      if (rc != GPSX_OK)
-        return rc;
-      if (d_keys) {
-        launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
-                        shard_count);
-        LAUNCHCHK(ctx, "k_acq_keys");
-      }
-      return GPSX_OK;
-    }
-  }
+  const bool fine = ctx->algo == kAlgoPoly && n_bits == 8 && !inspect;
   bool poly = fine;
   bool block_parallel = false;
   if (poly && g->n_ms > 1) {
@@ -525,7 +454,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
       HIPCHK(ctx, hipMalloc((void **)&ctx->d_acc, 2 * n_peaks * sizeof(uint32_t)));
       ctx->acc_entries = n_peaks;
     }
-    launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
+    ctx->last_kernel = launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
                     ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1,
                     ctx->d_energy, block_parallel, ctx->seg_force);
     LAUNCHCHK(ctx, "k_acq_poly");
@@ -534,6 +463,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     launch_acq(ctx->stream, kAcqGroup, algo, local_units, prm, static_cast<const uint8_t *>(d_if_blocks),
                algo == kAlgoDot8 ? ctx->d_grid_cw8 : ctx->d_grid_cw, ctx->d_grid_bits);
     LAUNCHCHK(ctx, "k_acq");
+    ctx->last_kernel = algo == kAlgoSad ? (g->n_ms > 1 ? "k_acq<8,true,sad>" : "k_acq<8,false,sad>")
+                                        : (g->n_ms > 1 ? "k_acq<8,true,dot8>" : "k_acq<8,false,dot8>");
   }
   if (d_keys) {
     launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
@@ -543,8 +474,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   return GPSX_OK;
 }
 
-int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks, gpsx_peak_t *peaks,
-                  int64_t *keys)
+int gpsx_acq_grid_async(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks, gpsx_peak_t *peaks,
+                        int64_t *keys)
 {
   if (int rc = use_device(ctx)) return rc;
   if (int rc = check_grid(ctx, g, n_blocks)) return rc;
@@ -567,6 +498,13 @@ int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blo
   HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_peaks * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
   if (keys)
     HIPCHK(ctx, hipMemcpyAsync(keys, d_keys, n_keys * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  return GPSX_OK;   // stream order protects the arena: the next call's copies and launches queue behind these
+}
+
+int gpsx_acq_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const uint8_t *if_blocks, int n_blocks, gpsx_peak_t *peaks,
+                  int64_t *keys)
+{
+  if (int rc = gpsx_acq_grid_async(ctx, g, if_blocks, n_blocks, peaks, keys)) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return GPSX_OK;
 }

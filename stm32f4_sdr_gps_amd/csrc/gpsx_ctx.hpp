@@ -32,6 +32,7 @@ struct gpsx_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
+  const char *last_kernel = "";      // dominant kernel of the last acquisition launch (gpsx_last_kernel)
   hipDeviceProp_t prop;
 
   // tables for every PRN, slot == prn (slot 0 is the empty code): K1 output
@@ -47,14 +48,6 @@ struct gpsx_ctx {
   int ms_mode = 0;                   // $GPSX_ACQ_MS_MODE = walk | blocks: force one multi-block form (tests, A/B); 0 = by size
   uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
   size_t energy_bytes = 0;
-  // Doppler-shared kernel: boundary tables of the last Doppler grid, per-(search, Doppler) prepared data (grow-only)
-  int ds_grid[3] = {0, 0, 0};        // dopp_min_hz, dopp_step_hz, n_dopp the tables were built for
-  bool ds_ok = false;
-  uint32_t *d_ds_tables = nullptr;
-  size_t ds_rows_off = 0, ds_cst0_off = 0;
-  uint32_t *d_ds_work = nullptr;
-  size_t ds_work_dwords = 0;
-
   // grouped tables for the PRN list of the last grid call
   std::vector<uint8_t> grid_prns;
   int grid_slots = 0;

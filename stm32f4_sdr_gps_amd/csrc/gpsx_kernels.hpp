@@ -11,13 +11,13 @@
 namespace gpsx {
 
 constexpr int kAcqGroup = 8;      // PRNs per accumulator set (one main-loop pass) in the grid kernel
-constexpr int kSuperGroups = 2;   // groups per sharding unit: a unit is (search, 16 PRNs, Doppler bin)
+constexpr int kSuperGroups = 1;   // groups per sharding unit: a unit is (search, 8-PRN group, Doppler bin) -- 84 units per
+                                  // 32 PRN x 21 Doppler search, SURVEY.md 8(e)
 constexpr int kCodeWords = 256;   // 4-chip code words per PRN (1023 chips + 1 masked pad)
 constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window sum inside 32 bits
 constexpr int kAlgoSad = 0;       // main loop: v_msad_u8 on 8-bit block sums, 4 chips per instruction
 constexpr int kAlgoDot8 = 1;      // main loop: v_dot8_u32_u4 on 4-bit block sums, 8 chips per instruction
 constexpr int kAlgoPoly = 2;      // fine grid only: polyphase recurrence across the 16 sample offsets, AND + popcount (default)
-constexpr int kAlgoDs = 3;        // fine grid only: the same recurrence with the bit-plane correlations shared by all Doppler bins
 
 // One search = one workgroup pass: `count` (<= group size) consecutive code-table slots, one carrier frequency,
 // one replica bit shift, n_ms consecutive blocks.
@@ -64,7 +64,8 @@ void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqP
 // acq_poly_energy_bytes(local_units) of scratch for the running per-hypothesis sums between blocks.  d_keyacc / d_sumacc: two
 // u32 scratch planes of n_peaks entries, used (zeroed, merged with atomics, converted into d_peaks) only when the launch
 // is split into two 8-offset workgroups per chip; the one-workgroup-per-chip form writes d_peaks directly.
-void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
+// Returns the name of the dominant kernel it launched (for gpsx_last_kernel / bench reports).
+const char *launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
                      gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel,
                      int seg_force);
@@ -80,26 +81,6 @@ inline size_t acq_poly_energy_bytes(long local_units)
 void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks);
 
-// Doppler-shared polyphase variant (k_acq_ds.hip): phase_mode FINE, n_ms == 1, no sharding, no inspection outputs.
-constexpr int kDsDopplersPerWave = 21;   // <= 24 (row format)
-constexpr int kDsRecDwords = 1032;   // one alignment copy of the interleaved wiped bytes of a (search, Doppler)
-struct DsParams {
-  int32_t n_search, n_prn, n_dopp, n_chunks;
-  int32_t win_start, win_stop;
-  const uint32_t *rows;       // [n_chunks][6 plane classes][33][16]: carrier sign changes of the chunk's bins per
-                              // 32-chip word, + the K = 1022 end terms
-  const int32_t *cst0;        // [n_dopp][2]: constant term of sum_j H_j
-  uint32_t *hdr;              // [n_search][n_dopp][4]: pop(D_I), pop(D_Q), first byte of D_I, D_Q
-  uint32_t *rec;              // [n_search][n_dopp][2][kDsRecDwords]: (I, Q) byte pairs, two alignments
-  uint32_t *xpl;              // [n_search][16][32]: raw polyphase bit planes
-  uint4 *etab;                // [n_search][n_dopp][16 offsets]: per-offset uniforms of the epilogue
-  const uint32_t *chipbits;   // [slots][32]
-  uint32_t *keyacc, *sumacc;  // [n_peaks] each, contiguous
-};
-// false: some bin has two carrier sign changes inside one 32-chip word (|Doppler| >= ~8 kHz) -- use another kernel
-bool build_ds_tables(int dopp_min_hz, int dopp_step_hz, int n_dopp, std::vector<uint32_t> &rows, std::vector<int32_t> &cst0);
-void launch_acq_ds(hipStream_t s, const DsParams &prm, const uint8_t *d_if, int if_format, int search_stride_blocks,
-                   int dopp_min_hz, int dopp_step_hz, size_t n_peaks, gpsx_peak_t *d_peaks);
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
                      int n_dopp, int n_bits, int shard_index, int shard_count);

@@ -620,37 +620,19 @@ static void launch_acq_t(hipStream_t s, int n_workgroups, const AcqParams &prm, 
   }
 }
 
-int acq_groups_per_workgroup(int group, const AcqParams &prm, long local_units)
-{
-  // Two PRN groups per workgroup halve the per-block preamble; worth it while the launch still has several waves of
-  // workgroups per CU slot (256 CUs x 3 resident) and only in the plain single-block production instantiation.
-  const bool plain = group == kAcqGroup && prm.n_ms == 1 && !prm.per_ms && !prm.energy && !prm.cnt && !prm.jobs;
-  const long wgs_if_two = local_units * prm.n_bits;
-  static const char *force = std::getenv("GPSX_ACQ_GPW");   // "1" / "2": A/B measurements
-  if (force && plain && prm.n_groups >= 2)
-    return force[0] == '2' ? 2 : 1;
-  return (plain && prm.n_groups >= 2 && wgs_if_two >= 4 * 768) ? 2 : 1;
-}
-
 void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqParams &prm, const uint8_t *d_if,
                 const uint32_t *d_cw, const uint32_t *d_chipbits)
 {
   if (local_units <= 0)
     return;
   if (group == kAcqGroup) {
-    const int gpw = acq_groups_per_workgroup(group, prm, local_units);
-    const int n_wg = (int)(local_units * prm.n_bits * (kSuperGroups / gpw));
-    if (algo == kAlgoDot8) {
-      if (gpw == 2)
-        launch_acq_t<kAcqGroup, kAlgoDot8, 2>(s, n_wg, prm, d_if, d_cw, d_chipbits);
-      else
-        launch_acq_t<kAcqGroup, kAlgoDot8, 1>(s, n_wg, prm, d_if, d_cw, d_chipbits);
-    } else {
-      if (gpw == 2)
-        launch_acq_t<kAcqGroup, kAlgoSad, 2>(s, n_wg, prm, d_if, d_cw, d_chipbits);
-      else
-        launch_acq_t<kAcqGroup, kAlgoSad, 1>(s, n_wg, prm, d_if, d_cw, d_chipbits);
-    }
+    // (a two-groups-per-workgroup form, sharing the preamble between 16 PRNs, measured neutral in round 1 and went
+    //  when the sharding unit became one 8-PRN group)
+    const int n_wg = (int)(local_units * prm.n_bits * kSuperGroups);
+    if (algo == kAlgoDot8)
+      launch_acq_t<kAcqGroup, kAlgoDot8, 1>(s, n_wg, prm, d_if, d_cw, d_chipbits);
+    else
+      launch_acq_t<kAcqGroup, kAlgoSad, 1>(s, n_wg, prm, d_if, d_cw, d_chipbits);
   } else {   // job list: one PRN, one workgroup per job
     if (algo == kAlgoDot8)
       launch_acq_t<1, kAlgoDot8, 1>(s, (int)local_units, prm, d_if, d_cw, d_chipbits);

@@ -592,13 +592,13 @@ void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t
                      d_peaks);
 }
 
-void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
+const char *launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
                      const uint32_t *d_chipbits, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
                      gpsx_peak_t *d_peaks, bool peaks_are_zero, uint32_t *d_energy, bool block_parallel,
                      int seg_force)
 {
   if (local_units <= 0 || n_peaks == 0)
-    return;
+    return "";
   if (prm.n_ms > 1 && block_parallel) {
     // Few multi-block searches: a workgroup per (unit, block) instead of per unit walking its blocks, the blocks'
     // magnitudes through HBM (d_energy holds them as u16), one more small kernel to sum and search them.  Eight-offset
@@ -612,14 +612,14 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
                          d_cw8, d_chipbits, d_keyacc, d_sumacc, d_peaks, d_energy);
     hipLaunchKernelGGL(k_acq_vals_search, dim3((unsigned)(n_peaks / 8)), dim3(kThreads), 0, s, prm,
                        reinterpret_cast<const uint16_t *>(d_energy), d_peaks);
-    return;
+    return wg16 >= 6 * 768 ? "k_acq_poly<8,16,2>" : "k_acq_poly<8,8,2>";
   }
   if (prm.n_ms > 1) {
     // Non-coherent integration: always one workgroup per chip -- the energies of a (PRN, Doppler) pair then have one
     // owner, which walks the blocks itself and keeps the running sums in its own 64 KB-per-PRN slice of d_energy.
     hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, kPolyMulti>), dim3((unsigned)(local_units * kSuperGroups)), dim3(kThreads), 0,
                        s, prm, d_if, d_cw8, d_chipbits, d_keyacc, d_sumacc, d_peaks, d_energy);
-    return;
+    return "k_acq_poly<8,16,1>";
   }
   // One workgroup per chip (16 offsets: one direct step + 15 recurrence steps; results merged in LDS and written once)
   // when that still leaves several waves of workgroups per CU slot; otherwise two (8 offsets each) or, for launches of
@@ -631,7 +631,7 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
     (void)peaks_are_zero;   // units of other shards keep whatever the caller zeroed
     hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 16, kPolySingle>), dim3((unsigned)wg16), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
-    return;
+    return "k_acq_poly<8,16,0>";
   }
   (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
   if (seg == 4)
@@ -642,6 +642,7 @@ void launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, cons
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
   hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
                      d_peaks);
+  return seg == 4 ? "k_acq_poly<8,4,0>" : "k_acq_poly<8,8,0>";
 }
 
 }  // namespace gpsx

@@ -1,6 +1,7 @@
 """Index arithmetic of the multi-GPU acquisition sweep (host side; mirrors k_acq / k_acq_keys in csrc/k_acq_grid.hip).
 
-A work UNIT is one (search, super group of 16 PRNs, Doppler bin): unit = (search * n_groups + prn_idx // 16) * n_dopp + dopp_idx.
+A work UNIT is one (search, group of 8 PRNs, Doppler bin): unit = (search * n_groups + prn_idx // 8) * n_dopp + dopp_idx
+(84 units for one 32 PRN x 21 Doppler search: 11 or 10 per rank on 8 GPUs).
 Rank r of `world` computes the units with unit % world == r (all 8 replica bit shifts of a unit stay together, so the
 best fine phase of a (search, PRN, Doppler) pair is decided locally).  Every rank fills its entries of a zero-initialised
 int64 table key[search, prn, dopp] = (energy << 14) | (16383 - fine_phase); ONE all-reduce(MAX) merges the ranks.  The
@@ -10,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-GROUP = 16
+GROUP = 8
 
 
 def n_groups(n_prn: int) -> int:

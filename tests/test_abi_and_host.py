@@ -109,8 +109,20 @@ def test_sharding_partition_and_key_packing():
     assert int(e[0]) == 9 and int(f[0]) == 8 * 4 + 3
     # weak-scaling balance of the bench default (16 searches per GPU): every rank gets the same number of units
     for world in (1, 2, 4, 8):
-        counts = [int(sharding.owned_mask(16 * world, 32, 21, r, world)[:, ::16, :].sum()) for r in range(world)]
-        assert len(set(counts)) == 1 and counts[0] == 16 * 2 * 21
+        counts = [int(sharding.owned_mask(16 * world, 32, 21, r, world)[:, ::8, :].sum()) for r in range(world)]
+        assert len(set(counts)) == 1 and counts[0] == 16 * 4 * 21
+    # BASELINE.json configs[3] as written: ONE 32 PRN x 21 Doppler search on 8 GPUs = 84 units, 11 or 10 per rank
+    # (SURVEY.md 8(e)); a unit is one 8-PRN group x one Doppler bin
+    assert sharding.GROUP == 8 and int(sharding.unit_table(1, 32, 21).max()) == 83
+    counts = [int(sharding.owned_mask(1, 32, 21, r, 8)[:, ::8, :].sum()) for r in range(8)]
+    assert sorted(counts) == [10, 10, 10, 10, 11, 11, 11, 11]
+    assert max(counts) / (84 / 8) < 1.05
+    # the ownership rule written out by hand for a small grid: unit = (search * n_groups + prn // 8) * n_dopp + dopp
+    m = sharding.owned_mask(2, 10, 3, 1, 3)
+    for s in range(2):
+        for p in range(10):
+            for d in range(3):
+                assert m[s, p, d] == (((s * 2 + p // 8) * 3 + d) % 3 == 1)
 
 
 def test_public_headers_are_plain_c(tmp_path):
@@ -122,3 +134,53 @@ def test_public_headers_are_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only",
                            "-x", "c++", str(src)])
+
+
+def test_reference_step_sources_relink_against_libgpsx_unmodified(lib_path, tmp_path):
+    """INTEGRATION.md tier 1, "relink, no source change": the reference's own acquisition.c and tracking.c, compiled
+    where they lie, link against libgpsx.so, and every correlator primitive they call (PM/GPS/gps_misc.h:195-216) and
+    the three scratch buffers (PM/GPS/common_ram.h:12-14) resolve to the library -- not to a stray reference object.
+    Container-only (needs /root/reference); nothing is copied and nothing is run (no GPU here)."""
+    ref = "/root/reference/Firmware/project_main"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    inc = [f"-I{ref}", f"-I{ref}/GPS", f"-I{ref}/GPS/RTK"]
+    objs = []
+    for name in ("acquisition", "tracking"):
+        obj = tmp_path / f"{name}.o"
+        subprocess.check_call(["gcc", "-w", "-O2", "-fno-strict-aliasing", "-c", *inc, f"{ref}/GPS/{name}.c", "-o", str(obj)])
+        objs.append(str(obj))
+    main_c = tmp_path / "main.c"
+    main_c.write_text(
+        "#include <stdint.h>\n#include \"gps_misc.h\"\n#include \"acquisition.h\"\n#include \"tracking.h\"\n"
+        "gps_ch_t ch[GPS_SAT_CNT]; uint8_t blk[2048];\n"
+        "int main(void){ gps_fill_summ_table(); gps_channell_prepare(&ch[0]); acquisition_start_channel(&ch[0]);\n"
+        " acquisition_process(ch, blk); gps_tracking_process(&ch[0], blk, 0); return 0; }\n")
+    exe = tmp_path / "relinked"
+    libdir = os.path.dirname(lib_path)
+    subprocess.check_call(["gcc", "-w", *inc, str(main_c), *objs, "-o", str(exe), f"-L{libdir}", "-lgpsx", "-lm",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    undefined = {l.split()[-1] for l in subprocess.check_output(["nm", "-u", str(exe)], text=True).splitlines() if l.strip()}
+    lib_defined = {l.split()[-1] for l in subprocess.check_output(["nm", "-D", "--defined-only", lib_path], text=True).splitlines()
+                   if l.strip()}
+    primitives = {"gps_fill_summ_table", "gps_channell_prepare", "gps_correlation8", "gps_correlation_iq",
+                  "correlation_search", "gps_shift_to_zero_freq", "gps_shift_to_zero_freq_track",
+                  "gps_generate_prn_data2", "gps_rewind_if_phase"}
+    buffers = {"tmp_prn_data", "tmp_data_i", "tmp_data_q"}
+    strip = lambda s: s.split("@")[0]
+    undefined = {strip(s) for s in undefined}
+    assert primitives <= undefined, sorted(primitives - undefined)          # imported, not defined by the reference objects
+    # data objects used from an executable are bound by copy relocation: undefined in the reference's objects, a
+    # R_X86_64_COPY against the library's definition in the linked program
+    obj_undef = {strip(l.split()[-1]) for o in objs for l in subprocess.check_output(["nm", "-u", o], text=True).splitlines()
+                 if l.strip()}
+    assert buffers <= obj_undef, sorted(buffers - obj_undef)
+    relocs = subprocess.check_output(["readelf", "-r", "-W", str(exe)], text=True)
+    for b in buffers:
+        assert re.search(r"R_X86_64_(COPY|GLOB_DAT)\s+\S+\s+" + b + r"\b", relocs), b
+    assert primitives | buffers <= lib_defined
+    # the step logic in this executable IS the reference's (its objects win over the library's same-named exports)
+    own = {l.split()[-1] for l in subprocess.check_output(["nm", "--defined-only", str(exe)], text=True).splitlines() if l.strip()}
+    assert {"acquisition_process", "gps_tracking_process"} <= own
+    needed = subprocess.check_output(["readelf", "-d", str(exe)], text=True)
+    assert "libgpsx.so" in needed

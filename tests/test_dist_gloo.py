@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc = pyoracle.Oracle()
     n_search, n_dopp = 2, 3
-    prns = np.array([5, 14, 20, 30, 1, 2, 3, 4, 6, 7], np.uint8)     # 10 PRNs -> 2 groups
+    prns = np.array([5, 14, 20, 30, 1, 2, 3, 4, 6, 7], np.uint8)     # 10 PRNs -> 2 groups of 8: both terms of the ownership rule are exercised
     blocks = synth.default_four_sv(n_search, seed=7)
     keys = np.zeros((n_search, len(prns), n_dopp), np.int64)
     mine = sharding.owned_mask(n_search, len(prns), n_dopp, rank, world)

@@ -12,14 +12,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_sharded_sweep_equals_unsharded():
+@pytest.mark.parametrize("n_ms, searches, port, ms_mode", [(10, 2, 29571, "blocks"), (1, 4, 29572, ""), (10, 4, 29573, "walk")])
+def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode):
+    """n_ms = 10 is what the driver's N > 1 runs execute (BASELINE.json configs[3]; bench.py's default there), in both
+    multi-block forms: a workgroup per (unit, block), and -- what the 64-searches-per-GPU runs take -- a workgroup
+    walking its unit's ten blocks; n_ms = 1 is the coherent grid.  GPSX_BENCH_VERIFY compares the merged key table with
+    an unsharded sweep of the same captures."""
     env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1")
+    if ms_mode:
+        env["GPSX_ACQ_MS_MODE"] = ms_mode
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--searches", "4", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--searches", str(searches), "--no-cpu-baseline"] + (["--n-ms", "1"] if n_ms == 1 else [])
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "VERIFY sharded == unsharded" in res.stdout
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 1e9
-    assert line["config"]["hypotheses_per_step"] == 2 * 4 * 32 * 21 * 16368
+    assert line["config"]["blocks_per_search"] == n_ms
+    assert line["config"]["hypotheses_per_step"] == 2 * searches * n_ms * 32 * 21 * 16368
+    assert 0 < line["roofline"]["frac"] <= 1.0
+    if n_ms > 1:
+        assert line["single_search"]["ms_per_search"] > 0
