@@ -52,6 +52,29 @@ __global__ __launch_bounds__(256) void k_rate(u32* out, u32 seed_a, u32 seed_b)
       if (OP == 14) { acc[i] = acc[i] * a[i] + b; }                                          // v_mad_u32_u24 / mul_lo
       if (OP == 15) { acc[i] = __builtin_amdgcn_sad_u16(a[i], b, acc[i]); }
       if (OP == 16) { acc[i] = (acc[i] + a[i]) ^ b; }                                        // add + xor (2 ops) or v_add3/xad
+      // round 2: exact instructions by inline asm, to price the grid kernels' instruction mix (which ops are 2-cycle?)
+      if (OP == 17) { u32 t; asm volatile("v_and_b32 %0, %1, %2" : "=v"(t) : "s"(b), "v"(a[i]));
+                      asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i]) : "v"(t)); }   // the polyphase main-loop pair
+      if (OP == 18) { asm volatile("v_and_b32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 19) { asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 20) { asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 21) { asm volatile("v_mad_i32_i24 %0, %1, -2, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 22) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 23) { asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 24) { asm volatile("v_sqrt_f32 %0, %0" : "+v"(acc[i])); }
+      if (OP == 25) { asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(acc[i])); }
+      if (OP == 26) { asm volatile("v_max_u32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 27) { asm volatile("v_lshl_or_b32 %0, %0, 11, %1" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 28) { asm volatile("v_add3_u32 %0, %1, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 29) { asm volatile("v_bfe_u32 %0, %0, %1, 8" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 30) { asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 31) { asm volatile("v_add_u32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 32) { asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(acc[i])); }
+      if (OP == 33) { asm volatile("v_sub_u32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i]));
+                      asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }  // simple op beside bcnt
+      if (OP == 34) { asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(acc[i]) : "v"(a[i]), "s"(b)); }  // SGPR shift
+      if (OP == 35) { asm volatile("v_max_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
+      if (OP == 36) { asm volatile("v_pk_add_u16 %0, %1, %0" : "+v"(acc[i]) : "v"(a[i])); }
     }
     b += 0x01010101u;
   }
@@ -106,5 +129,25 @@ int main()
   run<9>("v_perm_b32", 1, d_out);
   run<14>("mul+add u32", 1, d_out);
   run<16>("add+xor", 2, d_out);
+  run<17>("v_and(sgpr)+v_bcnt(acc)", 2, d_out);
+  run<18>("v_and_b32", 1, d_out);
+  run<19>("v_bcnt_u32_b32 (acc)", 1, d_out);
+  run<33>("v_sub_u32+v_bcnt", 2, d_out);
+  run<31>("v_add_u32", 1, d_out);
+  run<20>("v_cndmask_b32 (vcc)", 1, d_out);
+  run<21>("v_mad_i32_i24", 1, d_out);
+  run<28>("v_add3_u32", 1, d_out);
+  run<27>("v_lshl_or_b32", 1, d_out);
+  run<29>("v_bfe_u32", 1, d_out);
+  run<26>("v_max_u32", 1, d_out);
+  run<34>("v_alignbit_b32 (sgpr shift)", 1, d_out);
+  run<30>("v_mov_b32_dpp row_shr", 1, d_out);
+  run<22>("v_mul_f32", 1, d_out);
+  run<23>("v_fma_f32", 1, d_out);
+  run<35>("v_max_f32", 1, d_out);
+  run<24>("v_sqrt_f32", 1, d_out);
+  run<25>("v_cvt_f32_i32", 1, d_out);
+  run<32>("v_cvt_u32_f32", 1, d_out);
+  run<36>("v_pk_add_u16", 1, d_out);
   return 0;
 }
