@@ -141,8 +141,9 @@ typedef struct {
   int32_t        n_dopp;
   int32_t        phase_mode;           /* GPSX_PHASES_BYTE (replica shift 0 only) or GPSX_PHASES_FINE (0..7)   */
   int32_t        win_start, win_stop;  /* byte-offset window [start, stop); 0, 2046 for a full search           */
-  int32_t        shard_index;          /* multi-GPU: this process computes work units u with                    */
-  int32_t        shard_count;          /*   u % shard_count == shard_index; 0/1 for a single GPU                */
+  int32_t        shard_index;          /* multi-GPU: of the U = n_search * n_dopp * ceil(n_prn / 8) work units      */
+  int32_t        shard_count;          /*   u = (search * n_dopp + dopp) * ceil(n_prn / 8) + prn_idx / 8 this process  */
+                                       /*   computes the run [index * U / count, (index + 1) * U / count); 0/1: all    */
 } gpsx_acq_grid_t;
 
 /* number of replica bit shifts a phase_mode implies (1 or 8) */
@@ -198,7 +199,7 @@ static inline uint32_t gpsx_key_fine_phase(int64_t key) { return 16383u - (uint3
 /* ---- the sharded sweep inside ONE process (a C host has no torch.distributed): a group of contexts, one per GPU,
  *      joined by RCCL communicators (ncclCommInitAll; librccl is loaded when the first group is created).
  *      gpsx_acq_grid_sharded = what each rank of `bench.py --gpus N` does, for all the group's devices at once:
- *      context i sweeps the grid units with unit % n == i (g's own shard fields are ignored) on its own copy of the
+ *      context i sweeps the run of grid units [i * U / n, (i + 1) * U / n) (g's own shard fields are ignored) on its own copy of the
  *      captures, then ONE all-reduce(MAX) of the packed keys leaves the merged table in every d_keys[i].  Everything is
  *      enqueued on the contexts' streams; synchronize the contexts (or read through gpsx_memcpy_d2h) before using it. */
 typedef struct gpsx_group gpsx_group;

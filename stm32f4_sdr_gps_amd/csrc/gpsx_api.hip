@@ -30,7 +30,8 @@ int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     // free + null first: a failed hipMalloc below must not leave dangling members for the next call / gpsx_destroy
     void **members[] = {(void **)&ctx->d_grid_prns, (void **)&ctx->d_grid_chips, (void **)&ctx->d_grid_bits,
-                        (void **)&ctx->d_grid_cw, (void **)&ctx->d_grid_cw8};
+                        (void **)&ctx->d_grid_cw, (void **)&ctx->d_grid_cw8, (void **)&ctx->d_grid_mx_a,
+                        (void **)&ctx->d_grid_mx_t};
     for (void **m : members) {
       if (*m)
         (void)hipFree(*m);
@@ -43,6 +44,9 @@ int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_bits, (size_t)slots * 32 * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_cw, (size_t)slots * kCodeWords * 4));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_cw8, (size_t)slots * (kCodeWords / 2) * 4));
+    const size_t sets = (size_t)(slots + 31) / 32;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_mx_a, sets * 4096 * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_grid_mx_t, sets * 1032 * 4));
     ctx->grid_slots = slots;
   }
   std::vector<uint8_t> padded(slots, 0);
@@ -52,6 +56,8 @@ int ensure_grid_tables(gpsx_ctx *ctx, const uint8_t *prns, int n_prn)
   launch_build_codes(ctx->stream, ctx->d_grid_prns, slots, kAcqGroup, ctx->d_grid_chips, ctx->d_grid_bits,
                      ctx->d_grid_cw, ctx->d_grid_cw8);
   LAUNCHCHK(ctx, "k_build_codes");
+  launch_build_mx_tables(ctx->stream, ctx->d_grid_bits, slots, ctx->d_grid_mx_a, ctx->d_grid_mx_t);
+  LAUNCHCHK(ctx, "k_build_mx_tables");
   ctx->grid_prns.assign(prns, prns + n_prn);
   return GPSX_OK;
 }
@@ -141,10 +147,13 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
   }
   if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
     ctx->ms_mode = std::strcmp(m, "walk") == 0 ? 1 : (std::strcmp(m, "blocks") == 0 ? 2 : 0);
-  if (const char *a = std::getenv("GPSX_ACQ_ALGO"))
+  if (const char *a = std::getenv("GPSX_ACQ_ALGO")) {
     ctx->algo = std::strcmp(a, "sad") == 0 ? kAlgoSad
                 : std::strcmp(a, "dot8") == 0 ? kAlgoDot8
-                                              : kAlgoPoly;
+                : std::strcmp(a, "poly") == 0 ? kAlgoPoly
+                                              : kAlgoMx;
+    ctx->algo_forced = true;
+  }
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -192,7 +201,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
-                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_arena, ctx->d_acc, ctx->d_energy};
+                  ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_grid_mx_a, ctx->d_grid_mx_t, ctx->d_arena, ctx->d_acc, ctx->d_energy};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
@@ -382,9 +391,9 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   const int shard_index = g->shard_count > 0 ? g->shard_index : 0;
   const int n_bits = gpsx_acq_bits(g->phase_mode);
   const int n_groups = (g->n_prn + kAcqGroup - 1) / kAcqGroup;
-  const int n_super = (n_groups + kSuperGroups - 1) / kSuperGroups;
-  const long n_units = (long)g->n_search * n_super * g->n_dopp;
-  const long local_units = n_units > shard_index ? (n_units - shard_index + shard_count - 1) / shard_count : 0;
+  const long n_units = (long)g->n_search * n_groups * g->n_dopp;
+  const long unit_lo = n_units * shard_index / shard_count, unit_hi = n_units * (shard_index + 1) / shard_count;
+  const long local_units = unit_hi - unit_lo;
   if (local_units * n_bits * kSuperGroups > 0x7FFFFFFFL)
     return fail(ctx, GPSX_EINVAL, "grid too large for one launch");
 
@@ -401,8 +410,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.dopp_min_hz = g->dopp_min_hz;
   prm.dopp_step_hz = g->dopp_step_hz;
   prm.n_bits = n_bits;
-  prm.shard_index = shard_index;
-  prm.shard_count = shard_count;
+  prm.unit_lo = (int32_t)unit_lo;
+  prm.unit_hi = (int32_t)unit_hi;
   prm.win_start = g->win_start;
   prm.win_stop = g->win_stop;
   prm.if_format = ctx->if_format;
@@ -412,7 +421,45 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.energy = d_energy;
   prm.cnt = d_cnt;
   const bool inspect = d_per_ms || d_energy || d_cnt;
-  const bool fine = ctx->algo == kAlgoPoly && n_bits == 8 && !inspect;
+  const bool fine = (ctx->algo == kAlgoPoly || ctx->algo == kAlgoMx) && n_bits == 8 && !inspect;
+  // The matrix-core kernel runs one 512-thread workgroup per (search, Doppler, 32 PRNs) and CU: it takes the launches
+  // that fill the chip a few times over (a forced $GPSX_ACQ_ALGO=mx takes them all); smaller ones -- a receiver's single
+  // acquisition call -- spread better as the polyphase VALU kernel's 8-PRN, 4/8/16-offset workgroups.
+  bool mx = fine && ctx->algo == kAlgoMx;
+  if (mx) {
+    const long clusters = acq_mx_clusters(prm);
+    if (!ctx->algo_forced && clusters < 2 * ctx->prop.multiProcessorCount)
+      mx = false;
+    if (mx && g->n_ms > 1) {
+      const size_t need = acq_mx_energy_bytes(clusters);
+      if (need > ctx->energy_bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_energy)
+          (void)hipFree(ctx->d_energy);
+        ctx->d_energy = nullptr;
+        ctx->energy_bytes = 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2 &&
+            hipMalloc((void **)&ctx->d_energy, need) == hipSuccess)
+          ctx->energy_bytes = need;
+        else {
+          (void)hipGetLastError();
+          mx = false;
+        }
+      }
+    }
+  }
+  if (mx) {
+    ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
+                                     ctx->d_grid_mx_t, d_peaks, ctx->d_energy);
+    LAUNCHCHK(ctx, "k_acq_mx");
+    if (d_keys) {
+      launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,
+                      (int)unit_hi);
+      LAUNCHCHK(ctx, "k_acq_keys");
+    }
+    return GPSX_OK;
+  }
   bool poly = fine;
   bool block_parallel = false;
   if (poly && g->n_ms > 1) {
@@ -467,8 +514,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
                                         : (g->n_ms > 1 ? "k_acq<8,true,dot8>" : "k_acq<8,false,dot8>");
   }
   if (d_keys) {
-    launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, shard_index,
-                    shard_count);
+    launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,
+                    (int)unit_hi);
     LAUNCHCHK(ctx, "k_acq_keys");
   }
   return GPSX_OK;

@@ -41,7 +41,9 @@ struct gpsx_ctx {
   uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
   uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
   int if_format = GPSX_IF_1BIT;
-  int algo = gpsx::kAlgoPoly;              // $GPSX_ACQ_ALGO = poly (default) | dot8 | sad, for A/B measurements
+  int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: matrix cores when the launch fills the chip, else
+                                           // poly) | poly | dot8 | sad, for A/B measurements
+  bool algo_forced = false;                // $GPSX_ACQ_ALGO was given: no size heuristics
   uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
   size_t acc_entries = 0;
   int seg_force = 0;                 // $GPSX_ACQ_SEG = 4 | 8 | 16: force the polyphase kernel's offsets per workgroup (tests, A/B)
@@ -56,6 +58,8 @@ struct gpsx_ctx {
   uint32_t *d_grid_bits = nullptr;
   uint32_t *d_grid_cw = nullptr;
   uint32_t *d_grid_cw8 = nullptr;
+  uint32_t *d_grid_mx_a = nullptr;   // matrix-core kernel: A fragments per 32-slot cluster
+  uint32_t *d_grid_mx_t = nullptr;   //                     transposed chip words
 
   // the per-millisecond tracking step as a captured graph (one launch instead of five runtime calls), for the last
   // (channel count, sample format) shapes it was called with; pinned staging on both sides

@@ -11,13 +11,18 @@
 namespace gpsx {
 
 constexpr int kAcqGroup = 8;      // PRNs per accumulator set (one main-loop pass) in the grid kernel
-constexpr int kSuperGroups = 1;   // groups per sharding unit: a unit is (search, 8-PRN group, Doppler bin) -- 84 units per
-                                  // 32 PRN x 21 Doppler search, SURVEY.md 8(e)
+constexpr int kSuperGroups = 1;   // groups per sharding unit: a unit is (search, Doppler bin, 8-PRN group) -- 84 units per
+                                  // 32 PRN x 21 Doppler search, SURVEY.md 8(e).  Unit index u = (search * n_dopp + dopp) *
+                                  // n_groups + group (group fastest); shard r of W owns the contiguous run
+                                  // [r * U / W, (r + 1) * U / W) -- balanced to one unit, and the four groups of a
+                                  // (search, Doppler) pair stay on one GPU (the matrix-core kernel sweeps 32 PRNs at once)
 constexpr int kCodeWords = 256;   // 4-chip code words per PRN (1023 chips + 1 masked pad)
 constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window sum inside 32 bits
 constexpr int kAlgoSad = 0;       // main loop: v_msad_u8 on 8-bit block sums, 4 chips per instruction
 constexpr int kAlgoDot8 = 1;      // main loop: v_dot8_u32_u4 on 4-bit block sums, 8 chips per instruction
-constexpr int kAlgoPoly = 2;      // fine grid only: polyphase recurrence across the 16 sample offsets, AND + popcount (default)
+constexpr int kAlgoPoly = 2;      // fine grid only: polyphase recurrence across the 16 sample offsets, AND + popcount
+constexpr int kAlgoMx = 4;        // fine grid only: the same recurrence as a Toeplitz GEMM on the matrix cores, MX-FP4 (default for
+                                  // launches that fill the chip; smaller ones take the polyphase VALU kernel)
 
 // One search = one workgroup pass: `count` (<= group size) consecutive code-table slots, one carrier frequency,
 // one replica bit shift, n_ms consecutive blocks.
@@ -36,7 +41,7 @@ struct AcqParams {
   int32_t search_stride_blocks;
   int32_t n_prn, n_groups, n_dopp, dopp_min_hz, dopp_step_hz;
   int32_t n_bits;
-  int32_t shard_index, shard_count;
+  int32_t unit_lo, unit_hi;   // this shard's run of sharding units
   int32_t win_start, win_stop;
   int32_t if_format;        // GPSX_IF_1BIT / GPSX_IF_2BIT_SM
   // explicit job list (job mode)
@@ -78,12 +83,20 @@ inline size_t acq_poly_energy_bytes(long local_units)
 {
   return (size_t)local_units * kSuperGroups * kAcqGroup * 16 * 1024 * sizeof(uint32_t);
 }
+// Matrix-core variant (k_acq_mx.hip): phase_mode FINE, no inspection outputs; one 512-thread workgroup per (search, Doppler,
+// 32 PRN slots).  Tables: mx_a [sets][4096] A fragments, mx_t [sets][1032] transposed chip words (launch_build_mx_tables).
+// n_ms > 1 needs d_energy = acq_mx_energy_bytes(clusters) of scratch.
+void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slots, uint32_t *d_mx_a, uint32_t *d_mx_t);
+long acq_mx_clusters(const AcqParams &prm);
+inline size_t acq_mx_energy_bytes(long clusters) { return (size_t)clusters * 8 * (16 * 4 * 16 * 64) * sizeof(uint32_t); }
+const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
+                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy);
 void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks);
 
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
-                     int n_dopp, int n_bits, int shard_index, int shard_count);
+                     int n_dopp, int n_bits, int unit_lo, int unit_hi);
 
 // generic per-call primitives on caller-shaped buffers
 void launch_wipeoff(hipStream_t s, const uint8_t *d_signal, float freq_hz, uint32_t accum_in, uint8_t *d_i,

@@ -117,8 +117,7 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
   const int wave = tid >> 6;
 
   // ---- decode this workgroup's search ------------------------------------------------------------------------
-  // Grid mode: the sharding unit is (search, 16-PRN super group, Doppler); a super group is two G-PRN groups, handled
-  // by one workgroup (GPW = 2) or two (GPW = 1), times the replica bit shifts.
+  // Grid mode: the sharding unit is (search, Doppler, G-PRN group), one workgroup per unit and replica bit shift.
   int first_block, group0, n_groups_here, b, win_start, win_stop, dopp = 0, search = 0;
   float freq_hz;
   AcqJobRec jr{};
@@ -138,14 +137,12 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
     id /= kParts;
     b = id % prm.n_bits;
     const int unit_local = id / prm.n_bits;
-    const int unit = prm.shard_index + unit_local * prm.shard_count;
-    dopp = unit % prm.n_dopp;
-    const int t = unit / prm.n_dopp;
-    const int n_super = (prm.n_groups + kSuperGroups - 1) / kSuperGroups;
-    const int super = t % n_super;
-    search = t / n_super;
+    const int unit = prm.unit_lo + unit_local;
+    const int t = unit / prm.n_groups;
+    dopp = t % prm.n_dopp;
+    search = t / prm.n_dopp;
     first_block = search * prm.search_stride_blocks;
-    group0 = super * kSuperGroups + part * GPW;
+    group0 = unit % prm.n_groups + part * GPW;
     n_groups_here = prm.n_groups - group0 < GPW ? prm.n_groups - group0 : GPW;
     if (n_groups_here <= 0)
       return;   // odd number of groups: the last super group has one
@@ -643,7 +640,7 @@ void launch_acq(hipStream_t s, int group, int algo, long local_units, const AcqP
 
 // One packed key per (search, PRN, Doppler): max over the bit shifts, zero for units this shard did not compute.
 __global__ void k_acq_keys(const gpsx_peak_t *__restrict__ peaks, int64_t *__restrict__ keys, int n_search, int n_prn,
-                           int n_groups, int n_dopp, int n_bits, int shard_index, int shard_count)
+                           int n_groups, int n_dopp, int n_bits, int unit_lo, int unit_hi)
 {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = n_search * n_prn * n_dopp;
@@ -652,10 +649,9 @@ __global__ void k_acq_keys(const gpsx_peak_t *__restrict__ peaks, int64_t *__res
   const int dopp = idx % n_dopp;
   const int prn = (idx / n_dopp) % n_prn;
   const int search = idx / (n_dopp * n_prn);
-  const int n_super = (n_groups + kSuperGroups - 1) / kSuperGroups;
-  const int unit = (search * n_super + prn / (kAcqGroup * kSuperGroups)) * n_dopp + dopp;
+  const int unit = (search * n_dopp + dopp) * n_groups + prn / kAcqGroup;
   int64_t best = 0;
-  if (unit % shard_count == shard_index) {
+  if (unit >= unit_lo && unit < unit_hi) {
     for (int b = 0; b < n_bits; b++) {
       const gpsx_peak_t pk = peaks[(size_t)idx * n_bits + b];
       const int64_t key = ((int64_t)pk.max_val << 14) | (int64_t)(16383 - (int)(8 * pk.phase + b));
@@ -666,13 +662,13 @@ __global__ void k_acq_keys(const gpsx_peak_t *__restrict__ peaks, int64_t *__res
 }
 
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,
-                     int n_dopp, int n_bits, int shard_index, int shard_count)
+                     int n_dopp, int n_bits, int unit_lo, int unit_hi)
 {
   const int n = n_search * n_prn * n_dopp;
   if (n <= 0)
     return;
   hipLaunchKernelGGL(k_acq_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_peaks, d_keys, n_search, n_prn, n_groups,
-                     n_dopp, n_bits, shard_index, shard_count);
+                     n_dopp, n_bits, unit_lo, unit_hi);
 }
 
 }  // namespace gpsx

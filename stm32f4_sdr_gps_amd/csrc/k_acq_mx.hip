@@ -1,0 +1,526 @@
+// k_acq_mx.hip -- the acquisition grid kernel for the fine (16368-phase) sweep with the correlations on the matrix cores.
+//
+// Same contract as k_acq / k_acq_poly: per (search, PRN, Doppler, replica bit shift) the triplet correlation_search
+// (PM/GPS/gps_misc.c:155-191) returns, bit for bit; same preamble (capture -> LDS, carrier wipe-off K3), same
+// per-hypothesis corrections of the reference's quirks and the same magnitude.  What changes is where the sums
+//      M_t0(q) = sum_c chip_p[c] * S_t0[q + c],   S_t0[k] = pop(D[16 k + t0, +16)),   sample offset s = 16 q + t0
+// come from.  In the polyphase form (k_acq_poly.hip)  M_{t0+1}(q) - M_t0(q) = sum_c chip_p[c] * e_t0[q + c]  with
+// e_t0[k] = d_t0[k + 1] - d_t0[k] in {-1, 0, +1},  d_t0[k] = D(16 k + t0): for the 32 PRNs of a workgroup and the 1023
+// chip offsets q that is a GEMM   C[p][q] += A[p][c] * B[c][q],   A = chips (32 x 1024),  B = the TOEPLITZ matrix
+// B[c][q] = e[(q + c) mod 1023]  of ONE 1023-element vector -- and C, kept in the accumulator registers from one sample
+// offset to the next, IS M_t0.  Operands are MX-FP4 (E2M1: 0, +-1, 2, 3, 4 exact; block scale E8M0 2^0 or 2^2),
+// v_mfma_scale_f32_32x32x64_f8f6f4 accumulates in f32: every partial sum is an integer below 2^24, so the result is
+// exact whatever the order (tools/microbench/mfma_fp4_corr.hip checks layouts and exactness on the device).
+// M for the first offset takes two passes: S = (S & 3) + 4 (S >> 2), both parts FP4-exact, the second at scale 2^2.
+//
+// Data movement: B never exists.  The nibble vector (2048 entries: one period + its wrap-around) sits in LDS in eight
+// copies, copy c starting at nibble c, so that lane (n, h) of tile (Q, kappa) -- column q = 32 Q + n, chips
+// 64 kappa + 32 h .. + 31 -- finds its 32 nibbles dword-aligned at dword 4 (Q + 2 kappa + h) + n / 8 of copy n % 8, bank
+// conflict free.  Tile (Q, kappa) reads what (Q - 2, kappa + 1) reads: a wave owns q-tiles Q0, Q0 + 2, Q0 + 4, Q0 + 6
+// and walks the anti-diagonals f = Q + 2 kappa, 19 fragment loads for 64 MFMAs per stream.
+//
+// A workgroup = 8 waves = one (search, Doppler) pair x 32 PRNs (four 8-PRN sharding units) x all 16 sample offsets.
+// Lane (n, h) of a wave holds, per tile, column q for the 16 PRNs p = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15 -- the
+// per-offset work (corrections, window test) is shared by 16 hypotheses.  The matrix pipe and the vector ALU of a SIMD
+// are separate: waves 0..3 and 4..7 (one of each per SIMD) run half a step apart, one group's MFMA pass under the
+// other's epilogue, with one barrier per half step.
+#include <cstdlib>
+
+#include "gpsx_device.hpp"
+#include "gpsx_kernels.hpp"
+
+namespace gpsx {
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kMxThreads = 512;
+constexpr int kMxTiles = 4;            // q-tiles (32 chip offsets each) per wave
+constexpr int kCopyDwords = 264;       // one shifted copy of the nibble vector: 256 dwords + slack
+constexpr int kVecDwords = 258;        // dwords of copy 0 that the shifted copies are cut from
+constexpr int kPlaneWordsMx = 66;      // polyphase bit plane: 1023 bits + circular extension to 2112
+constexpr u32 kScaleOne = 0x7F7F7F7Fu;   // E8M0 127 = 2^0
+constexpr u32 kScaleFour = 0x81818181u;  // E8M0 129 = 2^2
+constexpr int kPasses = 17;            // 2 for the first offset + 15 recurrence steps
+
+struct MxShared {
+  uint16_t x[1024];                      // raw IF block (sign plane)
+  u32 d[2][514];                         // wiped I / Q streams (word 511 = wrap-around copy, then zero pad)
+  u32 plane[2][16][kPlaneWordsMx];       // d_t0 for the 16 sample offsets, circularly extended
+  u32 base[2][kCopyDwords];              // nibble vector of the pass in preparation (copy 0), I / Q
+  u32 e8[2][2][8][kCopyDwords];          // [buffer][stream][copy][dword]
+  v4i chips_a[16][2][32];                // A fragments: [kappa][h][PRN] = 32 FP4 chips 64 kappa + 32 h ..
+  u32 chip_t[1032];                      // chip_t[c + 1]: bit p = chip c of PRN p of this cluster; [0] = chip -1 = 0
+  u32 ones[2];                           // pop(D) per stream
+  u32 part[8][32][2];                    // (packed best key, sum) per bit shift and PRN
+};
+
+__device__ __forceinline__ v8i widen(v4i x) { return v8i{x.x, x.y, x.z, x.w, 0, 0, 0, 0}; }
+
+__device__ __forceinline__ u32 lds_byte(const u32 *words, int byte_index)
+{
+  return (words[byte_index >> 2] >> ((byte_index & 3) * 8)) & 0xFFu;
+}
+
+// 8 bits -> 8 nibbles (bit k -> bit 4 k)
+__device__ __forceinline__ u32 spread8(u32 x)
+{
+  u32 t = (x | (x << 12)) & 0x000F000Fu;
+  t = (t | (t << 6)) & 0x03030303u;
+  t = (t | (t << 3)) & 0x11111111u;
+  return t;
+}
+
+__device__ __forceinline__ int wrap1023(int i)   // i < 3 * 1023
+{
+  i = i >= 2 * kChips ? i - 2 * kChips : i;
+  return i >= kChips ? i - kChips : i;
+}
+
+// bits [pos, pos + 9) of a plane
+__device__ __forceinline__ u32 plane_bits9(const u32 *pl, int pos)
+{
+  return __builtin_amdgcn_alignbit(pl[(pos >> 5) + 1], pl[pos >> 5], (u32)(pos & 31)) & 0x1FFu;
+}
+
+// ---- per block: capture -> LDS, wipe-off, polyphase planes -------------------------------------------------------------
+__device__ void mx_prepare_block(MxShared &sh, const uint8_t *blk, int if_format, u32 step_word, int tid, int lane)
+{
+  for (int i = tid; i < 1024; i += kMxThreads)
+    sh.x[i] = i < kWords16 ? load_sign16(blk, i, if_format) : (uint16_t)0;
+  if (tid < 2)
+    sh.ones[tid] = 0;
+  __syncthreads();
+  {
+    const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
+    u32 ones_i = 0, ones_q = 0;
+    for (int w = tid; w < 514; w += kMxThreads) {
+      u32 vi = 0, vq = 0;
+      if (w < kWords32) {
+        const u32 quad = (step_word * (u32)w) >> 30;
+        vi = carrier_i(quad) ^ x32[w];
+        vq = carrier_q(quad) ^ x32[w];
+      }
+      sh.d[0][w] = vi;
+      sh.d[1][w] = vq;
+      ones_i += __popc(vi);
+      ones_q += __popc(vq);
+    }
+    ones_i = wave_sum_u32(ones_i);
+    ones_q = wave_sum_u32(ones_q);
+    if (lane == 0) {
+      atomicAdd(&sh.ones[0], ones_i);
+      atomicAdd(&sh.ones[1], ones_q);
+    }
+  }
+  __syncthreads();
+  if (tid < 2)
+    sh.d[tid][511] = sh.d[tid][0] << 16;   // samples 16352..16367 are zero, then the stream wraps to sample 0
+  __syncthreads();
+  // plane[iq][t0] bit i = D(16 (i mod 1023) + t0), i < 2112
+  for (int m = tid; m < 2 * 16 * kPlaneWordsMx; m += kMxThreads) {
+    const int iq = m / (16 * kPlaneWordsMx);
+    const int r = m - iq * 16 * kPlaneWordsMx;
+    const int t0 = r / kPlaneWordsMx;
+    const int w = r - t0 * kPlaneWordsMx;
+    const u32 *dd = sh.d[iq];
+    u32 bits = 0;
+#pragma unroll 8
+    for (int e = 0; e < 32; e++) {
+      const int k = wrap1023(32 * w + e);
+      const int pos = 16 * k + t0;   // < 16368: the stream's own samples (the last 16 are zero)
+      bits |= ((dd[pos >> 5] >> (pos & 31)) & 1u) << e;
+    }
+    sh.plane[iq][t0][w] = bits;
+  }
+  // (the caller's next barrier publishes the planes)
+}
+
+// ---- per pass: the nibble vector, copy 0 (phase 1), then its eight shifted copies (phase 2) --------------------------------
+// pass 0: S_0 & 3, pass 1: S_0 >> 2 (scale 2^2), pass p >= 2: e_{p-2}
+__device__ void mx_vector_phase1(MxShared &sh, int pass, int tid)
+{
+  // nibbles 0 .. 2055 are ever read (dword 4 * 62 + 3 + 3 of copy 7): 258 dwords of copy 0
+  for (int m = tid; m < 2 * kVecDwords; m += kMxThreads) {
+    const int iq = m / kVecDwords, dw = m - iq * kVecDwords;
+    u32 packed = 0;
+    if (pass < 2) {
+      const u32 *dd = sh.d[iq];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = wrap1023(8 * dw + e);
+        const int pos = 16 * k;
+        const u32 sum = pop16(__builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31)));
+        // FP4 codes of 0, 1, 2, 3, 4: 0, 2, 4, 5, 6
+        const u32 val = pass == 0 ? (sum & 3u) : (sum >> 2);
+        packed |= ((0x65420u >> (4u * val)) & 0xFu) << (4 * e);
+      }
+    } else {
+      const u32 w = plane_bits9(sh.plane[iq][pass - 2], 8 * dw);
+      const u32 cur = w & 0xFFu, nxt = (w >> 1) & 0xFFu;
+      const u32 plus = spread8(nxt & ~cur), minus = spread8(cur & ~nxt);
+      packed = (plus << 1) | (minus << 1) | (minus << 3);   // +1 = 0x2, -1 = 0xA
+    }
+    sh.base[iq][dw] = packed;
+  }
+}
+
+__device__ void mx_vector_phase2(MxShared &sh, int buf, int tid)
+{
+  for (int m = tid; m < 2 * 256; m += kMxThreads) {
+    const int iq = m >> 8, j = m & 255;
+    const u32 lo = sh.base[iq][j], hi = sh.base[iq][j + 1];
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      sh.e8[buf][iq][c][j] = c ? __builtin_amdgcn_alignbit(hi, lo, 4u * (u32)c) : lo;
+  }
+}
+
+// ---- one MFMA pass: acc[stream][tile] += chips x Toeplitz(vector) -------------------------------------------------------
+__device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][kMxTiles],
+                                        u32 scale_b)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const u32 *wi = &sh.e8[buf][0][n & 7][4 * (q0_tile + h) + (n >> 3)];
+  const u32 *wq = &sh.e8[buf][1][n & 7][4 * (q0_tile + h) + (n >> 3)];
+  const v4i *ca = &sh.chips_a[0][h][n];
+  v4i a[16];
+#pragma unroll
+  for (int s = 0; s < 16 + kMxTiles - 1; s++) {
+    if (s < 16)
+      a[s] = ca[s * 64];                                   // chips_a[s][h][n]
+    const v4i fi = v4i{(int)wi[8 * s], (int)wi[8 * s + 1], (int)wi[8 * s + 2], (int)wi[8 * s + 3]};   // fragment Q0 + 2 s
+    const v4i fq = v4i{(int)wq[8 * s], (int)wq[8 * s + 1], (int)wq[8 * s + 2], (int)wq[8 * s + 3]};
+#pragma unroll
+    for (int j = 0; j < kMxTiles; j++) {
+      const int kappa = s - j;
+      if (kappa < 0 || kappa >= 16)
+        continue;
+      acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fi), acc[0][j], 4, 4, 0, kScaleOne,
+                                                                   0, scale_b);
+      acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fq), acc[1][j], 4, 4, 0, kScaleOne,
+                                                                   0, scale_b);
+    }
+  }
+}
+
+// max / sum over the 32 lanes of each wave half on the DPP network; results in lanes 31 and 63
+__device__ __forceinline__ u32 half_max_to_lane31(u32 v)
+{
+  u32 o;
+  o = dpp<0xB1>(v, v); v = o > v ? o : v;
+  o = dpp<0x4E>(v, v); v = o > v ? o : v;
+  o = dpp<0x141>(v, v); v = o > v ? o : v;
+  o = dpp<0x140>(v, v); v = o > v ? o : v;
+  o = dpp<0x142, 0xA>(v, v); v = o > v ? o : v;      // row_bcast15 into rows 1, 3
+  return v;
+}
+__device__ __forceinline__ u32 half_sum_to_lane31(u32 v)
+{
+  v += dpp<0xB1>(0u, v);
+  v += dpp<0x4E>(0u, v);
+  v += dpp<0x141>(0u, v);
+  v += dpp<0x140>(0u, v);
+  v += dpp<0x142, 0xA>(0u, v);
+  return v;
+}
+
+// ---- epilogue of one sample offset: corrections of the reference's quirks, magnitude, windowed max / sum ----------------
+// (port of poly_finish_offset to the accumulator layout; the corrections in their linear form
+//    cnt = K(q) - 2 M + c1022 A(q) + c1021 B(q) - chip[p1 - 1] alpha - chip[p1] beta,   p1 = 1022 - q,
+//  K, A, B per lane and stream, alpha, beta per wave and stream; the last three terms only for odd byte offsets)
+template <bool MULTI>
+__device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
+                                            int win_start, int win_stop, u32 group_mask, u32 *__restrict__ energy,
+                                            bool ms_first, bool ms_last)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const int b = t0 & 7, half = t0 >> 3;
+  const u32 low_mask = (1u << b) - 1u;
+  const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;
+  const int base_i = (int)sh.ones[0] + 8192, base_q = (int)sh.ones[1] + 8192;   // C0 = pop(D) + 8192 - 2 M
+  // odd byte offsets skip the word at the wrap, data bytes (2045, 0): popcount against replica word p1 in linear form
+  const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8, wrap_q = (sh.d[1][0] & 0xFFu) << 8;
+  const int alpha_i = b - 2 * (int)__popc(wrap_i & low_mask), beta_i = (16 - b) - 2 * (int)__popc(wrap_i & high_mask);
+  const int alpha_q = b - 2 * (int)__popc(wrap_q & low_mask), beta_q = (16 - b) - 2 * (int)__popc(wrap_q & high_mask);
+  const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
+  // chip 1021 / 1022 of this lane's 16 PRNs: bit (r & 3) + 8 (r >> 2) after the shift by 4 h
+  const u32 f21 = sh.chip_t[1021 + 1] >> (4 * h), f22 = sh.chip_t[1022 + 1] >> (4 * h);
+  u32 best[16], total[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    best[r] = 0;
+    total[r] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    const bool exists = q < kChips;
+    const int o = 2 * q + half;
+    const bool in_win = exists && o >= win_start && o < win_stop;
+    const int oc = exists ? o : 0;
+    int k_i = base_i, k_q = base_q;
+    int a_i = 2 * (int)__popc(lds_byte(sh.d[0], oc) & low_mask) - b;      // quirk Q5, PRNs whose chip 1022 is set
+    int a_q = 2 * (int)__popc(lds_byte(sh.d[1], oc) & low_mask) - b;
+    int b_i = 0, b_q = 0;
+    u32 w0 = 0, w1 = 0;
+    if (half) {
+      k_i -= popw_i;
+      k_q -= popw_q;
+      if (q > 0 && exists) {   // quirk Q3: replica word 1022 against data bytes (o - 2, o - 1)
+        const u32 prev_i = lds_byte(sh.d[0], oc - 2) | (lds_byte(sh.d[0], oc - 1) << 8);
+        const u32 prev_q = lds_byte(sh.d[1], oc - 2) | (lds_byte(sh.d[1], oc - 1) << 8);
+        k_i -= (int)__popc(prev_i);
+        k_q -= (int)__popc(prev_q);
+        a_i -= (16 - b) - 2 * (int)__popc(prev_i & high_mask);
+        a_q -= (16 - b) - 2 * (int)__popc(prev_q & high_mask);
+        b_i = -(b - 2 * (int)__popc(prev_i & low_mask));
+        b_q = -(b - 2 * (int)__popc(prev_q & low_mask));
+      }
+      const int p1 = exists ? kChips - 1 - q : 0;
+      w0 = sh.chip_t[p1] >> (4 * h);        // chip p1 - 1
+      w1 = sh.chip_t[p1 + 1] >> (4 * h);    // chip p1
+    }
+    const u32 key_lo = (u32)(2047 - o);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      if (!((group_mask >> g) & 1u))   // wave-uniform: 8-PRN groups of other shards, or beyond the PRN list
+        continue;
+      u32 prev[MULTI ? 4 : 1];
+      u32 *e_ptr = nullptr;
+      if (MULTI) {
+        e_ptr = energy + ((size_t)((t0 * kMxTiles + j) * 16 + 4 * g) * 64 + lane);
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          prev[MULTI ? rr : 0] = e_ptr[rr * 64];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int r = 4 * g + rr;
+        const int pb = (r & 3) + 8 * (r >> 2);
+        const int c22 = (int)((f22 >> pb) & 1u), c21 = (int)((f21 >> pb) & 1u);
+        int ci = k_i + __mul24((int)acc[0][j][r], -2) + __mul24(c22, a_i);
+        int cq = k_q + __mul24((int)acc[1][j][r], -2) + __mul24(c22, a_q);
+        if (half) {
+          const int c0 = (int)((w0 >> pb) & 1u), c1 = (int)((w1 >> pb) & 1u);
+          ci += __mul24(c21, b_i) - __mul24(c0, alpha_i) - __mul24(c1, beta_i);
+          cq += __mul24(c21, b_q) - __mul24(c0, alpha_q) - __mul24(c1, beta_q);
+        }
+        u32 val = in_win ? (u32)mag8_fast<!MULTI>(ci, cq) : 0u;
+        if (MULTI) {
+          val += ms_first ? 0u : prev[MULTI ? rr : 0];
+          if (!ms_last)
+            e_ptr[rr * 64] = val;
+        }
+        const u32 key = (val << 11) | key_lo;
+        best[r] = key > best[r] ? key : best[r];
+        total[r] += val;
+      }
+    }
+  }
+  if (MULTI && !ms_last)
+    return;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    if (!((group_mask >> g) & 1u))
+      continue;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      const int r = 4 * g + rr;
+      const u32 k = half_max_to_lane31(best[r]);
+      const u32 t = half_sum_to_lane31(total[r]);
+      if (n == 31) {
+        const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
+        atomicMax(&sh.part[b][p][0], k);
+        atomicAdd(&sh.part[b][p][1], t);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// mx_a [set][16][2][32][4]: the A fragments of a 32-slot cluster; mx_t [set][1032]: its transposed chip words
+__global__ void k_build_mx_tables(const u32 *__restrict__ chipbits, int n_slots, u32 *__restrict__ mx_a, u32 *__restrict__ mx_t)
+{
+  const int n_sets = (n_slots + 31) / 32;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_set = 16 * 2 * 32 * 4 + 1032;
+  if (idx >= n_sets * per_set)
+    return;
+  const int set = idx / per_set, r = idx - set * per_set;
+  if (r < 16 * 2 * 32 * 4) {
+    const int dw = r & 3, p = (r >> 2) & 31, h = (r >> 7) & 1, kappa = r >> 8;
+    const int slot = 32 * set + p;
+    const u32 word = slot < n_slots ? chipbits[(size_t)slot * 32 + 2 * kappa + h] : 0u;   // chips 64 kappa + 32 h ..
+    mx_a[(size_t)set * (16 * 2 * 32 * 4) + r] = spread8((word >> (8 * dw)) & 0xFFu) << 1;   // chip 1 -> FP4 code 2 (= 1.0)
+  } else {
+    const int c = r - 16 * 2 * 32 * 4 - 1;   // -1 .. 1030
+    u32 w = 0;
+    if (c >= 0 && c < kChips)
+      for (int p = 0; p < 32; p++) {
+        const int slot = 32 * set + p;
+        if (slot < n_slots)
+          w |= ((chipbits[(size_t)slot * 32 + (c >> 5)] >> (c & 31)) & 1u) << p;
+      }
+    mx_t[(size_t)set * 1032 + (c + 1)] = w;
+  }
+}
+
+void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slots, uint32_t *d_mx_a, uint32_t *d_mx_t)
+{
+  const int n_sets = (n_slots + 31) / 32;
+  const int n = n_sets * (16 * 2 * 32 * 4 + 1032);
+  hipLaunchKernelGGL(k_build_mx_tables, dim3((n + 255) / 256), dim3(256), 0, s, d_chipbits, n_slots, d_mx_a, d_mx_t);
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,
+                                                          const u32 *__restrict__ mx_a, const u32 *__restrict__ mx_t,
+                                                          gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy)
+{
+  __shared__ MxShared sh;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int role = wave >> 2;                            // waves w and w + 4 share a SIMD: half a step apart
+  const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
+
+  // ---- decode: cluster = (search, Doppler, set of 32 PRN slots); its four 8-PRN groups are sharding units -----------
+  const int n_sets = (prm.n_groups + 3) / 4;
+  const int cluster = cluster_lo + (int)blockIdx.x;
+  const int set = cluster % n_sets;
+  const int sd = cluster / n_sets;
+  const int dopp = sd % prm.n_dopp;
+  const int search = sd / prm.n_dopp;
+  u32 group_mask = 0;
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int group = 4 * set + g;
+    const int unit = sd * prm.n_groups + group;
+    if (group < prm.n_groups && unit >= prm.unit_lo && unit < prm.unit_hi)
+      group_mask |= 1u << g;
+  }
+  group_mask = (u32)__builtin_amdgcn_readfirstlane((int)group_mask);
+  if (group_mask == 0)
+    return;
+  const float freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
+  const u32 step_word = nco_step_per_word(freq_hz);
+
+  // tables of the cluster
+  {
+    const u32 *src_a = mx_a + (size_t)set * (16 * 2 * 32 * 4);
+    u32 *dst_a = reinterpret_cast<u32 *>(&sh.chips_a[0][0][0]);
+    for (int i = tid; i < 16 * 2 * 32 * 4; i += kMxThreads)
+      dst_a[i] = src_a[i];
+    const u32 *src_t = mx_t + (size_t)set * 1032;
+    for (int i = tid; i < 1032; i += kMxThreads)
+      sh.chip_t[i] = src_t[i];
+    for (int i = tid; i < 8 * 32 * 2; i += kMxThreads)
+      (&sh.part[0][0][0])[i] = 0;
+    for (int i = tid; i < 2 * 2 * 8 * kCopyDwords; i += kMxThreads)
+      (&sh.e8[0][0][0][0])[i] = 0;   // the slack dwords are read (and their products discarded); keep them finite
+  }
+
+  u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 16 * 64) : nullptr;
+  const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
+  const int n_ms = MULTI ? prm.n_ms : 1;
+#pragma unroll 1
+  for (int ms = 0; ms < n_ms; ms++) {
+    const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
+    __syncthreads();   // the previous block's readers are done
+    mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms) * block_bytes, prm.if_format,
+                     step_word, tid, lane);
+    __syncthreads();
+    mx_vector_phase1(sh, 0, tid);
+    __syncthreads();
+    mx_vector_phase2(sh, 0, tid);
+
+    v16f acc[2][kMxTiles];
+#pragma unroll
+    for (int st = 0; st < 2; st++)
+#pragma unroll
+      for (int j = 0; j < kMxTiles; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          acc[st][j][r] = 0.f;
+
+    // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
+    // half step later.  The vector of pass p + 1 is built in half steps 2 p (copy 0) and 2 p + 1 (its shifted copies),
+    // into the buffer whose last reader (role 1, pass p - 1) finished in half step 2 p - 1.
+#pragma unroll 1
+    for (int hs = 0; hs <= 2 * kPasses; hs++) {
+      __syncthreads();
+      const int p_vec = (hs >> 1) + 1;
+      if (p_vec < kPasses) {
+        if ((hs & 1) == 0)
+          mx_vector_phase1(sh, p_vec, tid);
+        else
+          mx_vector_phase2(sh, p_vec & 1, tid);
+      }
+      const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
+      if (x < 0 || x >= 2 * kPasses)
+        continue;
+      const int p = x >> 1;
+      if ((x & 1) == 0) {
+        mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleFour : kScaleOne);
+      } else if (p >= 1) {
+        mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, prm.win_start, prm.win_stop, group_mask, e_wave, ms_first, ms_last);
+      }
+    }
+  }
+  __syncthreads();
+  // the finished triplets: one per (PRN, bit shift)
+  if (tid < 256) {
+    const int p = tid >> 3, b = tid & 7;
+    const int slot = 32 * set + p;
+    if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn) {
+      const u32 k = sh.part[b][p][0], t = sh.part[b][p][1];
+      gpsx_peak_t pk;
+      pk.max_val = k >> 11;
+      pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+      pk.sum = t;
+      pk.avr = t / (2u * kChips);
+      peaks[((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * 8 + b] = pk;
+    }
+  }
+}
+
+// clusters that intersect this shard's run of units
+static void mx_cluster_range(const AcqParams &prm, int *c_lo, int *c_hi)
+{
+  const int n_sets = (prm.n_groups + 3) / 4;
+  auto cluster_of = [&](int unit) { return (unit / prm.n_groups) * n_sets + (unit % prm.n_groups) / 4; };
+  *c_lo = cluster_of(prm.unit_lo);
+  *c_hi = cluster_of(prm.unit_hi - 1) + 1;
+}
+
+long acq_mx_clusters(const AcqParams &prm)
+{
+  if (prm.unit_hi <= prm.unit_lo)
+    return 0;
+  int c_lo, c_hi;
+  mx_cluster_range(prm, &c_lo, &c_hi);
+  return c_hi - c_lo;
+}
+
+const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
+                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy)
+{
+  if (prm.unit_hi <= prm.unit_lo)
+    return "";
+  int c_lo, c_hi;
+  mx_cluster_range(prm, &c_lo, &c_hi);
+  if (prm.n_ms > 1) {
+    hipLaunchKernelGGL(k_acq_mx<true>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+                       d_peaks, d_energy);
+    return "k_acq_mx<1>";
+  }
+  hipLaunchKernelGGL(k_acq_mx<false>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+                     d_peaks, (u32 *)nullptr);
+  return "k_acq_mx<0>";
+}
+
+}  // namespace gpsx

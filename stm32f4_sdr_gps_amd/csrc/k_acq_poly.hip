@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
   const int tid = threadIdx.x;
   const int lane = tid & 63;
 
-  // ---- decode: (sharding unit = search x 16-PRN super group x Doppler) x group x segment [x block, STORE] -------------
+  // ---- decode: (sharding unit = search x Doppler x 8-PRN group) x segment [x block, STORE] --------------------------------
   constexpr int kSegs = kMaxSegment / SEG;   // workgroups per chip
   int id = blockIdx.x;
   const int seg = id % kSegs;
@@ -237,13 +237,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, c
   id /= kSuperGroups;
   const int ms_store = STORE ? id % prm.n_ms : 0;
   const int unit_local = STORE ? id / prm.n_ms : id;
-  const int unit = prm.shard_index + unit_local * prm.shard_count;
-  const int dopp = unit % prm.n_dopp;
-  const int t = unit / prm.n_dopp;
-  const int n_super = (prm.n_groups + kSuperGroups - 1) / kSuperGroups;
-  const int super = t % n_super;
-  const int search = t / n_super;
-  const int group = super * kSuperGroups + gsel;
+  const int unit = prm.unit_lo + unit_local;
+  const int t = unit / prm.n_groups;
+  const int dopp = t % prm.n_dopp;
+  const int search = t / prm.n_dopp;
+  const int group = unit % prm.n_groups + gsel;
   if (group >= prm.n_groups)
     return;
   const int slot0 = group * G;
@@ -538,9 +536,8 @@ __global__ __launch_bounds__(kThreads) void k_acq_vals_search(const AcqParams pr
   id /= prm.n_dopp;
   const int prn = id % prm.n_prn;
   const int search = id / prm.n_prn;
-  const int n_super = (prm.n_groups + kSuperGroups - 1) / kSuperGroups;
-  const int unit = (search * n_super + prn / (kAcqGroup * kSuperGroups)) * prm.n_dopp + dopp;
-  if (unit % prm.shard_count != prm.shard_index)
+  const int unit = (search * prm.n_dopp + dopp) * prm.n_groups + prn / kAcqGroup;
+  if (unit < prm.unit_lo || unit >= prm.unit_hi)
     return;
   const size_t plane = (size_t)prm.n_prn * prm.n_dopp * (16 * 1024);                      // one block's magnitudes
   const uint16_t *v0 = vals + ((size_t)(search * prm.n_ms) * prm.n_prn * prm.n_dopp + (size_t)prn * prm.n_dopp + dopp) * (16 * 1024);

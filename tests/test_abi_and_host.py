@@ -117,12 +117,18 @@ def test_sharding_partition_and_key_packing():
     counts = [int(sharding.owned_mask(1, 32, 21, r, 8)[:, ::8, :].sum()) for r in range(8)]
     assert sorted(counts) == [10, 10, 10, 10, 11, 11, 11, 11]
     assert max(counts) / (84 / 8) < 1.05
-    # the ownership rule written out by hand for a small grid: unit = (search * n_groups + prn // 8) * n_dopp + dopp
+    # ... and at most two (search, Doppler) pairs per rank are split between ranks (whole 32-PRN clusters elsewhere)
+    for r in range(8):
+        m = sharding.owned_mask(1, 32, 21, r, 8)[0, ::8, :]          # [group, dopp]
+        partial = int(((m.sum(axis=0) > 0) & (m.sum(axis=0) < 4)).sum())
+        assert partial <= 2
+    # the ownership rule written out by hand for a small grid: unit = (search * n_dopp + dopp) * n_groups + prn // 8,
+    # rank 1 of 3 owns units [U / 3, 2 U / 3) with U = 2 * 3 * 2
     m = sharding.owned_mask(2, 10, 3, 1, 3)
     for s in range(2):
         for p in range(10):
             for d in range(3):
-                assert m[s, p, d] == (((s * 2 + p // 8) * 3 + d) % 3 == 1)
+                assert m[s, p, d] == (4 <= (s * 3 + d) * 2 + p // 8 < 8)
 
 
 def test_public_headers_are_plain_c(tmp_path):

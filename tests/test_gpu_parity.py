@@ -746,9 +746,10 @@ def test_capture_replay_of_a_recorded_if_file(eng, stream, tmp_path):
 
 # ---- the alternative grid kernels stay bit-identical to the default ($GPSX_ACQ_ALGO, read when a context is created) --
 
-@pytest.mark.parametrize("algo", ["dot8", "sad", "seg4", "seg8", "seg16"])
+@pytest.mark.parametrize("algo", ["mx", "poly", "dot8", "sad", "seg4", "seg8", "seg16"])
 def test_alternative_grid_kernels_match_the_default(eng, stream, algo, monkeypatch):
-    """dot8 / sad = the direct forms, seg* = the polyphase kernel at a forced number of sample offsets per workgroup.
+    """mx = the matrix-core kernel (forced: by itself it only takes launches that fill the chip), poly = the polyphase
+    VALU kernel, dot8 / sad = the direct forms, seg* = the polyphase kernel at a forced number of offsets per workgroup.
     Windows, a PRN count that is not a multiple of the group, odd Doppler counts and steps, multi-block searches."""
     from stm32f4_sdr_gps_amd import capi
     var, val = ("GPSX_ACQ_SEG", algo[3:]) if algo.startswith("seg") else ("GPSX_ACQ_ALGO", algo)   # seg*: the polyphase
@@ -776,6 +777,68 @@ def test_alternative_grid_kernels_match_the_default(eng, stream, algo, monkeypat
         assert np.array_equal(pk, one_pk) and np.array_equal(keys, one_keys), algo
     finally:
         alt.close()
+
+
+@pytest.fixture(scope="module")
+def eng_mx():
+    """An engine whose fine grids all run on the matrix cores (k_acq_mx.hip), whatever their size."""
+    import os
+    from stm32f4_sdr_gps_amd import capi
+    old = os.environ.get("GPSX_ACQ_ALGO")
+    os.environ["GPSX_ACQ_ALGO"] = "mx"
+    try:
+        e = capi.Engine(0)
+    finally:
+        if old is None:
+            del os.environ["GPSX_ACQ_ALGO"]
+        else:
+            os.environ["GPSX_ACQ_ALGO"] = old
+    yield e
+    e.close()
+
+
+def test_matrix_core_grid_vs_oracle(eng_mx, oracle, stream):
+    """k_acq_mx against the CPU oracle directly: 32 PRNs (one full cluster) x 3 Doppler bins x 16368 phases on two
+    captures, and the 10-block non-coherent sum (BASELINE.json configs[3]'s integration) on a 5-PRN list."""
+    prns = np.arange(1, 33, dtype=np.uint8)
+    peaks, keys = eng_mx.acq_grid(stream[:2], prns, n_search=2, dopp_min_hz=500, dopp_step_hz=1500, n_dopp=3)
+    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<0>"
+    for s in range(2):
+        want = oracle.acq_grid(stream[s:s + 1], 1, prns, 500, 1500, 3, 8, n_threads=8)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(peaks[s][f], want[f]), (s, f)
+    prns5 = np.array([5, 14, 20, 30, 7], np.uint8)
+    peaks, _ = eng_mx.acq_grid(stream[:10], prns5, n_search=1, n_ms=10, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
+    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<1>"
+    want = oracle.acq_grid(stream[:10], 10, prns5, -1000, 500, 5, 8, n_threads=8)
+    for f in ("max_val", "phase", "sum", "avr"):
+        assert np.array_equal(peaks[0][f], want[f]), f
+
+
+def test_matrix_core_grid_windows_sets_and_shards(eng_mx, eng, stream):
+    """40 PRNs = two 32-slot clusters (the second one a single 8-PRN group), windows, and every shard of 2, 3, 5 and 8:
+    a shard's run of units cuts clusters anywhere, the kernel then skips the foreign 8-PRN groups of a workgroup."""
+    prns = np.concatenate([np.arange(1, 33), [33, 40, 61, 100, 120, 150, 200, 210]]).astype(np.uint8)
+    for kw in (dict(n_search=2, dopp_min_hz=-2000, dopp_step_hz=1000, n_dopp=5),
+               dict(n_search=1, dopp_min_hz=250, dopp_step_hz=500, n_dopp=2, win=(100, 1901)),
+               dict(n_search=1, dopp_min_hz=0, dopp_step_hz=500, n_dopp=1, win=(7, 8))):
+        want_pk, want_keys = eng.acq_grid(stream[:2], prns, **kw)
+        pk, keys = eng_mx.acq_grid(stream[:2], prns, **kw)
+        assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys), kw
+    kw = dict(n_search=2, dopp_min_hz=-2000, dopp_step_hz=1000, n_dopp=5)
+    want_pk, want_keys = eng.acq_grid(stream[:2], prns, **kw)
+    for world in (2, 3, 5, 8):
+        acc = np.zeros_like(want_keys)
+        owned = np.zeros(want_keys.shape, np.int32)
+        for r in range(world):
+            pk, ks = eng_mx.acq_grid(stream[:2], prns, shard=(r, world), **kw)
+            mine = ks != 0
+            owned += mine
+            acc = np.maximum(acc, ks)
+            for f in ("max_val", "phase", "sum", "avr"):
+                assert np.array_equal(pk[f][mine], want_pk[f][mine]), (world, r, f)
+            assert not pk["sum"][~mine].any()
+        assert np.array_equal(acc, want_keys) and (owned == 1).all()
 
 
 @pytest.mark.parametrize("amp_scale", [0.25, 1.0])
