@@ -415,6 +415,10 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.win_start = g->win_start;
   prm.win_stop = g->win_stop;
   prm.if_format = ctx->if_format;
+  {
+    static const char *ex = std::getenv("GPSX_MX_EXPERIMENT");
+    prm.experiment = ex ? std::atoi(ex) : 0;
+  }
   prm.jobs = nullptr;
   prm.peaks = d_peaks;
   prm.per_ms = d_per_ms;

@@ -44,6 +44,7 @@ struct AcqParams {
   int32_t unit_lo, unit_hi;   // this shard's run of sharding units
   int32_t win_start, win_stop;
   int32_t if_format;        // GPSX_IF_1BIT / GPSX_IF_2BIT_SM
+  int32_t experiment;       // $GPSX_MX_EXPERIMENT: ablations of k_acq_mx for timing (results are then wrong); 0 in production
   // explicit job list (job mode)
   const AcqJobRec *jobs;
   // outputs (optional ones may be null)

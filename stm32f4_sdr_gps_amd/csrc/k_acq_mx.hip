@@ -309,7 +309,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
           ci += __mul24(c21, b_i) - __mul24(c0, alpha_i) - __mul24(c1, beta_i);
           cq += __mul24(c21, b_q) - __mul24(c0, alpha_q) - __mul24(c1, beta_q);
         }
-        u32 val = in_win ? (u32)mag8_fast<!MULTI>(ci, cq) : 0u;
+        u32 val = in_win ? (u32)mag8_fast<false>(ci, cq) : 0u;   // (no wave-uniform shortcut: straight-line code schedules better here)
         if (MULTI) {
           val += ms_first ? 0u : prev[MULTI ? rr : 0];
           if (!ms_last)
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __shared__ MxShared sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int role = wave >> 2;                            // waves w and w + 4 share a SIMD: half a step apart
+  const int ex = prm.experiment;   // timing ablations: 1 = no epilogue, 2 = no MFMA, 4 = no stagger, 8 = no vector prep
+  const int role = (ex & 4) ? 0 : wave >> 2;             // waves w and w + 4 share a SIMD: half a step apart
   const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
 
   // ---- decode: cluster = (search, Doppler, set of 32 PRN slots); its four 8-PRN groups are sharding units -----------
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     for (int hs = 0; hs <= 2 * kPasses; hs++) {
       __syncthreads();
       const int p_vec = (hs >> 1) + 1;
-      if (p_vec < kPasses) {
+      if (p_vec < kPasses && !(ex & 8)) {
         if ((hs & 1) == 0)
           mx_vector_phase1(sh, p_vec, tid);
         else
@@ -465,8 +466,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         continue;
       const int p = x >> 1;
       if ((x & 1) == 0) {
-        mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleFour : kScaleOne);
-      } else if (p >= 1) {
+        if (!(ex & 2))
+          mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleFour : kScaleOne);
+      } else if (p >= 1 && !(ex & 1)) {
         mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, prm.win_start, prm.win_stop, group_mask, e_wave, ms_first, ms_last);
       }
     }
