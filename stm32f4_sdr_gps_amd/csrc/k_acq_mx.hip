@@ -11,13 +11,28 @@
 // offset to the next, IS M_t0.  Operands are MX-FP4 (E2M1: 0, +-1, 2, 3, 4 exact; block scale E8M0 2^0 or 2^2),
 // v_mfma_scale_f32_32x32x64_f8f6f4 accumulates in f32: every partial sum is an integer below 2^24, so the result is
 // exact whatever the order (tools/microbench/mfma_fp4_corr.hip checks layouts and exactness on the device).
-// M for the first offset takes two passes: S = (S & 3) + 4 (S >> 2), both parts FP4-exact, the second at scale 2^2.
+// M for the first offset takes two passes: S = (S & 3) + 4 (S >> 2), both parts FP4-exact, the second at a block scale.
 //
 // Data movement: B never exists.  The nibble vector (2048 entries: one period + its wrap-around) sits in LDS in eight
 // copies, copy c starting at nibble c, so that lane (n, h) of tile (Q, kappa) -- column q = 32 Q + n, chips
 // 64 kappa + 32 h .. + 31 -- finds its 32 nibbles dword-aligned at dword 4 (Q + 2 kappa + h) + n / 8 of copy n % 8, bank
 // conflict free.  Tile (Q, kappa) reads what (Q - 2, kappa + 1) reads: a wave owns q-tiles Q0, Q0 + 2, Q0 + 4, Q0 + 6
 // and walks the anti-diagonals f = Q + 2 kappa, 19 fragment loads for 64 MFMAs per stream.
+//
+// Nothing linear is left to the vector ALU.  What the reference's quirks add to a popcount is linear in chip bits
+// (DESIGN.md 4.1d), so it rides in the same accumulators: the accumulator of (q, PRN p) holds, after the pass of sample
+// offset t0, exactly  cnt(q, t0, p) - 8184  -- the number gps_correlation8 clips and squares:
+//   * the vector carries -2 e (values 0, +-2), the accumulators start at pop(D) + 8192 - 8184 (or at -2^20 for byte offsets
+//     outside the search window: they clip to zero by themselves);
+//   * odd byte offsets skip the replica word at the wrap (quirk Q3), a popcount against chips (1021 - q, 1022 - q): two
+//     impulses of -1 / +1 in the vector at entries 1021 and 1022 (not in their wrap-around copies) per step;
+//   * the terms "PRN flag x per-offset value" (chip 1022: quirk Q5 and the tail word of Q3; chip 1021: the tail word) are
+//     one more K step of the GEMM: A column 0 of lane half 0 = chip 1022 of the PRN, of half 1 = chip 1021, B = the
+//     per-offset deltas (0, +-1, +-2) read as one byte per lane;
+//   * at the switch from even to odd byte offsets (t0 = 8) every such term jumps; that one step is patched into the
+//     accumulators by the vector ALU (mx_half_switch).
+// The epilogue of a sample offset is then: clip, square, add, correctly rounded root, truncate, (add the running sum of
+// earlier blocks,) pack the key, max, sum.
 //
 // A workgroup = 8 waves = one (search, Doppler) pair x 32 PRNs (four 8-PRN sharding units) x all 16 sample offsets.
 // Lane (n, h) of a wave holds, per tile, column q for the 16 PRNs p = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15 -- the
@@ -43,7 +58,7 @@ constexpr int kCopyDwords = 264;       // one shifted copy of the nibble vector:
 constexpr int kVecDwords = 258;        // dwords of copy 0 that the shifted copies are cut from
 constexpr int kPlaneWordsMx = 66;      // polyphase bit plane: 1023 bits + circular extension to 2112
 constexpr u32 kScaleOne = 0x7F7F7F7Fu;   // E8M0 127 = 2^0
-constexpr u32 kScaleFour = 0x81818181u;  // E8M0 129 = 2^2
+constexpr u32 kScaleEight = 0x82828282u; // E8M0 130 = 2^3
 constexpr int kPasses = 17;            // 2 for the first offset + 15 recurrence steps
 
 struct MxShared {
@@ -52,6 +67,7 @@ struct MxShared {
   u32 plane[2][16][kPlaneWordsMx];       // d_t0 for the 16 sample offsets, circularly extended
   u32 base[2][kCopyDwords];              // nibble vector of the pass in preparation (copy 0), I / Q
   u32 e8[2][2][8][kCopyDwords];          // [buffer][stream][copy][dword]
+  uint8_t corr[2][2][2][1024];           // [buffer][stream][chip 1022 / chip 1021 term][q]: FP4 code of the step's delta
   v4i chips_a[16][2][32];                // A fragments: [kappa][h][PRN] = 32 FP4 chips 64 kappa + 32 h ..
   u32 chip_t[1032];                      // chip_t[c + 1]: bit p = chip c of PRN p of this cluster; [0] = chip -1 = 0
   u32 ones[2];                           // pop(D) per stream
@@ -139,10 +155,19 @@ __device__ void mx_prepare_block(MxShared &sh, const uint8_t *blk, int if_format
   // (the caller's next barrier publishes the planes)
 }
 
-// ---- per pass: the nibble vector, copy 0 (phase 1), then its eight shifted copies (phase 2) --------------------------------
-// pass 0: S_0 & 3, pass 1: S_0 >> 2 (scale 2^2), pass p >= 2: e_{p-2}
-__device__ void mx_vector_phase1(MxShared &sh, int pass, int tid)
+// FP4 (E2M1) code of a small integer: 0, +-1, +-2, +-3, +-4 (and 6)
+__device__ __forceinline__ u32 fp4_code(int v)
 {
+  const u32 m = (u32)(v < 0 ? -v : v);
+  return ((0x0765420u >> (4u * (m > 5u ? 5u : m))) & 0xFu) | (v < 0 ? 8u : 0u);   // |v|: 0 1 2 3 4 6 -> 0 2 4 5 6 7
+}
+
+// ---- per pass: the nibble vector, copy 0 (phase 1), then its eight shifted copies (phase 2) --------------------------------
+// pass 0: -2 (S_0 & 3), pass 1: -(S_0 >> 2) at scale 2^3, pass p >= 2 (producing sample offset t0 = p - 1 from plane
+// p - 2): -2 e_{p-2}, plus the wrap-word impulses when t0 is 9..15; and the byte vectors of the extra K step.
+__device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid)
+{
+  const int t0 = pass - 1;
   // nibbles 0 .. 2055 are ever read (dword 4 * 62 + 3 + 3 of copy 7): 258 dwords of copy 0
   for (int m = tid; m < 2 * kVecDwords; m += kMxThreads) {
     const int iq = m / kVecDwords, dw = m - iq * kVecDwords;
@@ -154,17 +179,41 @@ __device__ void mx_vector_phase1(MxShared &sh, int pass, int tid)
         const int k = wrap1023(8 * dw + e);
         const int pos = 16 * k;
         const u32 sum = pop16(__builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31)));
-        // FP4 codes of 0, 1, 2, 3, 4: 0, 2, 4, 5, 6
-        const u32 val = pass == 0 ? (sum & 3u) : (sum >> 2);
-        packed |= ((0x65420u >> (4u * val)) & 0xFu) << (4 * e);
+        // pass 0: -2 (S & 3) = 0, -2, -4, -6 -> codes 0, C, E, F;  pass 1: -(S >> 2) = 0 .. -4 -> codes 0, A, C, D, E
+        const u32 code = pass == 0 ? (0xFEC0u >> (4u * (sum & 3u))) & 0xFu : (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;
+        packed |= code << (4 * e);
       }
     } else {
       const u32 w = plane_bits9(sh.plane[iq][pass - 2], 8 * dw);
       const u32 cur = w & 0xFFu, nxt = (w >> 1) & 0xFFu;
-      const u32 plus = spread8(nxt & ~cur), minus = spread8(cur & ~nxt);
-      packed = (plus << 1) | (minus << 1) | (minus << 3);   // +1 = 0x2, -1 = 0xA
+      const u32 plus = spread8(nxt & ~cur), minus = spread8(cur & ~nxt);   // e = +1 -> -2 (code C), e = -1 -> +2 (code 4)
+      packed = (plus << 2) | (plus << 3) | (minus << 2);
+      if (dw == 127 && t0 >= 9) {
+        // entries 1021 / 1022 (nibbles 5 / 6 of this dword, first period only): the skipped wrap word's coefficients
+        // alpha_b = b on chip 1021 - q and beta_b = const - b on chip 1022 - q move by +1 / -1 per step; they are
+        // subtracted from the count: -1 / +1 here
+        const int e5 = (int)((nxt >> 5) & 1u) - (int)((cur >> 5) & 1u), e6 = (int)((nxt >> 6) & 1u) - (int)((cur >> 6) & 1u);
+        packed = (packed & ~0x0FF00000u) | (fp4_code(-2 * e5 - 1) << 20) | (fp4_code(-2 * e6 + 1) << 24);
+      }
     }
     sh.base[iq][dw] = packed;
+  }
+  // extra K step: deltas of  c1022 * A'(q)  and  c1021 * B'(q)  (see mx_half_switch for the terms themselves)
+  for (int m = tid; m < 2 * 1024; m += kMxThreads) {
+    const int iq = m >> 10, q = m & 1023;
+    int ga = 0, gb = 0;
+    if (pass >= 2 && t0 != 8 && q < kChips) {
+      const u32 *pl = sh.plane[iq][pass - 2];
+      const int d = (int)((pl[q >> 5] >> (q & 31)) & 1u);
+      ga = 2 * d - 1;                                   // A_b = 2 pop(byte_o & low_b) - b grows by 2 D(8 o + b) - 1
+      if (t0 >= 9 && q > 0) {                           // tail word (o - 2, o - 1) of odd offsets: its bit b is d[q - 1]
+        const int dm = (int)((pl[(q - 1) >> 5] >> ((q - 1) & 31)) & 1u);
+        ga += 1 - 2 * dm;
+        gb = 2 * dm - 1;
+      }
+    }
+    sh.corr[buf][iq][0][q] = (uint8_t)fp4_code(ga);
+    sh.corr[buf][iq][1][q] = (uint8_t)fp4_code(gb);
   }
 }
 
@@ -181,7 +230,7 @@ __device__ void mx_vector_phase2(MxShared &sh, int buf, int tid)
 
 // ---- one MFMA pass: acc[stream][tile] += chips x Toeplitz(vector) -------------------------------------------------------
 __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][kMxTiles],
-                                        u32 scale_b)
+                                        u32 scale_b, v4i a_corr, bool with_corr)
 {
   const int n = lane & 31, h = lane >> 5;
   const u32 *wi = &sh.e8[buf][0][n & 7][4 * (q0_tile + h) + (n >> 3)];
@@ -203,6 +252,20 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
                                                                    0, scale_b);
       acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fq), acc[1][j], 4, 4, 0, kScaleOne,
                                                                    0, scale_b);
+    }
+  }
+  if (with_corr) {   // wave-uniform
+    // the extra K step: only column 0 of each lane half of A is set (chip 1022 / chip 1021 of the PRN), so only the first
+    // nibble of a lane's B window counts: the step's delta for (stream, term h, q), one byte per lane
+#pragma unroll
+    for (int j = 0; j < kMxTiles; j++) {
+      const int q = 32 * (q0_tile + 2 * j) + n;
+      const v4i gi = v4i{(int)sh.corr[buf][0][h][q], 0, 0, 0};
+      const v4i gq = v4i{(int)sh.corr[buf][1][h][q], 0, 0, 0};
+      acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gi), acc[0][j], 4, 4, 0, kScaleOne, 0,
+                                                                   kScaleOne);
+      acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gq), acc[1][j], 4, 4, 0, kScaleOne, 0,
+                                                                   kScaleOne);
     }
   }
 }
@@ -228,27 +291,102 @@ __device__ __forceinline__ u32 half_sum_to_lane31(u32 v)
   return v;
 }
 
-// ---- epilogue of one sample offset: corrections of the reference's quirks, magnitude, windowed max / sum ----------------
-// (port of poly_finish_offset to the accumulator layout; the corrections in their linear form
-//    cnt = K(q) - 2 M + c1022 A(q) + c1021 B(q) - chip[p1 - 1] alpha - chip[p1] beta,   p1 = 1022 - q,
-//  K, A, B per lane and stream, alpha, beta per wave and stream; the last three terms only for odd byte offsets)
+// gps_correlation8's magnitude (PM/GPS/gps_misc.c:106-118) on the centred counts as the accumulators hold them (exact
+// integers in f32): one-sided clip, the squares as f32 products -- the correctly rounded product of the exact square is what
+// (float)(I * I) is --, their f32 sum, the correctly rounded root (v_sqrt_f32 + the neighbour test, as mag8_fast), truncation.
+__device__ __forceinline__ u32 mag8_f32(float ci, float cq)
+{
+  const float i = __builtin_fmaxf(ci, 0.0f), q = __builtin_fmaxf(cq, 0.0f);
+  const float e = i * i + q * q;   // (-ffp-contract=off: two rounded products, one rounded sum)
+  float r = __builtin_amdgcn_sqrtf(e);
+  const float r_dn = __uint_as_float(__float_as_uint(r) - 1u);
+  const float r_up = __uint_as_float(__float_as_uint(r) + 1u);
+  const float res_dn = __builtin_fmaf(-r_dn, r, e);
+  const float res_up = __builtin_fmaf(-r_up, r, e);
+  r = res_dn <= 0.0f ? r_dn : r;
+  r = res_up > 0.0f ? r_up : r;
+  return (u32)(int)r;
+}
+
+constexpr float kOutside = -1048576.0f;   // start value of hypotheses outside the search window: stays negative, clips to 0
+
+// Start of a block: every accumulator = the part of  cnt - 8184  that does not depend on the code (even byte offsets)
+__device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int win_start,
+                                            int win_stop)
+{
+  const int n = lane & 31;
+  const float base_i = (float)((int)sh.ones[0] + 8192 - kHalf), base_q = (float)((int)sh.ones[1] + 8192 - kHalf);
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    const int o = 2 * q;
+    const bool in_win = q < kChips && o >= win_start && o < win_stop;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      acc[0][j][r] = in_win ? base_i : base_i + kOutside;
+      acc[1][j][r] = in_win ? base_q : base_q + kOutside;
+    }
+  }
+}
+
+// After the pass of sample offset 8 (the first odd byte offset, b = 0), before its epilogue: every quirk term jumps.
+//   cnt = C0 + c1022 A_b(q)                                                                    even offsets o = 2 q
+//   cnt = C0 + c1022 A_b(q) - [pop(W) + chip[1021 - q] alpha_b + chip[1022 - q] beta_b]        odd offsets o = 2 q + 1
+//            - T(q) [pop(P) + c1021 (b - 2 pop(P & low_b)) + c1022 (16 - b - 2 pop(P & high_b))]
+// A_b = 2 pop(byte_o & low_b) - b (quirk Q5); W = data bytes (2045, 0), the word at the wrap; P = data bytes (o - 2, o - 1),
+// T = [q > 0]: the two replica words odd offsets skip (quirk Q3); alpha_b = b, beta_b = 16 - 2 pop(W) - b because the low
+// byte of W (data byte 2045, never mixed) is zero.  At b = 0: A = 0, alpha = 0.
+__device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int win_start,
+                                               int win_stop)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8, wrap_q = (sh.d[1][0] & 0xFFu) << 8;
+  const float beta0_i = (float)(16 - 2 * (int)__popc(wrap_i)), beta0_q = (float)(16 - 2 * (int)__popc(wrap_q));
+  const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
+  const u32 f22 = sh.chip_t[1022 + 1] >> (4 * h);
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    const bool exists = q < kChips;
+    const int qc = exists ? q : 0;
+    const bool in0 = exists && 2 * q >= win_start && 2 * q < win_stop;
+    const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
+    // A_7 of the even offset goes, A_0 = 0 of the odd one comes
+    int fa_i = -(2 * (int)__popc(lds_byte(sh.d[0], 2 * qc) & 0x7Fu) - 7);
+    int fa_q = -(2 * (int)__popc(lds_byte(sh.d[1], 2 * qc) & 0x7Fu) - 7);
+    int fk_i = -popw_i, fk_q = -popw_q;
+    if (q > 0 && exists) {
+      const u32 prev_i = lds_byte(sh.d[0], 2 * qc - 1) | (lds_byte(sh.d[0], 2 * qc) << 8);
+      const u32 prev_q = lds_byte(sh.d[1], 2 * qc - 1) | (lds_byte(sh.d[1], 2 * qc) << 8);
+      fk_i -= (int)__popc(prev_i);
+      fk_q -= (int)__popc(prev_q);
+      fa_i -= 16 - 2 * (int)__popc(prev_i);
+      fa_q -= 16 - 2 * (int)__popc(prev_q);
+    }
+    float fkf_i = (float)fk_i, fkf_q = (float)fk_q;
+    if (in0 != in1) {   // the window edge falls between the two byte offsets of this chip offset
+      fkf_i += in1 ? -kOutside : kOutside;
+      fkf_q += in1 ? -kOutside : kOutside;
+    }
+    const float faf_i = (float)fa_i, faf_q = (float)fa_q;
+    const u32 w1 = sh.chip_t[(exists ? kChips - 1 - q : 0) + 1] >> (4 * h);   // chip 1022 - q of the lane's PRNs
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int pb = (r & 3) + 8 * (r >> 2);
+      const float c22 = (float)((f22 >> pb) & 1u), c1 = (float)((w1 >> pb) & 1u);
+      acc[0][j][r] += fkf_i + c22 * faf_i - c1 * beta0_i;
+      acc[1][j][r] += fkf_q + c22 * faf_q - c1 * beta0_q;
+    }
+  }
+}
+
+// ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
 template <bool MULTI>
 __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
-                                            int win_start, int win_stop, u32 group_mask, u32 *__restrict__ energy,
-                                            bool ms_first, bool ms_last)
+                                            u32 group_mask, u32 *__restrict__ energy, bool ms_first, bool ms_last)
 {
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
-  const u32 low_mask = (1u << b) - 1u;
-  const u32 high_mask = (0xFFFFu << b) & 0xFFFFu;
-  const int base_i = (int)sh.ones[0] + 8192, base_q = (int)sh.ones[1] + 8192;   // C0 = pop(D) + 8192 - 2 M
-  // odd byte offsets skip the word at the wrap, data bytes (2045, 0): popcount against replica word p1 in linear form
-  const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8, wrap_q = (sh.d[1][0] & 0xFFu) << 8;
-  const int alpha_i = b - 2 * (int)__popc(wrap_i & low_mask), beta_i = (16 - b) - 2 * (int)__popc(wrap_i & high_mask);
-  const int alpha_q = b - 2 * (int)__popc(wrap_q & low_mask), beta_q = (16 - b) - 2 * (int)__popc(wrap_q & high_mask);
-  const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
-  // chip 1021 / 1022 of this lane's 16 PRNs: bit (r & 3) + 8 (r >> 2) after the shift by 4 h
-  const u32 f21 = sh.chip_t[1021 + 1] >> (4 * h), f22 = sh.chip_t[1022 + 1] >> (4 * h);
   u32 best[16], total[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -258,33 +396,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
-    const bool exists = q < kChips;
-    const int o = 2 * q + half;
-    const bool in_win = exists && o >= win_start && o < win_stop;
-    const int oc = exists ? o : 0;
-    int k_i = base_i, k_q = base_q;
-    int a_i = 2 * (int)__popc(lds_byte(sh.d[0], oc) & low_mask) - b;      // quirk Q5, PRNs whose chip 1022 is set
-    int a_q = 2 * (int)__popc(lds_byte(sh.d[1], oc) & low_mask) - b;
-    int b_i = 0, b_q = 0;
-    u32 w0 = 0, w1 = 0;
-    if (half) {
-      k_i -= popw_i;
-      k_q -= popw_q;
-      if (q > 0 && exists) {   // quirk Q3: replica word 1022 against data bytes (o - 2, o - 1)
-        const u32 prev_i = lds_byte(sh.d[0], oc - 2) | (lds_byte(sh.d[0], oc - 1) << 8);
-        const u32 prev_q = lds_byte(sh.d[1], oc - 2) | (lds_byte(sh.d[1], oc - 1) << 8);
-        k_i -= (int)__popc(prev_i);
-        k_q -= (int)__popc(prev_q);
-        a_i -= (16 - b) - 2 * (int)__popc(prev_i & high_mask);
-        a_q -= (16 - b) - 2 * (int)__popc(prev_q & high_mask);
-        b_i = -(b - 2 * (int)__popc(prev_i & low_mask));
-        b_q = -(b - 2 * (int)__popc(prev_q & low_mask));
-      }
-      const int p1 = exists ? kChips - 1 - q : 0;
-      w0 = sh.chip_t[p1] >> (4 * h);        // chip p1 - 1
-      w1 = sh.chip_t[p1 + 1] >> (4 * h);    // chip p1
-    }
-    const u32 key_lo = (u32)(2047 - o);
+    const u32 key_lo = (u32)(2047 - (2 * q + half)) & 2047u;   // (q = 1023 does not exist: its magnitude is 0, its key never wins)
 #pragma unroll
     for (int g = 0; g < 4; g++) {
       if (!((group_mask >> g) & 1u))   // wave-uniform: 8-PRN groups of other shards, or beyond the PRN list
@@ -300,16 +412,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int r = 4 * g + rr;
-        const int pb = (r & 3) + 8 * (r >> 2);
-        const int c22 = (int)((f22 >> pb) & 1u), c21 = (int)((f21 >> pb) & 1u);
-        int ci = k_i + __mul24((int)acc[0][j][r], -2) + __mul24(c22, a_i);
-        int cq = k_q + __mul24((int)acc[1][j][r], -2) + __mul24(c22, a_q);
-        if (half) {
-          const int c0 = (int)((w0 >> pb) & 1u), c1 = (int)((w1 >> pb) & 1u);
-          ci += __mul24(c21, b_i) - __mul24(c0, alpha_i) - __mul24(c1, beta_i);
-          cq += __mul24(c21, b_q) - __mul24(c0, alpha_q) - __mul24(c1, beta_q);
-        }
-        u32 val = in_win ? (u32)mag8_fast<false>(ci, cq) : 0u;   // (no wave-uniform shortcut: straight-line code schedules better here)
+        u32 val = mag8_f32(acc[0][j][r], acc[1][j][r]);
         if (MULTI) {
           val += ms_first ? 0u : prev[MULTI ? rr : 0];
           if (!ms_last)
@@ -425,6 +528,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       (&sh.e8[0][0][0][0])[i] = 0;   // the slack dwords are read (and their products discarded); keep them finite
   }
 
+  __syncthreads();
+  // A operand of the extra K step: column 0 of lane half 0 = chip 1022 of PRN (lane & 31), of half 1 = chip 1021
+  const v4i a_corr = v4i{(int)(((sh.chip_t[(lane >> 5 ? 1021 : 1022) + 1] >> (lane & 31)) & 1u) << 1), 0, 0, 0};
   u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 16 * 64) : nullptr;
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const int n_ms = MULTI ? prm.n_ms : 1;
@@ -435,18 +541,12 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms) * block_bytes, prm.if_format,
                      step_word, tid, lane);
     __syncthreads();
-    mx_vector_phase1(sh, 0, tid);
+    mx_vector_phase1(sh, 0, 0, tid);
     __syncthreads();
     mx_vector_phase2(sh, 0, tid);
 
     v16f acc[2][kMxTiles];
-#pragma unroll
-    for (int st = 0; st < 2; st++)
-#pragma unroll
-      for (int j = 0; j < kMxTiles; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-          acc[st][j][r] = 0.f;
+    mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
 
     // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
     // half step later.  The vector of pass p + 1 is built in half steps 2 p (copy 0) and 2 p + 1 (its shifted copies),
@@ -457,7 +557,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       const int p_vec = (hs >> 1) + 1;
       if (p_vec < kPasses && !(ex & 8)) {
         if ((hs & 1) == 0)
-          mx_vector_phase1(sh, p_vec, tid);
+          mx_vector_phase1(sh, p_vec, p_vec & 1, tid);
         else
           mx_vector_phase2(sh, p_vec & 1, tid);
       }
@@ -467,9 +567,11 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       const int p = x >> 1;
       if ((x & 1) == 0) {
         if (!(ex & 2))
-          mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleFour : kScaleOne);
+          mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && p != 9);
+        if (p == 9)
+          mx_half_switch(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
       } else if (p >= 1 && !(ex & 1)) {
-        mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, prm.win_start, prm.win_stop, group_mask, e_wave, ms_first, ms_last);
+        mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, ms_first, ms_last);
       }
     }
   }
