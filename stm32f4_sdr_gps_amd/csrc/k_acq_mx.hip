@@ -296,7 +296,10 @@ __device__ __forceinline__ u32 half_sum_to_lane31(u32 v)
 // (float)(I * I) is --, their f32 sum, the correctly rounded root (v_sqrt_f32 + the neighbour test, as mag8_fast), truncation.
 __device__ __forceinline__ u32 mag8_f32(float ci, float cq)
 {
-  const float i = __builtin_fmaxf(ci, 0.0f), q = __builtin_fmaxf(cq, 0.0f);
+  // (clip on the bit patterns: a negative float is a negative int; fmaxf() would first canonicalise its operand with a
+  //  second v_max_f32)
+  const int ib = (int)__float_as_uint(ci), qb = (int)__float_as_uint(cq);
+  const float i = __uint_as_float((u32)(ib < 0 ? 0 : ib)), q = __uint_as_float((u32)(qb < 0 ? 0 : qb));
   const float e = i * i + q * q;   // (-ffp-contract=off: two rounded products, one rounded sum)
   float r = __builtin_amdgcn_sqrtf(e);
   const float r_dn = __uint_as_float(__float_as_uint(r) - 1u);
@@ -397,10 +400,11 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
     const u32 key_lo = (u32)(2047 - (2 * q + half)) & 2047u;   // (q = 1023 does not exist: its magnitude is 0, its key never wins)
+    // (all four 8-PRN groups, whether this shard owns them or not: a workgroup that owns only some -- at the ends of a
+    //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
+    //  group_mask decides below what is published)
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      if (!((group_mask >> g) & 1u))   // wave-uniform: 8-PRN groups of other shards, or beyond the PRN list
-        continue;
       u32 prev[MULTI ? 4 : 1];
       u32 *e_ptr = nullptr;
       if (MULTI) {
@@ -422,20 +426,25 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         best[r] = key > best[r] ? key : best[r];
         total[r] += val;
       }
+      // four hypotheses at a time: enough independent chains to cover the ALU latencies, few enough to keep the 128
+      // accumulators and the 32 running results in registers (left alone, the compiler sinks all 64 chains to the
+      // reductions below, runs them side by side and spills): the results are pinned here, in program order
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        asm volatile("" : "+v"(best[4 * g + rr]), "+v"(total[4 * g + rr]));
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (MULTI && !ms_last)
     return;
 #pragma unroll
   for (int g = 0; g < 4; g++) {
-    if (!((group_mask >> g) & 1u))
-      continue;
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int r = 4 * g + rr;
       const u32 k = half_max_to_lane31(best[r]);
       const u32 t = half_sum_to_lane31(total[r]);
-      if (n == 31) {
+      if (n == 31 && ((group_mask >> g) & 1u)) {
         const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
         atomicMax(&sh.part[b][p][0], k);
         atomicAdd(&sh.part[b][p][1], t);
