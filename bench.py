@@ -50,6 +50,13 @@ VALU_INT_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12         # 39.3 T lane-ops/s: 64 int
 # cheapest epilogue that still yields the reference's integers (2 centre/scale, 2 clips, 2 squares+add, 4 issue slots of
 # quarter-rate v_sqrt_f32, 1 truncate, 3 for key/max/sum) = 14
 LANE_OPS_PER_HYP_MIN_MODEL = 146
+# Matrix-core kernel (k_acq_mx): the correlations of one (search, Doppler) pair x 32 PRNs are 17 FP4 GEMM
+# passes (2 for the first sample offset, 15 recurrence steps) x 2 streams of M = 32 PRNs, N = 1024 chip offsets, K = 1024
+# chips: 2 * 32 * 1024 * 1024 flops each -> per hypothesis (32 PRN x 16368 phases per pair) 17 * 2 * 2 * 1024 * 1024 / 16368
+MFMA_FLOPS_PER_HYP = 17 * 2 * 2.0 * 32 * 1024 * 1024 / (32 * 16368)      # = 4356 algorithmic FP4 flops per hypothesis
+MFMA_FP4_PEAK_TFLOPS = 10000.0                       # MI355X_MICROARCH.md: ~10 PF dense MX-FP4 (9.1 PF micro-benchmarked)
+LANE_OPS_PER_HYP_MIN_MODEL_MX = 16                   # what is left to the vector ALU per hypothesis: clip x2, square x2, add,
+                                                     # sqrt (2 slots), fix-up 6, truncate, key, max, sum
 
 
 def _ref_prn_slice(ref, blk, prn_list, deadline):
@@ -396,16 +403,37 @@ def main():
                     if (ent.get("kernel") == kernel and ent.get("searches_per_launch") == args.searches
                             and ent.get("n_ms") == n_ms and ent.get("world", 1) == 1):
                         counters = ent
+        is_mx = kernel.startswith("k_acq_mx")
+        valu = None
         if counters and counters.get("SQ_INSTS_VALU"):
             issued = counters["SQ_INSTS_VALU"] * 64.0                       # lane-ops per launch
             ach = issued / (launch_ms * 1e-3) / 1e12
-            roof = {"bound": "valu-int-issue", "achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
+            min_model = LANE_OPS_PER_HYP_MIN_MODEL_MX if is_mx else LANE_OPS_PER_HYP_MIN_MODEL
+            valu = {"bound": "valu-issue", "achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
                     "frac": ach / VALU_INT_PEAK_TOPS,
                     "ops_per_hyp_issued": issued / hyp_per_launch,
-                    "ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
-                    "useful_frac": LANE_OPS_PER_HYP_MIN_MODEL * hyp_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
+                    "ops_per_hyp_min_model": min_model,
+                    "useful_frac": min_model * hyp_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
                     "ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF,
-                    "counter_source": counters.get("source")}
+                    "counter_source": counters.get("source"),
+                    "note": "issued vector-ALU lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
+                            "time) against one wave64 op per 4 cycles per SIMD (256 CU x 64 lanes/clk x 2.4 GHz); a few op "
+                            "classes (and, add, f32 mul/fma) issue in 2 cycles (profiles/r02_valu_rates_microbench.txt), so "
+                            "a mix of them can read slightly above 1"}
+        if is_mx:
+            # the GEMM on the matrix cores is the dominant operation of this kernel: algorithmic FP4 flops / launch time
+            # against the dense MX-FP4 peak; the vector-ALU side (epilogue, vector building) is priced beside it
+            flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
+            ach = flops / (launch_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / MFMA_FP4_PEAK_TFLOPS, "flops_per_hyp": MFMA_FLOPS_PER_HYP, "dtype": "MX-FP4 (E2M1) x MX-FP4 -> f32",
+                    "mfma_busy_frac": (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (launch_ms * 1e-3 * clk_khz * 1e3))
+                                      if counters and counters.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
+                    "counter_source": counters.get("source") if counters else None}
+        elif valu is not None:
+            roof = dict(valu)
+            roof["bound"] = "valu-int-issue"
+            valu = None
         else:
             # no committed counters for this kernel / shape: price the formulation's own lower bound instead (<= issued)
             ach = LANE_OPS_PER_HYP_MIN_MODEL * hyp_per_launch / (launch_ms * 1e-3) / 1e12
@@ -423,10 +451,15 @@ def main():
             "reference_equivalent_stream_gbs": hyp_per_launch * BYTES_PER_HYP / (launch_ms * 1e-3) / 1e9,
             "kernel": "gpsx::" + kernel,
             "kernel_ms": launch_ms,
-            "note": "operands stay in LDS, HBM traffic is ~0 by construction: the binding resource is integer VALU issue. "
-                    "achieved = issued lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
-                    "time); peak = 256 CU x 64 lanes/clk x 2.4 GHz (micro-benchmarked); reference_equivalent_stream_gbs is "
-                    "6138 B/hypothesis as the reference re-reads its operands -- information, not a fraction of anything",
+            "note": ("operands stay in LDS, HBM traffic is ~0 by construction.  The correlations run as an MX-FP4 Toeplitz GEMM "
+                     "on the matrix cores: achieved = algorithmic flops (17 passes x 2 streams x 2*32*1024*1024 per (search, "
+                     "Doppler) pair) / this run's launch time, peak = dense FP4; the vector ALU (clip, square, root, search) "
+                     "runs beside it, see roofline_valu" if is_mx else
+                     "operands stay in LDS, HBM traffic is ~0 by construction: the binding resource is integer VALU issue. "
+                     "achieved = issued lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
+                     "time); peak = 256 CU x 64 lanes/clk x 2.4 GHz (micro-benchmarked)") +
+                    "; reference_equivalent_stream_gbs is 6138 B/hypothesis as the reference re-reads its operands -- "
+                    "information, not a fraction of anything",
         })
         line = {
             "metric": "acquisition hypotheses/sec (PRN x Doppler x phase)",
@@ -439,7 +472,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u1 (bit planes; u32 popcount accumulators)",
+            "dtype": "u1 samples; MX-FP4 operands, exact f32 accumulation (integers < 2^24)" if is_mx else "u1 (bit planes; u32 popcount accumulators)",
             "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11; "
                     f"{'4092-byte 2-bit' if two_bit else '2046-byte 1-bit'} blocks)",
             "config": {
@@ -456,6 +489,7 @@ def main():
                 "inputs": "resident in HBM when the timed region starts; results left in HBM (pcie_inclusive: host to host)",
             },
             "roofline": roof,
+            **({"roofline_valu": valu} if valu is not None else {}),
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }
         if pcie is not None:

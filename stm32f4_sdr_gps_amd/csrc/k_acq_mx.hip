@@ -165,11 +165,11 @@ __device__ __forceinline__ u32 fp4_code(int v)
 // ---- per pass: the nibble vector, copy 0 (phase 1), then its eight shifted copies (phase 2) --------------------------------
 // pass 0: -2 (S_0 & 3), pass 1: -(S_0 >> 2) at scale 2^3, pass p >= 2 (producing sample offset t0 = p - 1 from plane
 // p - 2): -2 e_{p-2}, plus the wrap-word impulses when t0 is 9..15; and the byte vectors of the extra K step.
-__device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid)
+__device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid, int nthreads)
 {
   const int t0 = pass - 1;
   // nibbles 0 .. 2055 are ever read (dword 4 * 62 + 3 + 3 of copy 7): 258 dwords of copy 0
-  for (int m = tid; m < 2 * kVecDwords; m += kMxThreads) {
+  for (int m = tid; m < 2 * kVecDwords; m += nthreads) {
     const int iq = m / kVecDwords, dw = m - iq * kVecDwords;
     u32 packed = 0;
     if (pass < 2) {
@@ -199,7 +199,7 @@ __device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid)
     sh.base[iq][dw] = packed;
   }
   // extra K step: deltas of  c1022 * A'(q)  and  c1021 * B'(q)  (see mx_half_switch for the terms themselves)
-  for (int m = tid; m < 2 * 1024; m += kMxThreads) {
+  for (int m = tid; m < 2 * 1024; m += nthreads) {
     const int iq = m >> 10, q = m & 1023;
     int ga = 0, gb = 0;
     if (pass >= 2 && t0 != 8 && q < kChips) {
@@ -217,9 +217,9 @@ __device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid)
   }
 }
 
-__device__ void mx_vector_phase2(MxShared &sh, int buf, int tid)
+__device__ void mx_vector_phase2(MxShared &sh, int buf, int tid, int nthreads)
 {
-  for (int m = tid; m < 2 * 256; m += kMxThreads) {
+  for (int m = tid; m < 2 * 256; m += nthreads) {
     const int iq = m >> 8, j = m & 255;
     const u32 lo = sh.base[iq][j], hi = sh.base[iq][j + 1];
 #pragma unroll
@@ -396,6 +396,13 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     best[r] = 0;
     total[r] = 0;
   }
+  // MULTI: the running sums of the next four hypotheses are fetched one group ahead (the scratch is HBM: ~1 us away)
+  u32 nxt[MULTI ? 4 : 1];
+  if (MULTI) {
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++)
+      nxt[MULTI ? rr : 0] = ms_first ? 0u : energy[(size_t)((t0 * kMxTiles) * 16 + rr) * 64 + lane];
+  }
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
@@ -411,14 +418,20 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         e_ptr = energy + ((size_t)((t0 * kMxTiles + j) * 16 + 4 * g) * 64 + lane);
 #pragma unroll
         for (int rr = 0; rr < 4; rr++)
-          prev[MULTI ? rr : 0] = e_ptr[rr * 64];
+          prev[MULTI ? rr : 0] = nxt[MULTI ? rr : 0];
+        if (!ms_first && !(j == kMxTiles - 1 && g == 3)) {
+          const u32 *e_nxt = e_ptr + 4 * 64;   // the next group of this tile, or the first of the next tile
+#pragma unroll
+          for (int rr = 0; rr < 4; rr++)
+            nxt[MULTI ? rr : 0] = e_nxt[rr * 64];
+        }
       }
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int r = 4 * g + rr;
         u32 val = mag8_f32(acc[0][j][r], acc[1][j][r]);
         if (MULTI) {
-          val += ms_first ? 0u : prev[MULTI ? rr : 0];
+          val += prev[MULTI ? rr : 0];
           if (!ms_last)
             e_ptr[rr * 64] = val;
         }
@@ -533,8 +546,6 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       sh.chip_t[i] = src_t[i];
     for (int i = tid; i < 8 * 32 * 2; i += kMxThreads)
       (&sh.part[0][0][0])[i] = 0;
-    for (int i = tid; i < 2 * 2 * 8 * kCopyDwords; i += kMxThreads)
-      (&sh.e8[0][0][0][0])[i] = 0;   // the slack dwords are read (and their products discarded); keep them finite
   }
 
   __syncthreads();
@@ -550,38 +561,45 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms) * block_bytes, prm.if_format,
                      step_word, tid, lane);
     __syncthreads();
-    mx_vector_phase1(sh, 0, 0, tid);
+    mx_vector_phase1(sh, 0, 0, tid, kMxThreads);
     __syncthreads();
-    mx_vector_phase2(sh, 0, tid);
+    mx_vector_phase2(sh, 0, tid, kMxThreads);
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
 
     // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
     // half step later.  The vector of pass p + 1 is built in half steps 2 p (copy 0) and 2 p + 1 (its shifted copies),
-    // into the buffer whose last reader (role 1, pass p - 1) finished in half step 2 p - 1.
+    // into the buffer whose last reader (role 1, pass p - 1) finished in half step 2 p - 1 -- by the four waves whose
+    // turn it is on the matrix pipe, after their pass: that phase is the shorter one, the epilogue waves are not held up.
 #pragma unroll 1
     for (int hs = 0; hs <= 2 * kPasses; hs++) {
       __syncthreads();
       const int p_vec = (hs >> 1) + 1;
-      if (p_vec < kPasses && !(ex & 8)) {
-        if ((hs & 1) == 0)
-          mx_vector_phase1(sh, p_vec, p_vec & 1, tid);
-        else
-          mx_vector_phase2(sh, p_vec & 1, tid);
-      }
+      const bool build = p_vec < kPasses && !(ex & 8) && ((ex & 4) || role == (hs & 1));
+      const int b_tid = (ex & 4) ? tid : (tid & 255), b_n = (ex & 4) ? kMxThreads : 256;
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
-      if (x < 0 || x >= 2 * kPasses)
-        continue;
+      const bool active = x >= 0 && x < 2 * kPasses;
       const int p = x >> 1;
-      if ((x & 1) == 0) {
-        if (!(ex & 2))
+      if (active && (x & 1) == 0) {
+        if (!(ex & 2)) {
+          if (ex & 16)
+            __builtin_amdgcn_s_setprio(3);
           mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && p != 9);
+          if (ex & 16)
+            __builtin_amdgcn_s_setprio(0);
+        }
         if (p == 9)
           mx_half_switch(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-      } else if (p >= 1 && !(ex & 1)) {
-        mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, ms_first, ms_last);
       }
+      if (build) {
+        if ((hs & 1) == 0)
+          mx_vector_phase1(sh, p_vec, p_vec & 1, b_tid, b_n);
+        else
+          mx_vector_phase2(sh, p_vec & 1, b_tid, b_n);
+      }
+      if (active && (x & 1) && p >= 1 && !(ex & 1))
+        mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, ms_first, ms_last);
     }
   }
   __syncthreads();

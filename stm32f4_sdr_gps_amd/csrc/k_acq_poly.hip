@@ -217,8 +217,10 @@ __device__ __forceinline__ void poly_finish_offset(PolyShared<G, SEG> &sh, int t
 
 }  // namespace
 
+// (kPolyMulti: two workgroups per CU -- 256 registers per lane: at three its 64 + 64 accumulators spilled 50 VGPRs to
+//  scratch; it is the fallback now, the matrix-core kernel takes the launches large enough to walk their blocks)
 template <int G, int SEG, int MODE>
-__global__ __launch_bounds__(kThreads, 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
+__global__ __launch_bounds__(kThreads, MODE == kPolyMulti ? 2 : 3) void k_acq_poly(const AcqParams prm, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ cw8, const u32 *__restrict__ chipbits,
                                                           u32 *__restrict__ keyacc, u32 *__restrict__ sumacc,
                                                           gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy)

@@ -79,8 +79,11 @@ def main(tag="r02", searches=64, n_ms=1, pattern=None):
                 "gpu_cycles_per_launch": cycles,
                 "valu_issue_cycles_per_simd": c["SQ_INSTS_VALU"] * 4.0 / 1024.0,   # 4 cycles per wave64 int op, 1024 SIMDs
                 "valu_issue_utilisation": c["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cycles})
-        if "SQ_INSTS_VALU_MFMA_MOPS_I8" in c or "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-            entry["SQ_VALU_MFMA_BUSY_CYCLES"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES")
+        for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA"):
+            if k in c:
+                entry[k] = c[k]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            summary["derived"]["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
     with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     kc_path = os.path.join(dst, "kernel_counters.json")
