@@ -185,6 +185,9 @@ def main():
                          "unpacked to the sign plane in LDS inside the kernels (the reference's correlator never looks at "
                          "the magnitude bit either); 1bit = the 2046-byte sign stream the firmware's SPI delivers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true",
+                    help="skip the pcie_inclusive leg (profiling runs: its two concurrent contexts stretch the kernel durations "
+                         "a kernel trace averages)")
     ap.add_argument("--no-tracking", action="store_true",
                     help="skip the secondary metric (real-time tracking channels: E/P/L steps of growing channel counts)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -303,7 +306,7 @@ def main():
     # alternately through gpsx_acq_grid_async, so one call's transfers overlap the other's sweep -- what a host streaming
     # captures through the engine does.  `serial` is the one-context, synchronous gpsx_acq_grid() loop of round 1.
     pcie = None
-    if world == 1 and n_ms == 1:
+    if world == 1 and n_ms == 1 and not args.no_pcie:
         g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
                            dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
         engs = [capi.Engine(dev_index), capi.Engine(dev_index)]     # own non-blocking streams

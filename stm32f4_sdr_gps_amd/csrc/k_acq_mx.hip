@@ -383,80 +383,94 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
   }
 }
 
-// ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
-template <bool MULTI>
-__device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
-                                            u32 group_mask, u32 *__restrict__ energy, bool ms_first, bool ms_last)
+// MULTI: request the running sums of sample offset t0, records [first, first + count) of this lane's 16; zero for the first
+// block.  The first tile's records are requested before the wave's MFMA pass, the next tile's at the start of each tile
+// of the epilogue: always ~1 us ahead of their use, never more than 8 records in registers.
+template <int FIRST, int COUNT>
+__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first, uint4 (&pre)[16])
 {
+  const uint4 *e4 = reinterpret_cast<const uint4 *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
+#pragma unroll
+  for (int i = FIRST; i < FIRST + COUNT; i++)
+    pre[i] = ms_first ? uint4{0, 0, 0, 0} : e4[(size_t)i * 64];
+}
+
+// ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
+// SEARCH = false (MULTI, not the last block): only the running sums move on -- no key, no maximum, no window sum
+template <bool MULTI, bool SEARCH>
+__device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
+                                            u32 group_mask, u32 *__restrict__ energy, uint4 (&pre)[MULTI ? 16 : 1],
+                                            bool ms_first)
+{
+  constexpr bool ms_last = SEARCH;
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
-  u32 best[16], total[16];
+  u32 best[SEARCH ? 16 : 1], total[SEARCH ? 16 : 1];
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
+  for (int r = 0; r < (SEARCH ? 16 : 1); r++) {
     best[r] = 0;
     total[r] = 0;
   }
-  // MULTI: the running sums of the next four hypotheses are fetched one group ahead (the scratch is HBM: ~1 us away)
-  u32 nxt[MULTI ? 4 : 1];
-  if (MULTI) {
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++)
-      nxt[MULTI ? rr : 0] = ms_first ? 0u : energy[(size_t)((t0 * kMxTiles) * 16 + rr) * 64 + lane];
-  }
+  // MULTI: the running sums of a lane's four hypotheses of a group are one 16-byte record ([offset][tile][group][lane][4]:
+  // a wave reads / writes 1 KB per instruction); the 16 records of this offset were requested before the wave's MFMA pass
+  // (mx_prefetch_sums) -- the scratch is HBM, the pass hides its latency
+  uint4 *e4 = reinterpret_cast<uint4 *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
     const u32 key_lo = (u32)(2047 - (2 * q + half)) & 2047u;   // (q = 1023 does not exist: its magnitude is 0, its key never wins)
+    if constexpr (MULTI) {
+      if (j == 0)
+        mx_prefetch_sums<4, 4>(energy, lane, t0, ms_first, pre);
+      if (j == 1)
+        mx_prefetch_sums<8, 4>(energy, lane, t0, ms_first, pre);
+      if (j == 2)
+        mx_prefetch_sums<12, 4>(energy, lane, t0, ms_first, pre);
+    }
     // (all four 8-PRN groups, whether this shard owns them or not: a workgroup that owns only some -- at the ends of a
     //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
     //  group_mask decides below what is published)
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      u32 prev[MULTI ? 4 : 1];
-      u32 *e_ptr = nullptr;
-      if (MULTI) {
-        e_ptr = energy + ((size_t)((t0 * kMxTiles + j) * 16 + 4 * g) * 64 + lane);
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-          prev[MULTI ? rr : 0] = nxt[MULTI ? rr : 0];
-        if (!ms_first && !(j == kMxTiles - 1 && g == 3)) {
-          const u32 *e_nxt = e_ptr + 4 * 64;   // the next group of this tile, or the first of the next tile
-#pragma unroll
-          for (int rr = 0; rr < 4; rr++)
-            nxt[MULTI ? rr : 0] = e_nxt[rr * 64];
-        }
-      }
+      const uint4 rec = pre[MULTI ? j * 4 + g : 0];
+      const u32 prev[4] = {rec.x, rec.y, rec.z, rec.w};
+      uint4 *e_rec = e4 + (size_t)(j * 4 + g) * 64;
+      u32 out[4];
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int r = 4 * g + rr;
         u32 val = mag8_f32(acc[0][j][r], acc[1][j][r]);
-        if (MULTI) {
-          val += prev[MULTI ? rr : 0];
-          if (!ms_last)
-            e_ptr[rr * 64] = val;
+        if (MULTI)
+          val += prev[rr];
+        out[rr] = val;
+        if (SEARCH) {
+          const u32 key = (val << 11) | key_lo;
+          best[SEARCH ? r : 0] = key > best[SEARCH ? r : 0] ? key : best[SEARCH ? r : 0];
+          total[SEARCH ? r : 0] += val;
         }
-        const u32 key = (val << 11) | key_lo;
-        best[r] = key > best[r] ? key : best[r];
-        total[r] += val;
       }
+      if (MULTI && !ms_last)
+        *e_rec = uint4{out[0], out[1], out[2], out[3]};
       // four hypotheses at a time: enough independent chains to cover the ALU latencies, few enough to keep the 128
       // accumulators and the 32 running results in registers (left alone, the compiler sinks all 64 chains to the
       // reductions below, runs them side by side and spills): the results are pinned here, in program order
+      if (SEARCH) {
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++)
-        asm volatile("" : "+v"(best[4 * g + rr]), "+v"(total[4 * g + rr]));
+        for (int rr = 0; rr < 4; rr++)
+          asm volatile("" : "+v"(best[SEARCH ? 4 * g + rr : 0]), "+v"(total[SEARCH ? 4 * g + rr : 0]));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (MULTI && !ms_last)
+  if (!SEARCH)
     return;
 #pragma unroll
   for (int g = 0; g < 4; g++) {
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
       const int r = 4 * g + rr;
-      const u32 k = half_max_to_lane31(best[r]);
-      const u32 t = half_sum_to_lane31(total[r]);
+      const u32 k = half_max_to_lane31(best[SEARCH ? r : 0]);
+      const u32 t = half_sum_to_lane31(total[SEARCH ? r : 0]);
       if (n == 31 && ((group_mask >> g) & 1u)) {
         const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
         atomicMax(&sh.part[b][p][0], k);
@@ -567,6 +581,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+    uint4 pre[MULTI ? 16 : 1];
 
     // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
     // half step later.  The vector of pass p + 1 is built in half steps 2 p (copy 0) and 2 p + 1 (its shifted copies),
@@ -582,6 +597,10 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       const bool active = x >= 0 && x < 2 * kPasses;
       const int p = x >> 1;
       if (active && (x & 1) == 0) {
+        if constexpr (MULTI) {
+          if (p >= 1)
+            mx_prefetch_sums<0, 4>(e_wave, lane, p - 1, ms_first, pre);
+        }
         if (!(ex & 2)) {
           if (ex & 16)
             __builtin_amdgcn_s_setprio(3);
@@ -598,8 +617,12 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         else
           mx_vector_phase2(sh, p_vec & 1, b_tid, b_n);
       }
-      if (active && (x & 1) && p >= 1 && !(ex & 1))
-        mx_epilogue<MULTI>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, ms_first, ms_last);
+      if (active && (x & 1) && p >= 1 && !(ex & 1)) {
+        if (MULTI && !ms_last)
+          mx_epilogue<MULTI, false>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);
+        else
+          mx_epilogue<MULTI, true>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);
+      }
     }
   }
   __syncthreads();
@@ -647,11 +670,11 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   if (prm.n_ms > 1) {
     hipLaunchKernelGGL(k_acq_mx<true>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                        d_peaks, d_energy);
-    return "k_acq_mx<1>";
+    return "k_acq_mx<true>";
   }
   hipLaunchKernelGGL(k_acq_mx<false>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                      d_peaks, (u32 *)nullptr);
-  return "k_acq_mx<0>";
+  return "k_acq_mx<false>";
 }
 
 }  // namespace gpsx

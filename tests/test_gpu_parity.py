@@ -802,14 +802,14 @@ def test_matrix_core_grid_vs_oracle(eng_mx, oracle, stream):
     captures, and the 10-block non-coherent sum (BASELINE.json configs[3]'s integration) on a 5-PRN list."""
     prns = np.arange(1, 33, dtype=np.uint8)
     peaks, keys = eng_mx.acq_grid(stream[:2], prns, n_search=2, dopp_min_hz=500, dopp_step_hz=1500, n_dopp=3)
-    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<0>"
+    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<false>"
     for s in range(2):
         want = oracle.acq_grid(stream[s:s + 1], 1, prns, 500, 1500, 3, 8, n_threads=8)
         for f in ("max_val", "phase", "sum", "avr"):
             assert np.array_equal(peaks[s][f], want[f]), (s, f)
     prns5 = np.array([5, 14, 20, 30, 7], np.uint8)
     peaks, _ = eng_mx.acq_grid(stream[:10], prns5, n_search=1, n_ms=10, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
-    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<1>"
+    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<true>"
     want = oracle.acq_grid(stream[:10], 10, prns5, -1000, 500, 5, 8, n_threads=8)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(peaks[0][f], want[f]), f
