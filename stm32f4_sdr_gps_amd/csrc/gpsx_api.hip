@@ -627,7 +627,7 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, d_st, n_ch, ctx->d_chips_all,
-                   d_iq_out);
+                   ctx->d_bits_all, d_iq_out);
   LAUNCHCHK(ctx, "k_track_epl");
   return GPSX_OK;
 }
@@ -688,7 +688,7 @@ gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch, size_t blk_by
     ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
       ok = hipMemcpyAsync(t.d_buf, t.h_in, t.in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-      launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, d_st, n_ch, ctx->d_chips_all, d_iq);
+      launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all, d_iq);
       ok = ok && hipGetLastError() == hipSuccess &&
            hipMemcpyAsync(t.h_out, d_st, t.out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
       ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;

@@ -112,7 +112,7 @@ void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int firs
 
 // K2+K3+K5 tracking correlators, one workgroup per channel
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
-                      const uint8_t *d_chips, int16_t *d_iq);
+                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq);
 // N3: 2-bit sign/magnitude samples -> two 1-bit planes
 void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag);
 void launch_rewind(hipStream_t s, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps);

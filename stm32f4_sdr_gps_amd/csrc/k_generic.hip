@@ -256,48 +256,71 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K5, many channels: one WAVE per tracking channel and millisecond, four channels per workgroup (from 2048 channels on:
-// 30 % less time per channel than the workgroup-per-channel form above, which has the shorter latency for a few).
-//   fine = (int16) code_phase_fine;  replica shift = fine & 7;  prompt offset = fine / 8, early = prompt - 1
+// K5, many channels: one WAVE per tracking channel and millisecond, four channels per workgroup (from 2048 channels on).
+//   fine = (int16) code_phase_fine;  replica shift b = fine & 7;  prompt offset = fine / 8, early = prompt - 1
 //   (wraps to 2045), late = prompt + 1 (wraps to 0)                                   PM/GPS/tracking.c:115-130
 //   carrier NCO continues from if_freq_accum at (float)IF + if_freq_offset_hz and is stored back  gps_misc.c:244-274
-// The wave stages the channel's replica words and its wiped I / Q streams in LDS -- the streams with four bytes of
-// circular padding in front and six behind, so that the 16 data bits replica word i meets at byte offset
-// (o + 2 i) mod 2046 and their neighbours one byte either side are one contiguous 32-bit window -- and then walks the
-// 1023 replica words once: one replica read and one two-dword read per stream serve Early, Prompt and Late together
-// whenever they are the neighbours they normally are (any other triple of offsets, e.g. out of a negative code phase,
-// takes one window per offset).  gps_mult_and_summ's rules (PM/GPS/gps_misc.c:60-90) per offset: odd offsets skip word
-// p1 = (2046 - o) / 2 and word 1022.
+// Sample-stream formulation: gps_mult_and_summ at byte offset o pairs replica word i with data bytes (o + 2 i) mod 2046
+// (PM/GPS/gps_misc.c:60-90), i.e. replica BIT s with wiped sample (8 o + s) mod 16368 -- a rotation of the stream.  The
+// count over all 1023 words is therefore  pop(rot(D, 8 o) ^ R)  on 32-bit words: 512 XOR + popcount pairs per stream and
+// offset where the 16-bit form needs 1023 (plus their masks).  R, the replica as a bit stream -- chips delayed by b
+// samples, its first b bits zero (quirk Q5) -- is never stored: word j is cut from chips 2 j - 1 .. 2 j + 1 of the
+// packed code.  The wiped stream sits in LDS as 32-bit words with three words of continuation past the wrap (16368 =
+// 511.5 words: after the wrap the stream is 16 bits out of step), so any window starting before the wrap is two
+// neighbouring words.  Odd offsets then take back the two words the reference skips: p1 = (2045 - o) / 2, which pairs with
+// data bytes (2045, 0), and word 1022 (unless it is p1).  The four channels of a workgroup share one staging of the
+// block's sign plane (the 2-bit unpack happens once per workgroup, not once per channel).
+// r1 -> r2: 1231 -> 546 vector instructions per channel, 408 -> 223 us for 212 992 channels (profiles/r02_track_*).
 namespace {
 
 struct TrackLds {
-  u32 w[2][516];       // wiped stream, I / Q: byte k of w = data byte (k - 4) mod 2046
-  uint16_t rep[1024];  // replica words
+  // the wiped streams as (I, Q) word pairs, two periods back to back (16368 samples = 511.5 words: the second period sits 16
+  // bits out of step), one zero pair in front: pair 1 + w = word w; words 0..510 mixed, the low half of 511 = the sixteen
+  // never-mixed (zero) samples, its high half = samples 0..15 again, and so on to word 1022.  Any 32-bit window of the
+  // circular stream that starts in the first period is two neighbouring pairs: one 16-byte read serves I and Q.
+  uint2 dd[1026];
+  u32 cb[36];       // packed chips with one zero word in front (chip -1 = 0) and zeros behind
 };
 
-__device__ __forceinline__ u32 window32(const u32 *w, int byte_index)   // 32 bits from padded byte index
+__device__ __forceinline__ uint4 lds_read_pairs(const uint2 *p)   // p[0], p[1]: 8-byte aligned, one LDS instruction
 {
-  const int j = byte_index >> 2;
-  return __builtin_amdgcn_alignbit(w[j + 1], w[j], 8u * (u32)(byte_index & 3));
+  uint4 v;
+  __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 16);
+  return v;
 }
 
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restrict__ if_block, int if_format,
                                                         gpsx_trk_state_t *__restrict__ st, int n_ch,
-                                                        const uint8_t *__restrict__ chips_all,
+                                                        const u32 *__restrict__ chipbits_all,
                                                         int16_t *__restrict__ iq_out)
 {
+  __shared__ u32 s_x[512];
+  __shared__ uint2 s_carrier[4];   // (in-phase, quadrature) carrier word per NCO quadrant: one LDS read instead of two selects
   __shared__ TrackLds lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ch_raw = blockIdx.x * 4 + wave;
   const bool live = ch_raw < n_ch;
   const int ch = live ? ch_raw : n_ch - 1;   // idle waves of the last workgroup shadow a real channel (no early exit
-                                             // before the barriers) and write nothing
+                                             // before the barrier) and write nothing
   TrackLds &L = lds[wave];
+  if (threadIdx.x < 4)
+    s_carrier[threadIdx.x] = uint2{carrier_i(threadIdx.x), carrier_q(threadIdx.x)};
   const gpsx_trk_state_t state = st[ch];
   const int prn = state.prn >= 0 && state.prn <= GPSX_MAX_PRN ? state.prn : 0;
-  const uint8_t *chips = chips_all + (size_t)prn * 1024;
+
+  // the block's sign plane as 32-bit words, once per workgroup (word 511 = 16-bit word 1022 alone)
+  for (int w = threadIdx.x; w < 512; w += 256) {
+    const u32 lo = load_sign16(if_block, 2 * w, if_format);
+    const u32 hi = 2 * w + 1 < kWords16 ? (u32)load_sign16(if_block, 2 * w + 1, if_format) : 0u;
+    s_x[w] = lo | (hi << 16);
+  }
+  if (lane < 36)
+    L.cb[lane] = (lane >= 1 && lane <= 32) ? chipbits_all[(size_t)prn * 32 + (lane - 1)] : 0u;
+  if (lane == 0)
+    L.dd[0] = uint2{0u, 0u};
+  __syncthreads();
 
   const int fine = (int)(int16_t)(int)state.code_phase_fine;
   const u32 b = (u32)fine & 7u;
@@ -305,36 +328,34 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
   const float freq_hz = (float)kIfHz + state.if_freq_offset_hz;
   const u32 step = nco_step_per_word(freq_hz);
 
-  // replica words (K2) and the wiped streams (K3): dword w of the block -> padded dword w + 1
-  for (int i = lane; i < 1024; i += 64) {
-    const u32 prev = (i > 0 && i <= kWords16) ? chips[i - 1] : 0u;
-    const u32 cur = i < kWords16 ? chips[i] : 0u;
-    L.rep[i] = (uint16_t)((prev ? low : 0u) | (cur ? high : 0u));
-  }
-  for (int w = lane; w < 512; w += 64) {
-    u32 vi = 0, vq = 0;   // dword 511 = word 1022 + nothing: the 16 samples the NCO loop never mixes read as zero
-    if (w < kWords32) {
-      const u32 x = (u32)load_sign16(if_block, 2 * w, if_format) | ((u32)load_sign16(if_block, 2 * w + 1, if_format) << 16);
-      const u32 quad = (state.if_freq_accum + step * (u32)w) >> 30;
-      vi = carrier_i(quad) ^ x;
-      vq = carrier_q(quad) ^ x;
+  // K3: wipe-off, word w sees NCO phase accum + w * step
+  {
+    u32 acc = state.if_freq_accum + step * (u32)lane;
+    const u32 step64 = step * 64u;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int w = lane + 64 * it;
+      u32 vi = 0, vq = 0;   // word 511: the 16 samples the NCO loop never mixes read as zero (PM/GPS/gps_misc.c:229,261)
+      if (w < kWords32) {
+        const u32 x = s_x[w];
+        const uint2 c = s_carrier[acc >> 30];
+        vi = c.x ^ x;
+        vq = c.y ^ x;
+      }
+      L.dd[1 + w] = uint2{vi, vq};
+      acc += step64;
     }
-    L.w[0][w + 1] = vi;
-    L.w[1][w + 1] = vq;
+    // the second period: word 511 + m = word (m - 1) >> 16 | word m << 16, m = 0..511 (word -1 = the zero pair in front, word
+    // 511 of the first period = zero: its low half is all this needs, and its slot is being overwritten meanwhile)
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int m = lane + 64 * it;
+      uint4 v = lds_read_pairs(&L.dd[m]);
+      if (it == 7 && lane == 63)
+        v.z = v.w = 0u;
+      L.dd[1 + kWords32 + m] = uint2{__builtin_amdgcn_alignbit(v.z, v.x, 16u), __builtin_amdgcn_alignbit(v.w, v.y, 16u)};
+    }
   }
-  __syncthreads();
-  if (lane < 2) {
-    // circular padding: bytes -4..-1 = data bytes 2042..2045 (dword 511's low half holds 2044, 2045; 2046, 2047 are
-    // outside the circle), bytes 2046..2051 = data bytes 0..5
-    u32 *w = L.w[lane];
-    const u32 tail = (w[511] >> 16) | (w[512] << 16);                 // data bytes 2042..2045
-    const u32 head0 = w[1], head1 = w[2];                              // data bytes 0..3, 4..7
-    w[0] = tail;
-    w[512] = (w[512] & 0xFFFFu) | (head0 << 16);                       // 2044, 2045, then 0, 1
-    w[513] = (head0 >> 16) | (head1 << 16);                            // 2, 3, 4, 5
-    w[514] = head1 >> 16;
-  }
-  __syncthreads();
 
   // offsets exactly as tracking.c forms them, then reduced to the circle
   const unsigned prompt = (unsigned)(uint16_t)(fine / 8);
@@ -346,47 +367,67 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
     if (off[k] > 2u * kChips) off[k] = 0u;   // the reference would read out of bounds here; keep the access in range
     if (off[k] == 2u * kChips) off[k] = 0u;  // offset 2046 behaves as 0
   }
-  int p1[3];
-  bool odd[3];
+
+  // stream position of replica bit 32 lane at each offset: the window of iteration `it` starts 2048 it bits further on
+  const uint2 *win[3];
+  u32 sh[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    odd[k] = off[k] & 1u;
-    p1[k] = (kBytes - (int)off[k]) >> 1;
+    const int t = 8 * (int)off[k] + 32 * lane;
+    win[k] = &L.dd[1 + (t >> 5)];
+    sh[k] = (u32)(t & 31);
   }
-  const bool neighbours = off[0] == (off[1] + kBytes - 1) % kBytes && off[2] == (off[1] + 1) % kBytes;
   u32 ci[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
-  for (int i = lane; i < kWords16; i += 64) {
-    const u32 r = L.rep[i];
-    u32 di[3], dq[3];
-    if (neighbours) {
-      int a = (int)off[1] + 2 * i;
-      a = a >= kBytes ? a - kBytes : a;
-      const u32 wi = window32(L.w[0], a + 3), wq = window32(L.w[1], a + 3);   // data bytes a - 1 .. a + 2
-      di[0] = wi & 0xFFFFu;
-      di[1] = (wi >> 8) & 0xFFFFu;
-      di[2] = wi >> 16;
-      dq[0] = wq & 0xFFFFu;
-      dq[1] = (wq >> 8) & 0xFFFFu;
-      dq[2] = wq >> 16;
-    } else {
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        int a = (int)off[k] + 2 * i;
-        a = a >= kBytes ? a - kBytes : a;
-        di[k] = window32(L.w[0], a + 4) & 0xFFFFu;
-        dq[k] = window32(L.w[1], a + 4) & 0xFFFFu;
-      }
-    }
+  for (int it = 0; it < 8; it++) {
+    const int j = lane + 64 * it;
+    // replica word j = bits [32 j, 32 j + 32) of the delayed chip stream: chips 2 j - 1 (low b bits), 2 j, 2 j + 1
+    const int cbit = 2 * j - 1 + 32;
+    const u32 cw = __builtin_amdgcn_alignbit(L.cb[(cbit >> 5) + 1], L.cb[cbit >> 5], (u32)(cbit & 31));
+    // (an 8-entry LDS table of the replica words there are was measured 6 % slower: the lookup sits on the critical path)
+    u32 r = ((cw & 1u) ? low : 0u) | ((cw & 2u) ? (high | (low << 16)) : 0u) | ((cw & 4u) ? (high << 16) : 0u);
+    const u32 m = (it == 7 && lane == 63) ? 0xFFFFu : 0xFFFFFFFFu;   // word 511 is half a word (16-bit word 1022)
+    r &= m;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      const bool skip = odd[k] && (i == p1[k] || i == kWords16 - 1);
-      ci[k] += skip ? 0u : pop16(di[k] ^ r);
-      cq[k] += skip ? 0u : pop16(dq[k] ^ r);
+      const uint4 v = lds_read_pairs(win[k] + 64 * it);
+      const u32 wi = __builtin_amdgcn_alignbit(v.z, v.x, sh[k]);
+      const u32 wq = __builtin_amdgcn_alignbit(v.w, v.y, sh[k]);
+      ci[k] += (u32)__popc((wi & m) ^ r);
+      cq[k] += (u32)__popc((wq & m) ^ r);
     }
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const u32 si = wave_sum_to_lane63(ci[k]), sq = wave_sum_to_lane63(cq[k]);
+    // (both counts in one reduction: a lane's share is at most 8 x 32, the totals stay below 2^15)
+    const u32 both = wave_sum_to_lane63(ci[k] | (cq[k] << 16));
+    u32 si = both & 0xFFFFu, sq = both >> 16;
+    if (off[k] & 1u) {   // wave-uniform
+      const int o = (int)off[k];
+      const int p1 = (kBytes - o) >> 1;
+      auto rep16 = [&](int i) {   // replica word i of the 16-bit form: chip i - 1 below bit b, chip i from bit b on
+        const int cb0 = i - 1 + 32;
+        const u32 c2 = __builtin_amdgcn_alignbit(L.cb[(cb0 >> 5) + 1], L.cb[cb0 >> 5], (u32)(cb0 & 31));
+        return ((c2 & 1u) ? low : 0u) | ((c2 & 2u) ? high : 0u);
+      };
+      auto win16 = [&](int t, u32 &wi, u32 &wq) {
+        const uint4 v = lds_read_pairs(&L.dd[1 + (t >> 5)]);
+        wi = __builtin_amdgcn_alignbit(v.z, v.x, (u32)(t & 31)) & 0xFFFFu;
+        wq = __builtin_amdgcn_alignbit(v.w, v.y, (u32)(t & 31)) & 0xFFFFu;
+      };
+      const u32 r1 = rep16(p1);
+      u32 wi, wq;
+      win16(kSamples - 8, wi, wq);   // data bytes (2045, 0)
+      u32 sub_i = pop16(wi ^ r1), sub_q = pop16(wq ^ r1);
+      if (p1 != kWords16 - 1) {
+        const u32 r2 = rep16(kWords16 - 1);
+        win16(8 * (o - 2), wi, wq);   // data bytes (o - 2, o - 1); o >= 3 here
+        sub_i += pop16(wi ^ r2);
+        sub_q += pop16(wq ^ r2);
+      }
+      si -= sub_i;
+      sq -= sub_q;
+    }
     if (lane == 63 && live) {
       iq_out[ch * 6 + k * 2 + 0] = (int16_t)((int)si - kHalf);
       iq_out[ch * 6 + k * 2 + 1] = (int16_t)((int)sq - kHalf);
@@ -399,15 +440,15 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
 constexpr int kTrackWaveFormFrom = 2048;
 
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
-                      const uint8_t *d_chips, int16_t *d_iq)
+                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq)
 {
   if (n_ch <= 0)
     return;
   if (n_ch < kTrackWaveFormFrom)
     hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips, d_iq);
   else
-    hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips,
-                       d_iq);
+    hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch,
+                       d_chipbits, d_iq);
 }
 
 // N3 ingest: MAX2769 sign/magnitude pairs -> sign plane and magnitude plane in the reference's 1-bit layout.
