@@ -257,6 +257,52 @@ uint8_t *signal_capture_get_copy_buf(void);
 uint8_t *signal_capture_get_ready_buf(void);
 void     gpsx_compat_capture_push(const uint8_t *block);
 
+/* --- position solution (PM/GPS/RTK/solving.h:32-37, rtk_common.h:49-58,104-108; host arithmetic in double precision) --
+ * Single-point positioning as the reference runs it (an RTKLIB pntpos subset): satellite positions and clocks from the
+ * broadcast ephemerides at the transmission times, then iterated weighted least squares over (x, y, z, c dt) with the
+ * Klobuchar ionosphere (default coefficients when none were broadcast), the Saastamoinen troposphere at 70 % humidity and
+ * the reference's variance model.  No part of it touches the GPU: it is the last consumer of the correlator hot path
+ * (SURVEY.md 8(f) N4), four satellites twice a second. */
+#define GPSX_PVT_MAXSAT 4                /* MAXSAT, rtk_common.h:42 */
+typedef struct {                         /* obsd_t, rtk_common.h:49-58 */
+  gtime_t       time;                    /* receiver sampling time (GPST) */
+  unsigned char sat, rcv;                /* satellite (PRN) / receiver number */
+  unsigned char SNR[1], LLI[1], code[1];
+  double        L[1];                    /* carrier phase (cycles; unused) */
+  double        P[1];                    /* pseudorange (m) */
+  float         D[1];                    /* Doppler (Hz; unused) */
+} obsd_t;
+typedef struct {                         /* nav_t, rtk_common.h:104-108 */
+  int    n;                              /* ephemerides in eph[] */
+  eph_t *eph[GPSX_PVT_MAXSAT];
+  double ion_gps[8];                     /* Klobuchar a0..a3, b0..b3; all zero: the 2004 default set */
+} nav_t;
+#define SOLQ_NONE   0
+#define SOLQ_SINGLE 5
+typedef struct {                         /* sol_t, solving.h:17-30 */
+  gtime_t       time;                    /* solution time (GPST): reception time minus the receiver clock bias */
+  double        rr[6];                   /* ECEF position (m); velocity entries are zeroed */
+  float         qr[6];                   /* position covariance: xx, yy, zz, xy, yz, zx (m^2) */
+  double        dtr[6];                  /* dtr[0] = receiver clock bias (s) */
+  unsigned char type, stat, ns;          /* 0 = ECEF / SOLQ_* / satellites used */
+  float         age, ratio;
+} sol_t;
+/* One complete solution: 1 = found (sol->stat = SOLQ_SINGLE), 0 = not found.  The iteration starts from sol->rr.
+ * pntpos_iterative is the same computation (the reference slices it into < 1 ms pieces; here it finishes in its first
+ * call and returns 1, or -1 / -2 on failure as the reference does). */
+int  pntpos(const obsd_t *obs, int n, const nav_t *nav, sol_t *sol);
+int  pntpos_iterative(const obsd_t *obs, int n, const nav_t *nav, sol_t *sol);
+void ecef2pos(const double *r /* ECEF m */, double *pos /* lat, lon (rad), ellipsoidal height (m) */);
+/* The receiver-level calls: bind the four channels' ephemerides, then call gps_pos_solve(obs) until solving_is_busy()
+ * returns 0 (PM/GPS/gps_master.c:334-389).  Results: gps_sol, final_pos = {lat deg, lon deg, height m}. */
+void    gps_pos_solve_init(gps_ch_t *channels /* [GPS_SAT_CNT] */);
+void    gps_pos_solve(obsd_t *obs /* [GPS_SAT_CNT] */);
+uint8_t solving_is_busy(void);
+extern sol_t  gps_sol;
+extern double final_pos[3];
+/* azimuth / elevation (deg) of the four satellites of the last solution (the reference's global `azel`) */
+const double *gpsx_pvt_azel(void);
+
 /* not in the reference: release the default context (optional, for leak checkers) */
 void gpsx_compat_shutdown(void);
 

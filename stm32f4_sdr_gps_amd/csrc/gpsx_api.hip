@@ -654,12 +654,28 @@ void track_graph_release(gpsx_ctx *ctx)
   ctx->trk_graphs.clear();
 }
 
-// H2D(block + states) -> k_track_epl -> D2H(states + accumulators), captured once per (channel count, format) shape;
+// Channel capacity a graph is captured for: counts are rounded up (to 4 below 64, to 1/8 of the next power of two above)
+// so that a receiver whose channels come and go between pre-tracking and tracking (gps_tracking_process_batch) keeps
+// hitting the same few graphs instead of re-instantiating one per count.  The padding channels carry PRN 0 (the empty
+// code) and are computed and copied like the others.
+int track_graph_capacity(int n_ch)
+{
+  if (n_ch <= 64)
+    return (n_ch + 3) & ~3;
+  int p2 = 64;
+  while (p2 < n_ch)
+    p2 <<= 1;
+  const int step = p2 / 16;   // n_ch is in (p2 / 2, p2]: steps of 1/8 of p2 / 2
+  return (n_ch + step - 1) / step * step;
+}
+
+// H2D(block + states) -> k_track_epl -> D2H(states + accumulators), captured once per (channel capacity, format) shape;
 // returns the shape's graph (moved to the front of the small cache) or nullptr -> plain path
-gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch, size_t blk_bytes)
+gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch_asked, size_t blk_bytes)
 {
   if (ctx->trk_graph_unusable)
     return nullptr;
+  const int n_ch = track_graph_capacity(n_ch_asked);
   std::vector<gpsx_ctx::TrackGraph> &cache = ctx->trk_graphs;
   for (size_t i = 0; i < cache.size(); i++)
     if (cache[i].n_ch == n_ch && cache[i].if_format == ctx->if_format) {
@@ -724,13 +740,15 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   // between two small host copies into / out of pinned staging, instead of two copies in, a launch, two copies out.
   gpsx_ctx::TrackGraph *tg = n_ch <= kTrackGraphMaxCh ? track_graph_prepare(ctx, n_ch, blk_bytes) : nullptr;
   if (tg) {
-    gpsx_ctx::TrackGraph &t = *tg;
+    gpsx_ctx::TrackGraph &t = *tg;   // t.n_ch = the capacity the graph was captured for (>= n_ch)
     std::memcpy(t.h_in + t.blk_off, if_block, blk_bytes);
     std::memcpy(t.h_in + t.st_off, st, (size_t)n_ch * sizeof(gpsx_trk_state_t));
+    if (t.n_ch > n_ch)   // padding channels: PRN 0, the empty code
+      std::memset(t.h_in + t.st_off + (size_t)n_ch * sizeof(gpsx_trk_state_t), 0, (size_t)(t.n_ch - n_ch) * sizeof(gpsx_trk_state_t));
     HIPCHK(ctx, hipGraphLaunch(t.exec, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(st, t.h_out, (size_t)n_ch * sizeof(gpsx_trk_state_t));
-    std::memcpy(iq_out, t.h_out + (size_t)n_ch * sizeof(gpsx_trk_state_t), (size_t)n_ch * 12);
+    std::memcpy(iq_out, t.h_out + (size_t)t.n_ch * sizeof(gpsx_trk_state_t), (size_t)n_ch * 12);
     return GPSX_OK;
   }
   if (int rc = arena_reset(ctx, arena_size(blk_bytes + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
