@@ -67,7 +67,7 @@ struct MxShared {
   u32 plane[2][16][kPlaneWordsMx];       // d_t0 for the 16 sample offsets, circularly extended
   u32 base[2][kCopyDwords];              // nibble vector of the pass in preparation (copy 0), I / Q
   u32 e8[2][2][8][kCopyDwords];          // [buffer][stream][copy][dword]
-  uint8_t corr[2][2][2][1024];           // [buffer][stream][chip 1022 / chip 1021 term][q]: FP4 code of the step's delta
+  u32 corr[2][2][2][128];                // [buffer][stream][chip 1022 / chip 1021 term][q / 8]: FP4 codes of the step's deltas
   v4i chips_a[16][2][32];                // A fragments: [kappa][h][PRN] = 32 FP4 chips 64 kappa + 32 h ..
   u32 chip_t[1032];                      // chip_t[c + 1]: bit p = chip c of PRN p of this cluster; [0] = chip -1 = 0
   u32 ones[2];                           // pop(D) per stream
@@ -198,22 +198,33 @@ __device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid, int n
     }
     sh.base[iq][dw] = packed;
   }
-  // extra K step: deltas of  c1022 * A'(q)  and  c1021 * B'(q)  (see mx_half_switch for the terms themselves)
-  for (int m = tid; m < 2 * 1024; m += nthreads) {
-    const int iq = m >> 10, q = m & 1023;
-    int ga = 0, gb = 0;
-    if (pass >= 2 && t0 != 8 && q < kChips) {
+  // extra K step: deltas of  c1022 * A'(q)  and  c1021 * B'(q)  (see mx_half_switch for the terms themselves), eight
+  // chip offsets per dword:
+  //   t0 = 1..7, 9..15:  A_b = 2 pop(byte_o & low_b) - b grows by 2 D(8 o + b) - 1 = 2 d[q] - 1
+  //   t0 = 9..15, q > 0: the tail word (o - 2, o - 1) of odd offsets, whose bit b is d[q - 1]: A' += 1 - 2 d[q - 1],
+  //                      B' grows by 2 d[q - 1] - 1
+  for (int m = tid; m < 2 * 128; m += nthreads) {
+    const int iq = m >> 7, dw = m & 127;
+    u32 ca = 0, cb = 0;
+    if (pass >= 2 && t0 != 8) {
       const u32 *pl = sh.plane[iq][pass - 2];
-      const int d = (int)((pl[q >> 5] >> (q & 31)) & 1u);
-      ga = 2 * d - 1;                                   // A_b = 2 pop(byte_o & low_b) - b grows by 2 D(8 o + b) - 1
-      if (t0 >= 9 && q > 0) {                           // tail word (o - 2, o - 1) of odd offsets: its bit b is d[q - 1]
-        const int dm = (int)((pl[(q - 1) >> 5] >> ((q - 1) & 31)) & 1u);
-        ga += 1 - 2 * dm;
-        gb = 2 * dm - 1;
+      // bits 8 dw - 1 .. 8 dw + 7 of the plane (bit -1 = 0)
+      const u32 w = dw ? plane_bits9(pl, 8 * dw - 1) : (pl[0] << 1) & 0x1FFu;
+      const u32 d = (w >> 1) & 0xFFu, dm = w & 0xFFu;   // d[q], d[q - 1] for the eight q of this dword
+      const u32 exist = dw == 127 ? 0x7Fu : 0xFFu;       // q = 1023 does not exist
+      if (t0 < 8) {
+        // +1 -> code 2, -1 -> code A
+        ca = (spread8(d & exist) << 1) | (spread8(~d & exist) * 0xAu);
+      } else {
+        const u32 tail = dw == 0 ? 0xFEu : 0xFFu;        // q = 0 has no tail word
+        const u32 plus2 = d & ~dm & tail, minus2 = ~d & dm & tail;   // 2 (d - dm): code 4 / C
+        const u32 q0p = d & ~tail, q0m = ~d & ~tail;                 // q = 0: 2 d - 1
+        ca = (spread8(plus2 & exist) << 2) | (spread8(minus2 & exist) * 0xCu) | (spread8(q0p) << 1) | (spread8(q0m & 1u) * 0xAu);
+        cb = (spread8(dm & tail & exist) << 1) | (spread8(~dm & tail & exist) * 0xAu);
       }
     }
-    sh.corr[buf][iq][0][q] = (uint8_t)fp4_code(ga);
-    sh.corr[buf][iq][1][q] = (uint8_t)fp4_code(gb);
+    sh.corr[buf][iq][0][dw] = ca;
+    sh.corr[buf][iq][1][dw] = cb;
   }
 }
 
@@ -256,12 +267,13 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
   }
   if (with_corr) {   // wave-uniform
     // the extra K step: only column 0 of each lane half of A is set (chip 1022 / chip 1021 of the PRN), so only the first
-    // nibble of a lane's B window counts: the step's delta for (stream, term h, q), one byte per lane
+    // nibble of a lane's B window counts: the step's delta for (stream, term h, q)
 #pragma unroll
     for (int j = 0; j < kMxTiles; j++) {
+      // (nibble q & 7 of dword q >> 3 moved to nibble 0; what is left above it meets zero columns of A)
       const int q = 32 * (q0_tile + 2 * j) + n;
-      const v4i gi = v4i{(int)sh.corr[buf][0][h][q], 0, 0, 0};
-      const v4i gq = v4i{(int)sh.corr[buf][1][h][q], 0, 0, 0};
+      const v4i gi = v4i{(int)(sh.corr[buf][0][h][q >> 3] >> (4 * (n & 7))), 0, 0, 0};
+      const v4i gq = v4i{(int)(sh.corr[buf][1][h][q >> 3] >> (4 * (n & 7))), 0, 0, 0};
       acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gi), acc[0][j], 4, 4, 0, kScaleOne, 0,
                                                                    kScaleOne);
       acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gq), acc[1][j], 4, 4, 0, kScaleOne, 0,
