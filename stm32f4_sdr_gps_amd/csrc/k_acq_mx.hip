@@ -306,6 +306,13 @@ __device__ __forceinline__ u32 half_sum_to_lane31(u32 v)
 // gps_correlation8's magnitude (PM/GPS/gps_misc.c:106-118) on the centred counts as the accumulators hold them (exact
 // integers in f32): one-sided clip, the squares as f32 products -- the correctly rounded product of the exact square is what
 // (float)(I * I) is --, their f32 sum, the correctly rounded root (v_sqrt_f32 + the neighbour test, as mag8_fast), truncation.
+__device__ __forceinline__ u32 root_trunc(float e);
+__device__ __forceinline__ float clip_square_sum(float ci, float cq)
+{
+  const int ib = (int)__float_as_uint(ci), qb = (int)__float_as_uint(cq);
+  const float i = __uint_as_float((u32)(ib < 0 ? 0 : ib)), q = __uint_as_float((u32)(qb < 0 ? 0 : qb));
+  return i * i + q * q;
+}
 __device__ __forceinline__ u32 mag8_f32(float ci, float cq)
 {
   // (clip on the bit patterns: a negative float is a negative int; fmaxf() would first canonicalise its operand with a
@@ -313,6 +320,12 @@ __device__ __forceinline__ u32 mag8_f32(float ci, float cq)
   const int ib = (int)__float_as_uint(ci), qb = (int)__float_as_uint(cq);
   const float i = __uint_as_float((u32)(ib < 0 ? 0 : ib)), q = __uint_as_float((u32)(qb < 0 ? 0 : qb));
   const float e = i * i + q * q;   // (-ffp-contract=off: two rounded products, one rounded sum)
+  return root_trunc(e);
+}
+
+// (int) of the correctly rounded f32 root
+__device__ __forceinline__ u32 root_trunc(float e)
+{
   float r = __builtin_amdgcn_sqrtf(e);
   const float r_dn = __uint_as_float(__float_as_uint(r) - 1u);
   const float r_up = __uint_as_float(__float_as_uint(r) + 1u);
@@ -448,10 +461,33 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       const u32 prev[4] = {rec.x, rec.y, rec.z, rec.w};
       uint4 *e_rec = e4 + (size_t)(j * 4 + g) * 64;
       u32 out[4];
+      // Magnitudes of the group's four hypotheses.  When all 256 of them (4 x 64 lanes) lie below radius 1024 -- noise
+      // hypotheses sit at a few hundred -- e < 2^20 is an exact integer and trunc(v_sqrt_f32(e + 1/2)) is its integer
+      // root with no fix-up (the true root of n^2 + r + 1/2 keeps 1 / (4 (n + 1)) away from the integers around it, one
+      // ulp below 1024 is half of that; gps_mag8 checks every pair of that domain on the device): one wave-uniform test
+      // per group instead of four neighbour tests.
+      float e4v[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        e4v[rr] = clip_square_sum(acc[0][j][4 * g + rr], acc[1][j][4 * g + rr]);
+      // (their maximum on the bit patterns: non-negative floats order like integers)
+      const u32 eb0 = __float_as_uint(e4v[0]), eb1 = __float_as_uint(e4v[1]), eb2 = __float_as_uint(e4v[2]), eb3 = __float_as_uint(e4v[3]);
+      const u32 e_max = max(max(eb0, eb1), max(eb2, eb3));
+      const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x49800000u /* 2^20 as f32 */) == 0;
+      u32 mag[4];
+      if (small) {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          mag[rr] = (u32)(int)__builtin_amdgcn_sqrtf(e4v[rr] + 0.5f);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          mag[rr] = root_trunc(e4v[rr]);
+      }
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int r = 4 * g + rr;
-        u32 val = mag8_f32(acc[0][j][r], acc[1][j][r]);
+        u32 val = mag[rr];
         if (MULTI)
           val += prev[rr];
         out[rr] = val;
