@@ -93,7 +93,7 @@ def tracking_channels(eng_cls, dev_index, steps=400):
     eng = eng_cls(dev_index)
     stream = synth.default_four_sv(8, seed=7)
     rows, best = [], None
-    for n in (256, 4096, 65536, 131072, 196608, 229376, 262144):
+    for n in (256, 4096, 65536, 131072, 196608, 262144, 327680, 393216, 458752, 524288):
         st = np.zeros(n, capi.TRK_DTYPE)
         st["prn"] = (np.arange(n) % 32) + 1
         st["code_phase_fine"] = (61 * np.arange(n) % 16368).astype(np.float32)
@@ -172,7 +172,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--searches", type=int, default=64, help="1 ms captures per GPU per step")
+    ap.add_argument("--searches", type=int, default=256,
+                    help="1 ms captures per GPU per step.  256 (default): the matrix-core kernel runs one workgroup per (capture, "
+                         "Doppler bin) and CU, 256 x 21 workgroups are exactly 21 rounds of the 256 CUs; at 64 (round 1's batch) "
+                         "the launch ends with a quarter-filled sixth round (7.2e11 instead of 8.5e11 hyp/s)")
     ap.add_argument("--amp-scale", type=float, default=0.25,
                     help="scale of the six synthetic satellites' amplitudes: 0.25 (default) puts each satellite below the "
                          "noise like a live antenna; 1.0 is the strong test signal, whose long runs of saturated block sums "
@@ -423,7 +426,20 @@ def main():
                             "time) against one wave64 op per 4 cycles per SIMD (256 CU x 64 lanes/clk x 2.4 GHz); a few op "
                             "classes (and, add, f32 mul/fma) issue in 2 cycles (profiles/r02_valu_rates_microbench.txt), so "
                             "a mix of them can read slightly above 1"}
-        if is_mx:
+        mfma_block = None
+        if is_mx and n_ms > 1:
+            # Non-coherent integration: the running sums of the 16368 x 32 x 21 hypotheses of a search do not fit on chip,
+            # they make a round trip through HBM per block -- 4 B read + 4 B written per hypothesis and block, except the
+            # first block (nothing to read) and the last (nothing to write): that stream is what binds this form
+            alg_bytes = hyp_per_launch * 8.0 * (n_ms - 1) / n_ms
+            ach = alg_bytes / (launch_ms * 1e-3) / 1e9
+            flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
+            mfma_block = {"bound": "mfma", "achieved": flops / (launch_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": flops / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS}
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "bytes_per_hyp_block": 8.0 * (n_ms - 1) / n_ms,
+                    "counter_source": counters.get("source") if counters else None}
+        elif is_mx:
             # the GEMM on the matrix cores is the dominant operation of this kernel: algorithmic FP4 flops / launch time
             # against the dense MX-FP4 peak; the vector-ALU side (epilogue, vector building) is priced beside it
             flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
@@ -454,7 +470,11 @@ def main():
             "reference_equivalent_stream_gbs": hyp_per_launch * BYTES_PER_HYP / (launch_ms * 1e-3) / 1e9,
             "kernel": "gpsx::" + kernel,
             "kernel_ms": launch_ms,
-            "note": ("operands stay in LDS, HBM traffic is ~0 by construction.  The correlations run as an MX-FP4 Toeplitz GEMM "
+            "note": ("the captures stay in LDS and the correlations run as an MX-FP4 Toeplitz GEMM on the matrix cores; what binds "
+                     "the multi-block form is the running sums' round trip through HBM (8 B per hypothesis and block, first "
+                     "and last block 4 B): achieved = those algorithmic bytes / this run's launch time against 8 TB/s; "
+                     "`traffic` is what rocprofv3 counted" if (is_mx and n_ms > 1) else
+                     "operands stay in LDS, HBM traffic is ~0 by construction.  The correlations run as an MX-FP4 Toeplitz GEMM "
                      "on the matrix cores: achieved = algorithmic flops (17 passes x 2 streams x 2*32*1024*1024 per (search, "
                      "Doppler) pair) / this run's launch time, peak = dense FP4; the vector ALU (clip, square, root, search) "
                      "runs beside it, see roofline_valu" if is_mx else
@@ -493,6 +513,7 @@ def main():
             },
             "roofline": roof,
             **({"roofline_valu": valu} if valu is not None else {}),
+            **({"roofline_mfma": mfma_block} if mfma_block is not None else {}),
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }
         if pcie is not None:

@@ -25,7 +25,7 @@ def short_name(full):
     return m.group(1).replace(" ", "") if m else full
 
 
-def main(tag="r02", searches=64, n_ms=1, pattern=None):
+def main(tag="r02", searches=256, n_ms=1, pattern=None):
     searches, n_ms = int(searches), int(n_ms)
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
