@@ -426,13 +426,15 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.cnt = d_cnt;
   const bool inspect = d_per_ms || d_energy || d_cnt;
   const bool fine = (ctx->algo == kAlgoPoly || ctx->algo == kAlgoMx) && n_bits == 8 && !inspect;
-  // The matrix-core kernel runs one 512-thread workgroup per (search, Doppler, 32 PRNs) and CU: it takes the launches
-  // that fill the chip a few times over (a forced $GPSX_ACQ_ALGO=mx takes them all); smaller ones -- a receiver's single
-  // acquisition call -- spread better as the polyphase VALU kernel's 8-PRN, 4/8/16-offset workgroups.
+  // The matrix-core kernel (one 512-thread workgroup per (search, Doppler, 32 PRNs), one per CU) is the faster one at
+  // every launch size measured, a single capture included (0.155 ms against 0.166 ms, profiles/r02_launch_size_sweep.json),
+  // with one exception: a lone multi-block search, whose 21 workgroups would walk their blocks one after the other --
+  // there the polyphase kernel's block-parallel form (a workgroup per block, sums by a second kernel) has the shorter
+  // latency.  A forced $GPSX_ACQ_ALGO=mx takes everything.
   bool mx = fine && ctx->algo == kAlgoMx;
   if (mx) {
     const long clusters = acq_mx_clusters(prm);
-    if (!ctx->algo_forced && clusters < 2 * ctx->prop.multiProcessorCount)
+    if (!ctx->algo_forced && g->n_ms > 1 && clusters < 64)
       mx = false;
     if (mx && g->n_ms > 1) {
       const size_t need = acq_mx_energy_bytes(clusters);

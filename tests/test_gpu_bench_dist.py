@@ -12,15 +12,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_ms, searches, port, ms_mode", [(10, 2, 29571, "blocks"), (1, 4, 29572, ""), (10, 4, 29573, "walk")])
-def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode):
+@pytest.mark.parametrize("n_ms, searches, port, ms_mode, algo", [(10, 1, 29571, "blocks", ""), (1, 4, 29572, "", ""),
+                                                                (10, 4, 29573, "walk", "poly"), (10, 5, 29574, "", "")])
+def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode, algo):
     """n_ms = 10 is what the driver's N > 1 runs execute (BASELINE.json configs[3]; bench.py's default there), in both
-    multi-block forms: a workgroup per (unit, block), and -- what the 64-searches-per-GPU runs take -- a workgroup
-    walking its unit's ten blocks; n_ms = 1 is the coherent grid.  GPSX_BENCH_VERIFY compares the merged key table with
+    forms: the polyphase kernel with a workgroup per (unit, block) (what a lone search takes), the polyphase kernel walking
+    its blocks, and -- what the 256-searches-per-GPU runs take -- the matrix-core kernel walking them (default dispatch,
+    5 searches per rank); n_ms = 1 is the coherent grid on the matrix cores.  GPSX_BENCH_VERIFY compares the merged key table with
     an unsharded sweep of the same captures."""
     env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1")
     if ms_mode:
         env["GPSX_ACQ_MS_MODE"] = ms_mode
+    if algo:
+        env["GPSX_ACQ_ALGO"] = algo
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--searches", str(searches), "--no-cpu-baseline"] + (["--n-ms", "1"] if n_ms == 1 else [])
