@@ -427,17 +427,18 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   const bool inspect = d_per_ms || d_energy || d_cnt;
   const bool fine = (ctx->algo == kAlgoPoly || ctx->algo == kAlgoMx) && n_bits == 8 && !inspect;
   // The matrix-core kernel (one 512-thread workgroup per (search, Doppler, 32 PRNs), one per CU) is the faster one at
-  // every launch size measured, a single capture included (0.155 ms against 0.166 ms, profiles/r02_launch_size_sweep.json),
-  // with one exception: a lone multi-block search, whose 21 workgroups would walk their blocks one after the other --
-  // there the polyphase kernel's block-parallel form (a workgroup per block, sums by a second kernel) has the shorter
-  // latency.  A forced $GPSX_ACQ_ALGO=mx takes everything.
+  // every launch size measured, a single capture included (0.155 ms against 0.166 ms, profiles/r02_launch_size_sweep.json).
   bool mx = fine && ctx->algo == kAlgoMx;
   if (mx) {
     const long clusters = acq_mx_clusters(prm);
-    if (!ctx->algo_forced && g->n_ms > 1 && clusters < 64)
-      mx = false;
-    if (mx && g->n_ms > 1) {
-      const size_t need = acq_mx_energy_bytes(clusters);
+    // n_ms > 1, few searches: a workgroup per (cluster, block) instead of a workgroup walking its cluster's blocks -- a lone
+    // ten-block search is 210 workgroups (one round of the chip) instead of 21 doing ten blocks each
+    bool mx_blocks = false;
+    if (g->n_ms > 1) {
+      mx_blocks = ctx->ms_mode ? ctx->ms_mode == 2
+                               : clusters < ctx->prop.multiProcessorCount &&
+                                     acq_poly_vals_bytes(g->n_search, g->n_ms, g->n_prn, g->n_dopp) <= ((size_t)8 << 30);
+      const size_t need = mx_blocks ? acq_poly_vals_bytes(g->n_search, g->n_ms, g->n_prn, g->n_dopp) : acq_mx_energy_bytes(clusters);
       if (need > ctx->energy_bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_energy)
@@ -454,17 +455,17 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
         }
       }
     }
-  }
-  if (mx) {
-    ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
-                                     ctx->d_grid_mx_t, d_peaks, ctx->d_energy);
-    LAUNCHCHK(ctx, "k_acq_mx");
-    if (d_keys) {
-      launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,
-                      (int)unit_hi);
-      LAUNCHCHK(ctx, "k_acq_keys");
+    if (mx) {
+      ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
+                                       ctx->d_grid_mx_t, d_peaks, ctx->d_energy, mx_blocks, gpsx_acq_peaks_count(g));
+      LAUNCHCHK(ctx, "k_acq_mx");
+      if (d_keys) {
+        launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,
+                        (int)unit_hi);
+        LAUNCHCHK(ctx, "k_acq_keys");
+      }
+      return GPSX_OK;
     }
-    return GPSX_OK;
   }
   bool poly = fine;
   bool block_parallel = false;

@@ -90,8 +90,11 @@ inline size_t acq_poly_energy_bytes(long local_units)
 void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slots, uint32_t *d_mx_a, uint32_t *d_mx_t);
 long acq_mx_clusters(const AcqParams &prm);
 inline size_t acq_mx_energy_bytes(long clusters) { return (size_t)clusters * 8 * (16 * 4 * 16 * 64) * sizeof(uint32_t); }
+// block_parallel (n_ms > 1): a workgroup per (cluster, block) writes magnitudes into d_energy (acq_poly_vals_bytes of it, u16),
+// k_acq_vals_search sums and searches -- the form for a handful of multi-block searches
 const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
-                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy);
+                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks);
+void launch_acq_vals_search(hipStream_t s, const AcqParams &prm, const uint16_t *d_vals, gpsx_peak_t *d_peaks, size_t n_peaks);
 void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks);
 

@@ -528,6 +528,34 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
   }
 }
 
+// Block-parallel form of a multi-block search (kMxStore): this workgroup handled ONE block; its magnitudes go out as
+// u16 in the layout k_acq_vals_search (k_acq_poly.hip) sums and searches: per (search, block, PRN, Doppler) a plane of
+// [sample offset][q & 3][q >> 2].
+__device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles], u32 group_mask,
+                                                  uint16_t *__restrict__ plane0, size_t prn_stride, int slot0, int n_prn)
+{
+  const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    uint16_t *v = plane0 + (size_t)t0 * 1024 + (size_t)(q & 3) * 256 + (size_t)(q >> 2);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int r = 4 * g + rr;
+        const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const u32 val = mag8_f32(acc[0][j][r], acc[1][j][r]);
+        if (((group_mask >> g) & 1u) && slot0 + p < n_prn)
+          v[(size_t)p * prn_stride] = (uint16_t)val;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2;   // k_acq_mx's MODE
+
 }  // namespace
 
 // mx_a [set][16][2][32][4]: the A fragments of a 32-slot cluster; mx_t [set][1032]: its transposed chip words
@@ -564,11 +592,14 @@ void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slo
   hipLaunchKernelGGL(k_build_mx_tables, dim3((n + 255) / 256), dim3(256), 0, s, d_chipbits, n_slots, d_mx_a, d_mx_t);
 }
 
-template <bool MULTI>
+// MODE: kMxSingle (n_ms == 1), kMxWalk (the workgroup walks the blocks of its searches, running sums in HBM scratch),
+// kMxStore (a workgroup per block, magnitudes out as u16 for k_acq_vals_search: the form for few multi-block searches)
+template <int MODE>
 __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ mx_a, const u32 *__restrict__ mx_t,
                                                           gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy)
 {
+  constexpr bool MULTI = MODE == kMxWalk, STORE = MODE == kMxStore;
   __shared__ MxShared sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -578,7 +609,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 
   // ---- decode: cluster = (search, Doppler, set of 32 PRN slots); its four 8-PRN groups are sharding units -----------
   const int n_sets = (prm.n_groups + 3) / 4;
-  const int cluster = cluster_lo + (int)blockIdx.x;
+  const int ms_store = STORE ? (int)blockIdx.x % prm.n_ms : 0;
+  const int cluster = cluster_lo + (STORE ? (int)blockIdx.x / prm.n_ms : (int)blockIdx.x);
   const int set = cluster % n_sets;
   const int sd = cluster / n_sets;
   const int dopp = sd % prm.n_dopp;
@@ -620,8 +652,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   for (int ms = 0; ms < n_ms; ms++) {
     const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
     __syncthreads();   // the previous block's readers are done
-    mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms) * block_bytes, prm.if_format,
-                     step_word, tid, lane);
+    mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms + ms_store) * block_bytes,
+                     prm.if_format, step_word, tid, lane);
     __syncthreads();
     mx_vector_phase1(sh, 0, 0, tid, kMxThreads);
     __syncthreads();
@@ -665,7 +697,13 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         else
           mx_vector_phase2(sh, p_vec & 1, b_tid, b_n);
       }
-      if (active && (x & 1) && p >= 1 && !(ex & 1)) {
+      if (STORE) {
+        if (active && (x & 1) && p >= 1) {
+          uint16_t *plane0 = reinterpret_cast<uint16_t *>(energy) +
+                             ((size_t)((search * prm.n_ms + ms_store) * prm.n_prn + 32 * set) * prm.n_dopp + dopp) * (16 * 1024);
+          mx_epilogue_store(lane, q0_tile, p - 1, acc, group_mask, plane0, (size_t)prm.n_dopp * (16 * 1024), 32 * set, prm.n_prn);
+        }
+      } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
         if (MULTI && !ms_last)
           mx_epilogue<MULTI, false>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);
         else
@@ -673,6 +711,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       }
     }
   }
+  if (STORE)
+    return;   // k_acq_vals_search sums the blocks and searches
   __syncthreads();
   // the finished triplets: one per (PRN, bit shift)
   if (tid < 256) {
@@ -709,20 +749,26 @@ long acq_mx_clusters(const AcqParams &prm)
 }
 
 const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
-                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy)
+                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks)
 {
   if (prm.unit_hi <= prm.unit_lo)
     return "";
   int c_lo, c_hi;
   mx_cluster_range(prm, &c_lo, &c_hi);
-  if (prm.n_ms > 1) {
-    hipLaunchKernelGGL(k_acq_mx<true>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
-                       d_peaks, d_energy);
-    return "k_acq_mx<true>";
+  if (prm.n_ms > 1 && block_parallel) {
+    hipLaunchKernelGGL(k_acq_mx<kMxStore>, dim3((unsigned)((c_hi - c_lo) * prm.n_ms)), dim3(kMxThreads), 0, s, prm, c_lo, d_if,
+                       d_mx_a, d_mx_t, d_peaks, d_energy);
+    launch_acq_vals_search(s, prm, reinterpret_cast<const uint16_t *>(d_energy), d_peaks, n_peaks);
+    return "k_acq_mx<2>";
   }
-  hipLaunchKernelGGL(k_acq_mx<false>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+  if (prm.n_ms > 1) {
+    hipLaunchKernelGGL(k_acq_mx<kMxWalk>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+                       d_peaks, d_energy);
+    return "k_acq_mx<1>";
+  }
+  hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                      d_peaks, (u32 *)nullptr);
-  return "k_acq_mx<false>";
+  return "k_acq_mx<0>";
 }
 
 }  // namespace gpsx

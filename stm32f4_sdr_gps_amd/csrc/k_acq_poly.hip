@@ -584,6 +584,11 @@ __global__ __launch_bounds__(kThreads) void k_acq_vals_search(const AcqParams pr
   }
 }
 
+void launch_acq_vals_search(hipStream_t s, const AcqParams &prm, const uint16_t *d_vals, gpsx_peak_t *d_peaks, size_t n_peaks)
+{
+  hipLaunchKernelGGL(k_acq_vals_search, dim3((unsigned)(n_peaks / 8)), dim3(kThreads), 0, s, prm, d_vals, d_peaks);
+}
+
 void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks)
 {

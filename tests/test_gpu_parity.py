@@ -802,14 +802,14 @@ def test_matrix_core_grid_vs_oracle(eng_mx, oracle, stream):
     captures, and the 10-block non-coherent sum (BASELINE.json configs[3]'s integration) on a 5-PRN list."""
     prns = np.arange(1, 33, dtype=np.uint8)
     peaks, keys = eng_mx.acq_grid(stream[:2], prns, n_search=2, dopp_min_hz=500, dopp_step_hz=1500, n_dopp=3)
-    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<false>"
+    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<0>"
     for s in range(2):
         want = oracle.acq_grid(stream[s:s + 1], 1, prns, 500, 1500, 3, 8, n_threads=8)
         for f in ("max_val", "phase", "sum", "avr"):
             assert np.array_equal(peaks[s][f], want[f]), (s, f)
     prns5 = np.array([5, 14, 20, 30, 7], np.uint8)
     peaks, _ = eng_mx.acq_grid(stream[:10], prns5, n_search=1, n_ms=10, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
-    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<true>"
+    assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<2>"
     want = oracle.acq_grid(stream[:10], 10, prns5, -1000, 500, 5, 8, n_threads=8)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(peaks[0][f], want[f]), f
@@ -915,16 +915,19 @@ def test_in_process_group_sharded_sweep_over_rccl(eng, stream):
         other.close()
 
 
+@pytest.mark.parametrize("algo", ["mx", "poly"])
 @pytest.mark.parametrize("mode", ["walk", "blocks"])
-def test_both_multi_block_forms_match_the_oracle(oracle, stream, mode, monkeypatch):
-    """n_ms > 1 on the polyphase kernel has two forms, picked by launch size: `walk` (a workgroup walks the blocks of its
+def test_both_multi_block_forms_match_the_oracle(oracle, stream, mode, algo, monkeypatch):
+    """n_ms > 1 has two forms on the matrix-core kernel and on the polyphase kernel alike, picked by launch size: `walk` (a workgroup walks the blocks of its
     unit, running sums in an HBM slice) for many searches, `blocks` (a workgroup per (unit, block), all magnitudes
     through HBM as u16, k_acq_vals_search sums and searches) for few.  $GPSX_ACQ_MS_MODE forces one: both must give the
     oracle's triplets -- windows, stride, a PRN count off the group size, sharded halves included."""
     from stm32f4_sdr_gps_amd import capi
     monkeypatch.setenv("GPSX_ACQ_MS_MODE", mode)
+    monkeypatch.setenv("GPSX_ACQ_ALGO", algo)
     e = capi.Engine(0)
     monkeypatch.delenv("GPSX_ACQ_MS_MODE")
+    monkeypatch.delenv("GPSX_ACQ_ALGO")
     try:
         prns = np.array([1, 5, 7, 14, 20, 25, 30, 31, 32, 3, 12], np.uint8)
         for n_search, n_ms, stride, win in ((1, 10, 10, (0, 2046)), (2, 3, 4, (101, 1900)), (3, 2, 2, (0, 1))):
