@@ -429,15 +429,16 @@ def main():
         mfma_block = None
         if is_mx and n_ms > 1:
             # Non-coherent integration: the running sums of the 16368 x 32 x 21 hypotheses of a search do not fit on chip,
-            # they make a round trip through HBM per block -- 4 B read + 4 B written per hypothesis and block, except the
-            # first block (nothing to read) and the last (nothing to write): that stream is what binds this form
-            alg_bytes = hyp_per_launch * 8.0 * (n_ms - 1) / n_ms
+            # they make a round trip through HBM per block -- 3 B read + 3 B written per hypothesis and block (a sum stays
+            # below 2^21: four of them are packed into three dwords), except the first block (nothing to read) and the
+            # last (nothing to write): that stream is what binds this form
+            alg_bytes = hyp_per_launch * 6.0 * (n_ms - 1) / n_ms
             ach = alg_bytes / (launch_ms * 1e-3) / 1e9
             flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
             mfma_block = {"bound": "mfma", "achieved": flops / (launch_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": flops / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS}
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "bytes_per_hyp_block": 8.0 * (n_ms - 1) / n_ms,
+                    "bytes_per_hyp_block": 6.0 * (n_ms - 1) / n_ms,
                     "counter_source": counters.get("source") if counters else None}
         elif is_mx:
             # the GEMM on the matrix cores is the dominant operation of this kernel: algorithmic FP4 flops / launch time
@@ -471,8 +472,8 @@ def main():
             "kernel": "gpsx::" + kernel,
             "kernel_ms": launch_ms,
             "note": ("the captures stay in LDS and the correlations run as an MX-FP4 Toeplitz GEMM on the matrix cores; what binds "
-                     "the multi-block form is the running sums' round trip through HBM (8 B per hypothesis and block, first "
-                     "and last block 4 B): achieved = those algorithmic bytes / this run's launch time against 8 TB/s; "
+                     "the multi-block form is the running sums' round trip through HBM (6 B per hypothesis and block, first "
+                     "and last block 3 B): achieved = those algorithmic bytes / this run's launch time against 8 TB/s; "
                      "`traffic` is what rocprofv3 counted" if (is_mx and n_ms > 1) else
                      "operands stay in LDS, HBM traffic is ~0 by construction.  The correlations run as an MX-FP4 Toeplitz GEMM "
                      "on the matrix cores: achieved = algorithmic flops (17 passes x 2 streams x 2*32*1024*1024 per (search, "

@@ -408,23 +408,45 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
   }
 }
 
+// MULTI: the running sums between blocks.  A sum stays below 128 x 11573 < 2^21 (kMaxMs blocks), so four of them travel
+// as three dwords: the scratch stream is what binds this form (bench.py `roofline` of the multi-block run), a quarter less
+// of it is worth the six shifts.
+struct SumRec {
+  u32 w[3];
+};
+__device__ __forceinline__ void sums_unpack(const SumRec &r, u32 (&s)[4])
+{
+  s[0] = r.w[0] & 0xFFFFFFu;
+  s[1] = __builtin_amdgcn_alignbit(r.w[1], r.w[0], 24u) & 0xFFFFFFu;
+  s[2] = __builtin_amdgcn_alignbit(r.w[2], r.w[1], 16u) & 0xFFFFFFu;
+  s[3] = r.w[2] >> 8;
+}
+__device__ __forceinline__ SumRec sums_pack(const u32 (&s)[4])
+{
+  SumRec r;
+  r.w[0] = s[0] | (s[1] << 24);
+  r.w[1] = (s[1] >> 8) | (s[2] << 16);
+  r.w[2] = (s[2] >> 16) | (s[3] << 8);
+  return r;
+}
+
 // MULTI: request the running sums of sample offset t0, records [first, first + count) of this lane's 16; zero for the first
 // block.  The first tile's records are requested before the wave's MFMA pass, the next tile's at the start of each tile
 // of the epilogue: always ~1 us ahead of their use, never more than 8 records in registers.
 template <int FIRST, int COUNT>
-__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first, uint4 (&pre)[16])
+__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first, SumRec (&pre)[16])
 {
-  const uint4 *e4 = reinterpret_cast<const uint4 *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
+  const SumRec *e4 = reinterpret_cast<const SumRec *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
 #pragma unroll
   for (int i = FIRST; i < FIRST + COUNT; i++)
-    pre[i] = ms_first ? uint4{0, 0, 0, 0} : e4[(size_t)i * 64];
+    pre[i] = ms_first ? SumRec{{0, 0, 0}} : e4[(size_t)i * 64];
 }
 
 // ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
 // SEARCH = false (MULTI, not the last block): only the running sums move on -- no key, no maximum, no window sum
 template <bool MULTI, bool SEARCH>
 __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
-                                            u32 group_mask, u32 *__restrict__ energy, uint4 (&pre)[MULTI ? 16 : 1],
+                                            u32 group_mask, u32 *__restrict__ energy, SumRec (&pre)[MULTI ? 16 : 1],
                                             bool ms_first)
 {
   constexpr bool ms_last = SEARCH;
@@ -436,10 +458,10 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     best[r] = 0;
     total[r] = 0;
   }
-  // MULTI: the running sums of a lane's four hypotheses of a group are one 16-byte record ([offset][tile][group][lane][4]:
-  // a wave reads / writes 1 KB per instruction); the 16 records of this offset were requested before the wave's MFMA pass
-  // (mx_prefetch_sums) -- the scratch is HBM, the pass hides its latency
-  uint4 *e4 = reinterpret_cast<uint4 *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
+  // MULTI: the running sums of a lane's four hypotheses of a group are one 12-byte record ([offset][tile][group][lane]: a
+  // wave reads / writes 768 contiguous bytes per instruction); the first records of this offset were requested before
+  // the wave's MFMA pass (mx_prefetch_sums) -- the scratch is HBM, the pass hides its latency
+  SumRec *e4 = reinterpret_cast<SumRec *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
@@ -457,9 +479,10 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     //  group_mask decides below what is published)
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      const uint4 rec = pre[MULTI ? j * 4 + g : 0];
-      const u32 prev[4] = {rec.x, rec.y, rec.z, rec.w};
-      uint4 *e_rec = e4 + (size_t)(j * 4 + g) * 64;
+      u32 prev[4] = {0, 0, 0, 0};
+      if (MULTI)
+        sums_unpack(pre[MULTI ? j * 4 + g : 0], prev);
+      SumRec *e_rec = e4 + (size_t)(j * 4 + g) * 64;
       u32 out[4];
       // Magnitudes of the group's four hypotheses.  When all 256 of them (4 x 64 lanes) lie below radius 1024 -- noise
       // hypotheses sit at a few hundred -- e < 2^20 is an exact integer and trunc(v_sqrt_f32(e + 1/2)) is its integer
@@ -498,7 +521,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         }
       }
       if (MULTI && !ms_last)
-        *e_rec = uint4{out[0], out[1], out[2], out[3]};
+        *e_rec = sums_pack(out);
       // four hypotheses at a time: enough independent chains to cover the ALU latencies, few enough to keep the 128
       // accumulators and the 32 running results in registers (left alone, the compiler sinks all 64 chains to the
       // reductions below, runs them side by side and spills): the results are pinned here, in program order
@@ -645,7 +668,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __syncthreads();
   // A operand of the extra K step: column 0 of lane half 0 = chip 1022 of PRN (lane & 31), of half 1 = chip 1021
   const v4i a_corr = v4i{(int)(((sh.chip_t[(lane >> 5 ? 1021 : 1022) + 1] >> (lane & 31)) & 1u) << 1), 0, 0, 0};
-  u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 16 * 64) : nullptr;
+  u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * 3) : nullptr;   // SumRec = 3 dwords
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const int n_ms = MULTI ? prm.n_ms : 1;
 #pragma unroll 1
@@ -661,7 +684,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-    uint4 pre[MULTI ? 16 : 1];
+    SumRec pre[MULTI ? 16 : 1];
 
     // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
     // half step later.  The vector of pass p + 1 is built in half steps 2 p (copy 0) and 2 p + 1 (its shifted copies),
