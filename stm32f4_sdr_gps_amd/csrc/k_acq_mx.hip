@@ -477,58 +477,70 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     // (all four 8-PRN groups, whether this shard owns them or not: a workgroup that owns only some -- at the ends of a
     //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
     //  group_mask decides below what is published)
+    // GS hypotheses at a time: enough independent chains for a wave that has its SIMD's vector ALU to itself (its partner
+    // is in the MFMA pass) to cover the ALU, transcendental and branch latencies; few enough to keep the 128 accumulators
+    // and the 32 running results in registers (left alone, the compiler sinks all 64 chains to the reductions below, runs
+    // them side by side and spills): the results are pinned at the end of each group, in program order.
+    constexpr int GS = MULTI ? 4 : 8;
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-      u32 prev[4] = {0, 0, 0, 0};
-      if (MULTI)
-        sums_unpack(pre[MULTI ? j * 4 + g : 0], prev);
-      SumRec *e_rec = e4 + (size_t)(j * 4 + g) * 64;
-      u32 out[4];
-      // Magnitudes of the group's four hypotheses.  When all 256 of them (4 x 64 lanes) lie below radius 1024 -- noise
-      // hypotheses sit at a few hundred -- e < 2^20 is an exact integer and trunc(v_sqrt_f32(e + 1/2)) is its integer
-      // root with no fix-up (the true root of n^2 + r + 1/2 keeps 1 / (4 (n + 1)) away from the integers around it, one
-      // ulp below 1024 is half of that; gps_mag8 checks every pair of that domain on the device): one wave-uniform test
-      // per group instead of four neighbour tests.
-      float e4v[4];
+    for (int r0 = 0; r0 < 16; r0 += GS) {
+      u32 prev[GS];
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++)
-        e4v[rr] = clip_square_sum(acc[0][j][4 * g + rr], acc[1][j][4 * g + rr]);
-      // (their maximum on the bit patterns: non-negative floats order like integers)
-      const u32 eb0 = __float_as_uint(e4v[0]), eb1 = __float_as_uint(e4v[1]), eb2 = __float_as_uint(e4v[2]), eb3 = __float_as_uint(e4v[3]);
-      const u32 e_max = max(max(eb0, eb1), max(eb2, eb3));
+      for (int i = 0; i < GS; i++)
+        prev[i] = 0;
+      if (MULTI) {
+        u32 p4[4];
+        sums_unpack(pre[MULTI ? j * 4 + r0 / 4 : 0], p4);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          prev[i] = p4[i];
+      }
+      SumRec *e_rec = e4 + (size_t)(j * 4 + r0 / 4) * 64;
+      u32 out[GS];
+      // Magnitudes of the group's hypotheses.  When all of them (GS x 64 lanes) lie below radius 1024 -- noise hypotheses
+      // sit at a few hundred -- e < 2^20 is an exact integer and trunc(v_sqrt_f32(e + 1/2)) is its integer root with no
+      // fix-up (the true root of n^2 + r + 1/2 keeps 1 / (4 (n + 1)) away from the integers around it, one ulp below 1024
+      // is half of that; gps_mag8 checks every pair of that domain on the device): one wave-uniform test per group
+      // instead of GS neighbour tests.
+      float ev[GS];
+      u32 e_max = 0;
+#pragma unroll
+      for (int i = 0; i < GS; i++) {
+        ev[i] = clip_square_sum(acc[0][j][r0 + i], acc[1][j][r0 + i]);
+        e_max = max(e_max, __float_as_uint(ev[i]));   // (on the bit patterns: non-negative floats order like integers)
+      }
       const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x49800000u /* 2^20 as f32 */) == 0;
-      u32 mag[4];
+      u32 mag[GS];
       if (small) {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-          mag[rr] = (u32)(int)__builtin_amdgcn_sqrtf(e4v[rr] + 0.5f);
+        for (int i = 0; i < GS; i++)
+          mag[i] = (u32)(int)__builtin_amdgcn_sqrtf(ev[i] + 0.5f);
       } else {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-          mag[rr] = root_trunc(e4v[rr]);
+        for (int i = 0; i < GS; i++)
+          mag[i] = root_trunc(ev[i]);
       }
 #pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int r = 4 * g + rr;
-        u32 val = mag[rr];
+      for (int i = 0; i < GS; i++) {
+        const int r = r0 + i;
+        u32 val = mag[i];
         if (MULTI)
-          val += prev[rr];
-        out[rr] = val;
+          val += prev[i];
+        out[i] = val;
         if (SEARCH) {
           const u32 key = (val << 11) | key_lo;
           best[SEARCH ? r : 0] = key > best[SEARCH ? r : 0] ? key : best[SEARCH ? r : 0];
           total[SEARCH ? r : 0] += val;
         }
       }
-      if (MULTI && !ms_last)
-        *e_rec = sums_pack(out);
-      // four hypotheses at a time: enough independent chains to cover the ALU latencies, few enough to keep the 128
-      // accumulators and the 32 running results in registers (left alone, the compiler sinks all 64 chains to the
-      // reductions below, runs them side by side and spills): the results are pinned here, in program order
+      if (MULTI && !ms_last) {
+        const u32 o4[4] = {out[0], out[1], out[2], out[3]};
+        *e_rec = sums_pack(o4);
+      }
       if (SEARCH) {
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-          asm volatile("" : "+v"(best[SEARCH ? 4 * g + rr : 0]), "+v"(total[SEARCH ? 4 * g + rr : 0]));
+        for (int i = 0; i < GS; i++)
+          asm volatile("" : "+v"(best[SEARCH ? r0 + i : 0]), "+v"(total[SEARCH ? r0 + i : 0]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -694,7 +706,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     for (int hs = 0; hs <= 2 * kPasses; hs++) {
       __syncthreads();
       const int p_vec = (hs >> 1) + 1;
-      const bool build = p_vec < kPasses && !(ex & 8) && ((ex & 4) || role == (hs & 1));
+      const bool build = p_vec < kPasses && !(ex & 8) && ((ex & 4) || ((ex & 32) ? role != (hs & 1) : role == (hs & 1)));
       const int b_tid = (ex & 4) ? tid : (tid & 255), b_n = (ex & 4) ? kMxThreads : 256;
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
       const bool active = x >= 0 && x < 2 * kPasses;
