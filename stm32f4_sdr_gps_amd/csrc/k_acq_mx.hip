@@ -71,7 +71,9 @@ struct MxShared {
   v4i chips_a[16][2][32];                // A fragments: [kappa][h][PRN] = 32 FP4 chips 64 kappa + 32 h ..
   u32 chip_t[1032];                      // chip_t[c + 1]: bit p = chip c of PRN p of this cluster; [0] = chip -1 = 0
   u32 ones[2];                           // pop(D) per stream
-  u32 part[8][32][2];                    // (packed best key, sum) per bit shift and PRN
+  u32 part[8][32][2][32];                // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
+                                         // PRN: every lane folds its own results in with LDS atomics (no return value, no
+                                         // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
 };
 
 __device__ __forceinline__ v8i widen(v4i x) { return v8i{x.x, x.y, x.z, x.w, 0, 0, 0, 0}; }
@@ -282,27 +284,6 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
   }
 }
 
-// max / sum over the 32 lanes of each wave half on the DPP network; results in lanes 31 and 63
-__device__ __forceinline__ u32 half_max_to_lane31(u32 v)
-{
-  u32 o;
-  o = dpp<0xB1>(v, v); v = o > v ? o : v;
-  o = dpp<0x4E>(v, v); v = o > v ? o : v;
-  o = dpp<0x141>(v, v); v = o > v ? o : v;
-  o = dpp<0x140>(v, v); v = o > v ? o : v;
-  o = dpp<0x142, 0xA>(v, v); v = o > v ? o : v;      // row_bcast15 into rows 1, 3
-  return v;
-}
-__device__ __forceinline__ u32 half_sum_to_lane31(u32 v)
-{
-  v += dpp<0xB1>(0u, v);
-  v += dpp<0x4E>(0u, v);
-  v += dpp<0x141>(0u, v);
-  v += dpp<0x140>(0u, v);
-  v += dpp<0x142, 0xA>(0u, v);
-  return v;
-}
-
 // gps_correlation8's magnitude (PM/GPS/gps_misc.c:106-118) on the centred counts as the accumulators hold them (exact
 // integers in f32): one-sided clip, the squares as f32 products -- the correctly rounded product of the exact square is what
 // (float)(I * I) is --, their f32 sum, the correctly rounded root (v_sqrt_f32 + the neighbour test, as mag8_fast), truncation.
@@ -465,7 +446,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
-    const u32 key_lo = (u32)(2047 - (2 * q + half)) & 2047u;   // (q = 1023 does not exist: its magnitude is 0, its key never wins)
+    const u32 key_lo = (u32)(2047 - (2 * q + half));   // 0 .. 2047 (q = 1023 does not exist: its magnitude is 0)
     if constexpr (MULTI) {
       if (j == 0)
         mx_prefetch_sums<4, 4>(energy, lane, t0, ms_first, pre);
@@ -547,19 +528,12 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
   }
   if (!SEARCH)
     return;
+  // (all 16 PRNs of the lane, owned or not: group_mask decides what is written out)
 #pragma unroll
-  for (int g = 0; g < 4; g++) {
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const int r = 4 * g + rr;
-      const u32 k = half_max_to_lane31(best[SEARCH ? r : 0]);
-      const u32 t = half_sum_to_lane31(total[SEARCH ? r : 0]);
-      if (n == 31 && ((group_mask >> g) & 1u)) {
-        const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
-        atomicMax(&sh.part[b][p][0], k);
-        atomicAdd(&sh.part[b][p][1], t);
-      }
-    }
+  for (int r = 0; r < 16; r++) {
+    const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
+    atomicMax(&sh.part[b][p][0][n], best[SEARCH ? r : 0]);
+    atomicAdd(&sh.part[b][p][1][n], total[SEARCH ? r : 0]);
   }
 }
 
@@ -673,8 +647,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     const u32 *src_t = mx_t + (size_t)set * 1032;
     for (int i = tid; i < 1032; i += kMxThreads)
       sh.chip_t[i] = src_t[i];
-    for (int i = tid; i < 8 * 32 * 2; i += kMxThreads)
-      (&sh.part[0][0][0])[i] = 0;
+    for (int i = tid; i < 8 * 32 * 2 * 32; i += kMxThreads)
+      (&sh.part[0][0][0][0])[i] = 0;
   }
 
   __syncthreads();
@@ -754,7 +728,12 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     const int p = tid >> 3, b = tid & 7;
     const int slot = 32 * set + p;
     if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn) {
-      const u32 k = sh.part[b][p][0], t = sh.part[b][p][1];
+      u32 k = 0, t = 0;
+      for (int l = 0; l < 32; l++) {
+        const u32 kl = sh.part[b][p][0][(l + tid) & 31];   // (rotated start: the 256 threads spread over the banks)
+        k = kl > k ? kl : k;
+        t += sh.part[b][p][1][(l + tid) & 31];
+      }
       gpsx_peak_t pk;
       pk.max_val = k >> 11;
       pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
