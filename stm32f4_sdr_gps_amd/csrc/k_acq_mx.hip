@@ -433,9 +433,15 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
   constexpr bool ms_last = SEARCH;
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
-  u32 best[SEARCH ? 16 : 1], total[SEARCH ? 16 : 1];
+  // Search results: every lane owns a (bit shift, PRN) slot pair of LDS -- atomics without a return value at per-PRN
+  // constant offsets from one address, no conflicts.  Single-block searches keep a running maximum / sum per PRN in
+  // registers and fold them in once per sample offset (32 atomics); the multi-block form, short of registers next to its
+  // prefetched sums, folds every hypothesis in directly (measured: 3 % slower for the single-block form, 4 % faster here).
+  constexpr bool DIRECT = MULTI;
+  u32 *slot = SEARCH ? &sh.part[b][4 * h][0][n] : nullptr;
+  u32 best[SEARCH && !DIRECT ? 16 : 1], total[SEARCH && !DIRECT ? 16 : 1];
 #pragma unroll
-  for (int r = 0; r < (SEARCH ? 16 : 1); r++) {
+  for (int r = 0; r < (SEARCH && !DIRECT ? 16 : 1); r++) {
     best[r] = 0;
     total[r] = 0;
   }
@@ -459,9 +465,8 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
     //  group_mask decides below what is published)
     // GS hypotheses at a time: enough independent chains for a wave that has its SIMD's vector ALU to itself (its partner
-    // is in the MFMA pass) to cover the ALU, transcendental and branch latencies; few enough to keep the 128 accumulators
-    // and the 32 running results in registers (left alone, the compiler sinks all 64 chains to the reductions below, runs
-    // them side by side and spills): the results are pinned at the end of each group, in program order.
+    // is in the MFMA pass) to cover the ALU, transcendental and branch latencies, few enough to stay in registers next to
+    // the 128 accumulators.
     constexpr int GS = MULTI ? 4 : 8;
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += GS) {
@@ -508,32 +513,35 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         if (MULTI)
           val += prev[i];
         out[i] = val;
-        if (SEARCH) {
+        if (SEARCH && DIRECT) {
+          const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;   // PRN (r & 3) + 8 (r >> 2) + 4 h: 2 x 32 words per PRN
+          atomicMax(slot + p_off, (val << 11) | key_lo);
+          atomicAdd(slot + p_off + 32, val);
+        } else if (SEARCH) {
           const u32 key = (val << 11) | key_lo;
-          best[SEARCH ? r : 0] = key > best[SEARCH ? r : 0] ? key : best[SEARCH ? r : 0];
-          total[SEARCH ? r : 0] += val;
+          best[DIRECT ? 0 : r] = key > best[DIRECT ? 0 : r] ? key : best[DIRECT ? 0 : r];
+          total[DIRECT ? 0 : r] += val;
         }
       }
       if (MULTI && !ms_last) {
         const u32 o4[4] = {out[0], out[1], out[2], out[3]};
         *e_rec = sums_pack(o4);
       }
-      if (SEARCH) {
+      if (SEARCH && !DIRECT) {   // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
 #pragma unroll
         for (int i = 0; i < GS; i++)
-          asm volatile("" : "+v"(best[SEARCH ? r0 + i : 0]), "+v"(total[SEARCH ? r0 + i : 0]));
+          asm volatile("" : "+v"(best[DIRECT ? 0 : r0 + i]), "+v"(total[DIRECT ? 0 : r0 + i]));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (!SEARCH)
-    return;
-  // (all 16 PRNs of the lane, owned or not: group_mask decides what is written out)
+  if (SEARCH && !DIRECT) {
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int p = (r & 3) + 8 * (r >> 2) + 4 * h;
-    atomicMax(&sh.part[b][p][0][n], best[SEARCH ? r : 0]);
-    atomicAdd(&sh.part[b][p][1][n], total[SEARCH ? r : 0]);
+    for (int r = 0; r < 16; r++) {
+      const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;
+      atomicMax(slot + p_off, best[DIRECT ? 0 : r]);
+      atomicAdd(slot + p_off + 32, total[DIRECT ? 0 : r]);
+    }
   }
 }
 
