@@ -80,6 +80,11 @@ int gpsx_if_unpack2(gpsx_ctx *ctx, const uint8_t *if_2bit, int n_blocks, uint8_t
 
 /* device memory + HIP-event timing on the context's stream (so a C caller needs no HIP headers) */
 int gpsx_malloc(gpsx_ctx *ctx, void **dptr, size_t bytes);
+/* page-locked host memory for the buffers a real-time host hands to the host-pointer entry points every millisecond
+ * (capture blocks, channel states, accumulators): copies to and from it are plain DMA, without the runtime's staging of
+ * pageable pages and its jitter */
+int gpsx_host_alloc(gpsx_ctx *ctx, void **hptr, size_t bytes);
+int gpsx_host_free(gpsx_ctx *ctx, void *hptr);
 int gpsx_free(gpsx_ctx *ctx, void *dptr);
 int gpsx_memcpy_h2d(gpsx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int gpsx_memcpy_d2h(gpsx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);

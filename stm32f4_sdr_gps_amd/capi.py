@@ -62,6 +62,8 @@ def load_library() -> C.CDLL:
     lib.gpsx_last_error.argtypes = [C.c_void_p]
     lib.gpsx_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
     lib.gpsx_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_host_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
+    lib.gpsx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.gpsx_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.gpsx_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.gpsx_event_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -152,6 +154,9 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.gpsx_host_free(self.h, C.c_void_p(p))
+            self._pinned = []
             self.lib.gpsx_destroy(self.h)
             self.h = None
 
@@ -180,6 +185,17 @@ class Engine:
         p = C.c_void_p()
         self._chk(self.lib.gpsx_malloc(self.h, C.byref(p), nbytes), "gpsx_malloc")
         return p.value
+
+    def host_array(self, shape, dtype) -> np.ndarray:
+        """A numpy array in page-locked host memory (gpsx_host_alloc); lives until the engine is closed."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._chk(self.lib.gpsx_host_alloc(self.h, C.byref(p), max(n, 1)), "gpsx_host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)
+        buf = (C.c_ubyte * max(n, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def free(self, dptr: int):
         self._chk(self.lib.gpsx_free(self.h, dptr), "gpsx_free")
@@ -297,11 +313,12 @@ class Engine:
         return peaks, energy
 
     # -- tracking ---------------------------------------------------------------------------------------------
-    def track_epl(self, if_block: np.ndarray, states: np.ndarray) -> np.ndarray:
-        """states: TRK_DTYPE array, updated in place (if_freq_accum).  Returns int16 [n_ch, 6] = IE,QE,IP,QP,IL,QL."""
+    def track_epl(self, if_block: np.ndarray, states: np.ndarray, iq_out: np.ndarray | None = None) -> np.ndarray:
+        """states: TRK_DTYPE array, updated in place (if_freq_accum).  Returns int16 [n_ch, 6] = IE,QE,IP,QP,IL,QL
+        (written into iq_out when given, e.g. a page-locked array from host_array())."""
         assert states.dtype == TRK_DTYPE and states.flags.c_contiguous
         blk = np.ascontiguousarray(if_block, np.uint8)
-        iq = np.zeros((len(states), 6), np.int16)
+        iq = np.zeros((len(states), 6), np.int16) if iq_out is None else iq_out
         self._chk(self.lib.gpsx_track_epl_batch(self.h, blk.ctypes.data, states.ctypes.data, len(states),
                                                 iq.ctypes.data), "gpsx_track_epl_batch")
         return iq

@@ -205,6 +205,11 @@ void gpsx_destroy(gpsx_ctx *ctx)
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
+  if (ctx->aux_stream) {
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+    (void)hipEventDestroy(ctx->aux_event);
+  }
   if (ctx->own_stream && ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -269,6 +274,26 @@ int gpsx_malloc(gpsx_ctx *ctx, void **dptr, size_t bytes)
     (void)hipGetLastError();
     return fail(ctx, GPSX_ENOMEM, "hipMalloc failed");
   }
+  return GPSX_OK;
+}
+
+int gpsx_host_alloc(gpsx_ctx *ctx, void **hptr, size_t bytes)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!hptr)
+    return fail(ctx, GPSX_EINVAL, "null hptr");
+  if (hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, GPSX_ENOMEM, "hipHostMalloc failed");
+  }
+  return GPSX_OK;
+}
+
+int gpsx_host_free(gpsx_ctx *ctx, void *hptr)
+{
+  if (int rc = use_device(ctx)) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipHostFree(hptr));
   return GPSX_OK;
 }
 
@@ -764,6 +789,32 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   if (!d_if) {
     HIPCHK(ctx, hipMemcpyAsync(d_if_copy, if_block, blk_bytes, hipMemcpyHostToDevice, ctx->stream));
     d_if = d_if_copy;
+  }
+  // Very many channels: the step is mostly PCIe (16 B of state in, 28 B of state + accumulators out per channel), and the
+  // link is full duplex: the channels go through in chunks that alternate between the context's stream and a second one,
+  // so that one chunk's correlators and copy-out run under the next chunk's copy-in (page-locked caller buffers assumed:
+  // gpsx_host_alloc; with pageable ones the copies serialise in the runtime and nothing is lost).
+  constexpr int kChunkFrom = 131072, kChunks = 4;
+  if (n_ch >= kChunkFrom) {
+    if (!ctx->aux_stream) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->aux_event, ctx->stream));          // the block (and everything before) is in place
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
+    const int per = ((n_ch + kChunks - 1) / kChunks + 3) & ~3;
+    for (int c = 0, first = 0; first < n_ch; c++, first += per) {
+      const int n = std::min(per, n_ch - first);
+      hipStream_t s = (c & 1) ? ctx->aux_stream : ctx->stream;
+      HIPCHK(ctx, hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, s));
+      launch_track_epl(s, d_if, ctx->if_format, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all, d_iq + (size_t)first * 6);
+      LAUNCHCHK(ctx, "k_track_epl");
+      HIPCHK(ctx, hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, s));
+      HIPCHK(ctx, hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->aux_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return GPSX_OK;
   }
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
   if (int rc = gpsx_track_epl_batch_dev(ctx, d_if, d_st, n_ch, d_iq)) return rc;

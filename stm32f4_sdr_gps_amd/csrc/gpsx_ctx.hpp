@@ -31,6 +31,8 @@ struct gpsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t aux_stream = nullptr;   // second stream of the chunked tracking step (very many channels), created on first use
+  hipEvent_t aux_event = nullptr;
   std::string err;
   const char *last_kernel = "";      // dominant kernel of the last acquisition launch (gpsx_last_kernel)
   hipDeviceProp_t prop;

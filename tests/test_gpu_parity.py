@@ -815,7 +815,7 @@ def test_matrix_core_grid_vs_oracle(eng_mx, oracle, stream):
         assert np.array_equal(peaks[0][f], want[f]), f
 
 
-def test_matrix_core_grid_windows_sets_and_shards(eng_mx, eng, stream):
+def test_matrix_core_grid_windows_sets_and_shards(eng_mx, eng, oracle, stream):
     """40 PRNs = two 32-slot clusters (the second one a single 8-PRN group), windows, and every shard of 2, 3, 5 and 8:
     a shard's run of units cuts clusters anywhere, the kernel then skips the foreign 8-PRN groups of a workgroup."""
     prns = np.concatenate([np.arange(1, 33), [33, 40, 61, 100, 120, 150, 200, 210]]).astype(np.uint8)
@@ -825,6 +825,12 @@ def test_matrix_core_grid_windows_sets_and_shards(eng_mx, eng, stream):
         want_pk, want_keys = eng.acq_grid(stream[:2], prns, **kw)
         pk, keys = eng_mx.acq_grid(stream[:2], prns, **kw)
         assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys), kw
+    # a single PRN (one row of the GEMM in use) and 33 (a second cluster holding one PRN), against the oracle
+    for plist in (np.array([17], np.uint8), np.arange(1, 34, dtype=np.uint8)):
+        pk, _ = eng_mx.acq_grid(stream[3:4], plist, n_search=1, dopp_min_hz=-750, dopp_step_hz=1500, n_dopp=2)
+        want = oracle.acq_grid(stream[3:4], 1, plist, -750, 1500, 2, 8, n_threads=8)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(pk[0][f], want[f]), (len(plist), f)
     kw = dict(n_search=2, dopp_min_hz=-2000, dopp_step_hz=1000, n_dopp=5)
     want_pk, want_keys = eng.acq_grid(stream[:2], prns, **kw)
     for world in (2, 3, 5, 8):
