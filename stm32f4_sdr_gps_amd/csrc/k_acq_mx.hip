@@ -54,10 +54,12 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kMxThreads = 512;
 constexpr int kMxTiles = 4;            // q-tiles (32 chip offsets each) per wave
-constexpr int kCopyDwords = 264;       // one shifted copy of the nibble vector: 256 dwords + slack
+constexpr int kCopyDwords = 260;       // one shifted copy of the nibble vector: 256 dwords + slack; 260 = 4 (mod 32): the 32
+                                       // lanes of a fragment read (copy n % 8, dword n / 8 + ..) hit 32 different banks
 constexpr int kVecDwords = 258;        // dwords of copy 0 that the shifted copies are cut from
 constexpr int kPlaneWordsMx = 66;      // polyphase bit plane: 1023 bits + circular extension to 2112
 constexpr u32 kScaleOne = 0x7F7F7F7Fu;   // E8M0 127 = 2^0
+constexpr u32 kScaleA = kScaleOne;
 constexpr u32 kScaleEight = 0x82828282u; // E8M0 130 = 2^3
 constexpr int kPasses = 17;            // 2 for the first offset + 15 recurrence steps
 
@@ -242,31 +244,67 @@ __device__ void mx_vector_phase2(MxShared &sh, int buf, int tid, int nthreads)
 }
 
 // ---- one MFMA pass: acc[stream][tile] += chips x Toeplitz(vector) -------------------------------------------------------
+typedef __attribute__((address_space(3))) const u32 lds_cu32;
+
+// an LDS address the compiler cannot see through: what is added to it afterwards are small constants that fit the DS
+// instructions' offset fields (left alone it rebuilds "variable part + offset of the array in the LDS block + 32 s" with a
+// v_add per load: the array's offset does not fit the 8-bit dword offsets of ds_read2_b32)
+__device__ __forceinline__ lds_cu32 *lds_opaque(const u32 *p)
+{
+  u32 a = (u32)(size_t)(lds_cu32 *)p;
+  asm volatile("" : "+v"(a));
+  return (lds_cu32 *)(size_t)a;
+}
+__device__ __forceinline__ v4i lds_frag(lds_cu32 *w, int dw)   // four dwords, dword aligned only
+{
+  return v4i{(int)w[dw], (int)w[dw + 1], (int)w[dw + 2], (int)w[dw + 3]};
+}
+
+// One anti-diagonal of a pass (fragment Q0 + 2 S): request the fragments of the next one, then the MFMAs of this one.
+// The sched_group_barriers pin that order -- the DS reads first, (8 MFMAs = 260 cycles ahead of their use) -- which the
+// scheduler, short of registers, would otherwise turn into "requested one MFMA before the wait": the LDS is kept busy by
+// the four waves of the other role, a wave that waits for it at every step loses a third of the matrix pipe's time.
+template <int S>
+__device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v4i *ca, v4i (&a)[16], v4i &fi, v4i &fq,
+                                             v16f (&acc)[2][kMxTiles], u32 scale_b)
+{
+  constexpr int kSteps = 16 + kMxTiles - 1;
+  constexpr bool more = S + 1 < kSteps;
+  v4i fi_next = fi, fq_next = fq;
+  if constexpr (more) {
+    fi_next = lds_frag(wi, 8 * (S + 1));
+    fq_next = lds_frag(wq, 8 * (S + 1));
+    if constexpr (S + 1 < 16)
+      a[S + 1] = ca[(S + 1) * 64];                         // chips_a[S + 1][h][n]
+  }
+  constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < kMxTiles - 1 ? S : kMxTiles - 1;
+#pragma unroll
+  for (int j = j_lo; j <= j_hi; j++) {
+    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
+    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fq), acc[1][j], 4, 4, 0, kScaleA, 0, scale_b);
+  }
+  if constexpr (more) {
+    __builtin_amdgcn_sched_group_barrier(0x100, S + 1 < 16 ? 5 : 4, 0);   // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 2 * (j_hi - j_lo + 1), 0);   // MFMAs
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  fi = fi_next;
+  fq = fq_next;
+  if constexpr (more)
+    mx_pass_step<S + 1>(wi, wq, ca, a, fi, fq, acc, scale_b);
+}
+
 __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][kMxTiles],
                                         u32 scale_b, v4i a_corr, bool with_corr)
 {
   const int n = lane & 31, h = lane >> 5;
-  const u32 *wi = &sh.e8[buf][0][n & 7][4 * (q0_tile + h) + (n >> 3)];
-  const u32 *wq = &sh.e8[buf][1][n & 7][4 * (q0_tile + h) + (n >> 3)];
+  lds_cu32 *wi = lds_opaque(&sh.e8[buf][0][n & 7][4 * (q0_tile + h) + (n >> 3)]);
+  lds_cu32 *wq = lds_opaque(&sh.e8[buf][1][n & 7][4 * (q0_tile + h) + (n >> 3)]);
   const v4i *ca = &sh.chips_a[0][h][n];
   v4i a[16];
-#pragma unroll
-  for (int s = 0; s < 16 + kMxTiles - 1; s++) {
-    if (s < 16)
-      a[s] = ca[s * 64];                                   // chips_a[s][h][n]
-    const v4i fi = v4i{(int)wi[8 * s], (int)wi[8 * s + 1], (int)wi[8 * s + 2], (int)wi[8 * s + 3]};   // fragment Q0 + 2 s
-    const v4i fq = v4i{(int)wq[8 * s], (int)wq[8 * s + 1], (int)wq[8 * s + 2], (int)wq[8 * s + 3]};
-#pragma unroll
-    for (int j = 0; j < kMxTiles; j++) {
-      const int kappa = s - j;
-      if (kappa < 0 || kappa >= 16)
-        continue;
-      acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fi), acc[0][j], 4, 4, 0, kScaleOne,
-                                                                   0, scale_b);
-      acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fq), acc[1][j], 4, 4, 0, kScaleOne,
-                                                                   0, scale_b);
-    }
-  }
+  v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
+  a[0] = ca[0];
+  mx_pass_step<0>(wi, wq, ca, a, fi, fq, acc, scale_b);
   if (with_corr) {   // wave-uniform
     // the extra K step: only column 0 of each lane half of A is set (chip 1022 / chip 1021 of the PRN), so only the first
     // nibble of a lane's B window counts: the step's delta for (stream, term h, q)
@@ -276,9 +314,9 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
       const int q = 32 * (q0_tile + 2 * j) + n;
       const v4i gi = v4i{(int)(sh.corr[buf][0][h][q >> 3] >> (4 * (n & 7))), 0, 0, 0};
       const v4i gq = v4i{(int)(sh.corr[buf][1][h][q >> 3] >> (4 * (n & 7))), 0, 0, 0};
-      acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gi), acc[0][j], 4, 4, 0, kScaleOne, 0,
+      acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gi), acc[0][j], 4, 4, 0, kScaleA, 0,
                                                                    kScaleOne);
-      acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gq), acc[1][j], 4, 4, 0, kScaleOne, 0,
+      acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gq), acc[1][j], 4, 4, 0, kScaleA, 0,
                                                                    kScaleOne);
     }
   }
