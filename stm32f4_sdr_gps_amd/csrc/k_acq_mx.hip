@@ -59,7 +59,12 @@ constexpr int kCopyDwords = 260;       // one shifted copy of the nibble vector:
 constexpr int kVecDwords = 258;        // dwords of copy 0 that the shifted copies are cut from
 constexpr int kPlaneWordsMx = 66;      // polyphase bit plane: 1023 bits + circular extension to 2112
 constexpr u32 kScaleOne = 0x7F7F7F7Fu;   // E8M0 127 = 2^0
-constexpr u32 kScaleA = kScaleOne;
+// The accumulators hold (cnt - 8184) / 8192: the A operand's block scale is 2^-13 (E8M0 114).  A power of two changes no
+// rounding anywhere, and it puts every in-window value inside (-1, 1), where one v_mul_f32 c, |c| with the clamp modifier
+// IS the reference's clip-and-square (mx_clip_square).
+constexpr u32 kScaleA = 0x72727272u;
+constexpr float kAccScale = 1.0f / 8192.0f;
+constexpr float kUnscaleSq = 67108864.0f;   // 2^26: scaled squares -> integers
 constexpr u32 kScaleEight = 0x82828282u; // E8M0 130 = 2^3
 constexpr int kPasses = 17;            // 2 for the first offset + 15 recurrence steps
 
@@ -140,21 +145,35 @@ __device__ void mx_prepare_block(MxShared &sh, const uint8_t *blk, int if_format
   if (tid < 2)
     sh.d[tid][511] = sh.d[tid][0] << 16;   // samples 16352..16367 are zero, then the stream wraps to sample 0
   __syncthreads();
-  // plane[iq][t0] bit i = D(16 (i mod 1023) + t0), i < 2112
-  for (int m = tid; m < 2 * 16 * kPlaneWordsMx; m += kMxThreads) {
-    const int iq = m / (16 * kPlaneWordsMx);
-    const int r = m - iq * 16 * kPlaneWordsMx;
-    const int t0 = r / kPlaneWordsMx;
-    const int w = r - t0 * kPlaneWordsMx;
-    const u32 *dd = sh.d[iq];
+  // plane[iq][t0] bit i = D(16 (i mod 1023) + t0), i < 2112.  First period: word w of offset t0 takes bit t0 and bit 16 + t0
+  // of the stream words 16 w .. 16 w + 15 (bit 1023 = D(16368 + t0) is the wrap-around copy in word 511: D(t0), as it has
+  // to be); the 16 threads of a word read the same 16 addresses (LDS broadcast).
+  for (int m = tid; m < 2 * 32 * 16; m += kMxThreads) {
+    const int t0 = m & 15, w = (m >> 4) & 31, iq = m >> 9;
+    const u32 *src = &sh.d[iq][16 * w];
     u32 bits = 0;
-#pragma unroll 8
-    for (int e = 0; e < 32; e++) {
-      const int k = wrap1023(32 * w + e);
-      const int pos = 16 * k + t0;   // < 16368: the stream's own samples (the last 16 are zero)
-      bits |= ((dd[pos >> 5] >> (pos & 31)) & 1u) << e;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 sk = src[k];
+      bits |= ((sk >> t0) & 1u) << (2 * k);
+      bits |= ((sk >> (16 + t0)) & 1u) << (2 * k + 1);
     }
     sh.plane[iq][t0][w] = bits;
+  }
+  __syncthreads();
+  // circular extension: word w >= 32 = the 32 bits from position 32 w mod 1023 of the 1023-bit period
+  for (int m = tid; m < 2 * 16 * (kPlaneWordsMx - 32); m += kMxThreads) {
+    const int w = 32 + m % (kPlaneWordsMx - 32);
+    const int r = m / (kPlaneWordsMx - 32);
+    const u32 *pl = sh.plane[r >> 4][r & 15];
+    const int pos = 32 * w - (w >= 64 ? 2 * kChips : kChips);
+    const int lo = pos >> 5;
+    u32 v = __builtin_amdgcn_alignbit(lo < 31 ? pl[lo + 1] : 0u, pl[lo], (u32)(pos & 31));
+    if (pos + 32 > kChips) {   // the period ends inside the word: its first bits follow
+      const int k = kChips - pos;
+      v = (v & ((1u << k) - 1u)) | (pl[0] << k);
+    }
+    sh.plane[r >> 4][r & 15][w] = v;
   }
   // (the caller's next barrier publishes the planes)
 }
@@ -323,23 +342,23 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
 }
 
 // gps_correlation8's magnitude (PM/GPS/gps_misc.c:106-118) on the centred counts as the accumulators hold them (exact
-// integers in f32): one-sided clip, the squares as f32 products -- the correctly rounded product of the exact square is what
-// (float)(I * I) is --, their f32 sum, the correctly rounded root (v_sqrt_f32 + the neighbour test, as mag8_fast), truncation.
+// integers / 8192 in f32): one-sided clip and square in one instruction, the f32 sum of the two, the correctly rounded root
+// (v_sqrt_f32 + the neighbour test, as mag8_fast), truncation.
 __device__ __forceinline__ u32 root_trunc(float e);
-__device__ __forceinline__ float clip_square_sum(float ci, float cq)
+// max(c, 0)^2 for |c| < 1 (and 0 for any c <= -1): c |c| clamped to [0, 1].  The product of the exact count with itself,
+// rounded once: what (float)(I * I) is -- at 2^-26.
+__device__ __forceinline__ float mx_clip_square(float c)
 {
-  const int ib = (int)__float_as_uint(ci), qb = (int)__float_as_uint(cq);
-  const float i = __uint_as_float((u32)(ib < 0 ? 0 : ib)), q = __uint_as_float((u32)(qb < 0 ? 0 : qb));
-  return i * i + q * q;
+  // (v_mul_f32 c, |c| clamp: the median with 0 and 1 folds into the multiplication's clamp bit)
+  return __builtin_amdgcn_fmed3f(c * __builtin_fabsf(c), 0.0f, 1.0f);
+}
+__device__ __forceinline__ float clip_square_sum(float ci, float cq)   // (I^2 + Q^2) / 2^26
+{
+  return mx_clip_square(ci) + mx_clip_square(cq);
 }
 __device__ __forceinline__ u32 mag8_f32(float ci, float cq)
 {
-  // (clip on the bit patterns: a negative float is a negative int; fmaxf() would first canonicalise its operand with a
-  //  second v_max_f32)
-  const int ib = (int)__float_as_uint(ci), qb = (int)__float_as_uint(cq);
-  const float i = __uint_as_float((u32)(ib < 0 ? 0 : ib)), q = __uint_as_float((u32)(qb < 0 ? 0 : qb));
-  const float e = i * i + q * q;   // (-ffp-contract=off: two rounded products, one rounded sum)
-  return root_trunc(e);
+  return root_trunc(clip_square_sum(ci, cq) * kUnscaleSq);
 }
 
 // (int) of the correctly rounded f32 root
@@ -355,14 +374,15 @@ __device__ __forceinline__ u32 root_trunc(float e)
   return (u32)(int)r;
 }
 
-constexpr float kOutside = -1048576.0f;   // start value of hypotheses outside the search window: stays negative, clips to 0
+constexpr float kOutside = -1048576.0f * kAccScale;   // start value (scaled) of hypotheses outside the search window: stays
+                                                      // below -1, clips to 0
 
 // Start of a block: every accumulator = the part of  cnt - 8184  that does not depend on the code (even byte offsets)
 __device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int win_start,
                                             int win_stop)
 {
   const int n = lane & 31;
-  const float base_i = (float)((int)sh.ones[0] + 8192 - kHalf), base_q = (float)((int)sh.ones[1] + 8192 - kHalf);
+  const float base_i = (float)((int)sh.ones[0] + 8192 - kHalf) * kAccScale, base_q = (float)((int)sh.ones[1] + 8192 - kHalf) * kAccScale;
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
@@ -388,7 +408,7 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
 {
   const int n = lane & 31, h = lane >> 5;
   const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8, wrap_q = (sh.d[1][0] & 0xFFu) << 8;
-  const float beta0_i = (float)(16 - 2 * (int)__popc(wrap_i)), beta0_q = (float)(16 - 2 * (int)__popc(wrap_q));
+  const float beta0_i = (float)(16 - 2 * (int)__popc(wrap_i)) * kAccScale, beta0_q = (float)(16 - 2 * (int)__popc(wrap_q)) * kAccScale;
   const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
   const u32 f22 = sh.chip_t[1022 + 1] >> (4 * h);
 #pragma unroll
@@ -410,12 +430,12 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
       fa_i -= 16 - 2 * (int)__popc(prev_i);
       fa_q -= 16 - 2 * (int)__popc(prev_q);
     }
-    float fkf_i = (float)fk_i, fkf_q = (float)fk_q;
+    float fkf_i = (float)fk_i * kAccScale, fkf_q = (float)fk_q * kAccScale;
     if (in0 != in1) {   // the window edge falls between the two byte offsets of this chip offset
       fkf_i += in1 ? -kOutside : kOutside;
       fkf_q += in1 ? -kOutside : kOutside;
     }
-    const float faf_i = (float)fa_i, faf_q = (float)fa_q;
+    const float faf_i = (float)fa_i * kAccScale, faf_q = (float)fa_q * kAccScale;
     const u32 w1 = sh.chip_t[(exists ? kChips - 1 - q : 0) + 1] >> (4 * h);   // chip 1022 - q of the lane's PRNs
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -533,16 +553,16 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         ev[i] = clip_square_sum(acc[0][j][r0 + i], acc[1][j][r0 + i]);
         e_max = max(e_max, __float_as_uint(ev[i]));   // (on the bit patterns: non-negative floats order like integers)
       }
-      const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x49800000u /* 2^20 as f32 */) == 0;
+      const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
       u32 mag[GS];
       if (small) {
 #pragma unroll
         for (int i = 0; i < GS; i++)
-          mag[i] = (u32)(int)__builtin_amdgcn_sqrtf(ev[i] + 0.5f);
+          mag[i] = (u32)(int)__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f));
       } else {
 #pragma unroll
         for (int i = 0; i < GS; i++)
-          mag[i] = root_trunc(ev[i]);
+          mag[i] = root_trunc(ev[i] * kUnscaleSq);
       }
 #pragma unroll
       for (int i = 0; i < GS; i++) {
@@ -580,6 +600,74 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       atomicMax(slot + p_off, best[DIRECT ? 0 : r]);
       atomicAdd(slot + p_off + 32, total[DIRECT ? 0 : r]);
     }
+  }
+}
+
+// The single-block form's epilogue (n_ms == 1: what the headline sweep runs).  A wave that has its SIMD's vector ALU to
+// itself issues an instruction every ~6.5 cycles whatever the instruction (tools/microbench/issue_mix.hip), so what counts
+// here is their number: per hypothesis 2 clip-squares, 1 add, 3/8 of the group's radius test, 1 fma (e + 1/2), the root,
+// 1 add that rounds it down to an integer in the low mantissa bits, the key, and 1/2 + 1/2 for the running maximum and
+// sum of its PRN (two tiles at a time: v_max3_u32 / v_add3_u32).
+//   root + (2^23 - 1/2) rounds to 2^23 + floor(root) for every root of the small path (no root is an integer there, see
+//   mx_epilogue), whose f32 pattern is 0x4B000000 + floor(root): shifted left by 11 the exponent bits fall off the key; the
+//   sums carry 0x4B000000 per term, four terms per PRN and sample offset: they start at -4 x 0x4B000000 (mod 2^32).
+constexpr u32 kRootBias = 0x4B000000u;
+__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[kMxTiles], int t0,
+                                                   const v16f (&acc)[2][kMxTiles])
+{
+  const int n = lane & 31, h = lane >> 5;
+  const int b = t0 & 7, half = t0 >> 3;
+  u32 *slot = &sh.part[b][4 * h][0][n];
+  u32 best[16], total[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    best[r] = 0;
+    total[r] = 0u - 4u * kRootBias;
+  }
+#pragma unroll
+  for (int jp = 0; jp < kMxTiles; jp += 2) {
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      // eight hypotheses: two tiles x four PRNs
+      float ev[8];
+      u32 e_max = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        ev[i] = clip_square_sum(acc[0][jp + (i >> 2)][r0 + (i & 3)], acc[1][jp + (i >> 2)][r0 + (i & 3)]);
+        e_max = max(e_max, __float_as_uint(ev[i]));
+      }
+      const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
+      u32 bits[8];
+      if (__builtin_expect(small, 1)) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          bits[i] = __float_as_uint(__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f)) + 8388607.5f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          bits[i] = root_trunc(ev[i] * kUnscaleSq) + kRootBias;
+      }
+      // key = (magnitude << 11) | (2047 - byte offset), byte offset = 2 q + half: kq = 2047 - 2 q is the lane's own
+      // constant, the wave-uniform half comes off the maximum when it is folded into the LDS slot
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int r = r0 + rr;
+        const u32 k0 = (bits[rr] << 11) | kq[jp], k1 = (bits[4 + rr] << 11) | kq[jp + 1];
+        best[r] = max(max(best[r], k0), k1);
+        total[r] = total[r] + bits[rr] + bits[4 + rr];
+      }
+      // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        asm volatile("" : "+v"(best[r0 + rr]), "+v"(total[r0 + rr]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;   // PRN (r & 3) + 8 (r >> 2) + 4 h: 2 x 32 words per PRN
+    atomicMax(slot + p_off, best[r] - (u32)half);      // (kq >= 1: the subtraction stays inside the low field)
+    atomicAdd(slot + p_off + 32, total[r]);
   }
 }
 
@@ -657,7 +745,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   constexpr bool MULTI = MODE == kMxWalk, STORE = MODE == kMxStore;
   __shared__ MxShared sh;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values in SGPRs)
   const int ex = prm.experiment;   // timing ablations: 1 = no epilogue, 2 = no MFMA, 4 = no stagger, 8 = no vector prep
   const int role = (ex & 4) ? 0 : wave >> 2;             // waves w and w + 4 share a SIMD: half a step apart
   const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
@@ -700,6 +788,12 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __syncthreads();
   // A operand of the extra K step: column 0 of lane half 0 = chip 1022 of PRN (lane & 31), of half 1 = chip 1021
   const v4i a_corr = v4i{(int)(((sh.chip_t[(lane >> 5 ? 1021 : 1022) + 1] >> (lane & 31)) & 1u) << 1), 0, 0, 0};
+  u32 kq[kMxTiles];   // 2047 - (even byte offset of the lane's chip offset in tile j): the low field of its search keys
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    kq[j] = (u32)(2047 - 2 * (32 * (q0_tile + 2 * j) + (lane & 31)));
+    asm volatile("" : "+v"(kq[j]));
+  }
   u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * 3) : nullptr;   // SumRec = 3 dwords
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const int n_ms = MULTI ? prm.n_ms : 1;
@@ -716,6 +810,13 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+    if (ex & 2) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
+#pragma unroll
+      for (int j = 0; j < kMxTiles; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          acc[0][j][r] = acc[1][j][r] = (float)(lane + r) * kAccScale;
+    }
     SumRec pre[MULTI ? 16 : 1];
 
     // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
@@ -759,7 +860,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
           mx_epilogue_store(lane, q0_tile, p - 1, acc, group_mask, plane0, (size_t)prm.n_dopp * (16 * 1024), 32 * set, prm.n_prn);
         }
       } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
-        if (MULTI && !ms_last)
+        if (!MULTI)
+          mx_epilogue_single(sh, lane, kq, p - 1, acc);
+        else if (!ms_last)
           mx_epilogue<MULTI, false>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);
         else
           mx_epilogue<MULTI, true>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);

@@ -47,5 +47,7 @@ def main():
                       "hyp_per_s": hyp / (ms * 1e-3)}))
 
 
+
+
 if __name__ == "__main__":
     main()
