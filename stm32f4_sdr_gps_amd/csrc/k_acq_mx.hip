@@ -78,6 +78,8 @@ struct MxShared {
   v4i chips_a[16][2][32];                // A fragments: [kappa][h][PRN] = 32 FP4 chips 64 kappa + 32 h ..
   u32 chip_t[1032];                      // chip_t[c + 1]: bit p = chip c of PRN p of this cluster; [0] = chip -1 = 0
   u32 ones[2];                           // pop(D) per stream
+  u32 t_diff[512];                       // 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7 (mx_fill_tables)
+  u32 t_sign[256];                       // 8 bits -> FP4 codes of 2 bit - 1
   u32 part[8][32][2][32];                // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
                                          // PRN: every lane folds its own results in with LDS atomics (no return value, no
                                          // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
@@ -185,69 +187,85 @@ __device__ __forceinline__ u32 fp4_code(int v)
   return ((0x0765420u >> (4u * (m > 5u ? 5u : m))) & 0xFu) | (v < 0 ? 8u : 0u);   // |v|: 0 1 2 3 4 6 -> 0 2 4 5 6 7
 }
 
+// The vector builders' lookup tables (once per workgroup): what they replace is the bit -> nibble spreading, a dozen
+// vector instructions per dword of the vectors -- and the vectors are built once per sample offset next to the MFMA passes,
+// by waves that have better things to do.
+__device__ void mx_fill_tables(MxShared &sh, int tid)
+{
+  for (int w = tid; w < 512; w += kMxThreads) {
+    const u32 cur = (u32)w & 0xFFu, nxt = ((u32)w >> 1) & 0xFFu;
+    const u32 plus = spread8(nxt & ~cur), minus = spread8(cur & ~nxt);   // e = +1 -> -2 (code C), e = -1 -> +2 (code 4)
+    sh.t_diff[w] = (plus << 2) | (plus << 3) | (minus << 2);
+  }
+  for (int x = tid; x < 256; x += kMxThreads)
+    sh.t_sign[x] = (spread8((u32)x) << 1) | (spread8(~(u32)x & 0xFFu) * 0xAu);   // +1 -> code 2, -1 -> code A
+}
+
 // ---- per pass: the nibble vector, copy 0 (phase 1), then its eight shifted copies (phase 2) --------------------------------
 // pass 0: -2 (S_0 & 3), pass 1: -(S_0 >> 2) at scale 2^3, pass p >= 2 (producing sample offset t0 = p - 1 from plane
 // p - 2): -2 e_{p-2}, plus the wrap-word impulses when t0 is 9..15; and the byte vectors of the extra K step.
 __device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid, int nthreads)
 {
   const int t0 = pass - 1;
-  // nibbles 0 .. 2055 are ever read (dword 4 * 62 + 3 + 3 of copy 7): 258 dwords of copy 0
-  for (int m = tid; m < 2 * kVecDwords; m += nthreads) {
-    const int iq = m / kVecDwords, dw = m - iq * kVecDwords;
-    u32 packed = 0;
-    if (pass < 2) {
-      const u32 *dd = sh.d[iq];
+  // nibbles 0 .. 2055 are ever read (dword 4 * 62 + 3 + 3 of copy 7): 258 dwords of copy 0; then the 2 x 128 dword pairs of
+  // the extra K step
+  for (int m = tid; m < 2 * kVecDwords + 2 * 128; m += nthreads) {
+    if (m < 2 * kVecDwords) {
+      const int iq = m >= kVecDwords, dw = m - iq * kVecDwords;
+      u32 packed = 0;
+      if (pass < 2) {
+        const u32 *dd = sh.d[iq];
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int k = wrap1023(8 * dw + e);
-        const int pos = 16 * k;
-        const u32 sum = pop16(__builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31)));
-        // pass 0: -2 (S & 3) = 0, -2, -4, -6 -> codes 0, C, E, F;  pass 1: -(S >> 2) = 0 .. -4 -> codes 0, A, C, D, E
-        const u32 code = pass == 0 ? (0xFEC0u >> (4u * (sum & 3u))) & 0xFu : (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;
-        packed |= code << (4 * e);
-      }
-    } else {
-      const u32 w = plane_bits9(sh.plane[iq][pass - 2], 8 * dw);
-      const u32 cur = w & 0xFFu, nxt = (w >> 1) & 0xFFu;
-      const u32 plus = spread8(nxt & ~cur), minus = spread8(cur & ~nxt);   // e = +1 -> -2 (code C), e = -1 -> +2 (code 4)
-      packed = (plus << 2) | (plus << 3) | (minus << 2);
-      if (dw == 127 && t0 >= 9) {
-        // entries 1021 / 1022 (nibbles 5 / 6 of this dword, first period only): the skipped wrap word's coefficients
-        // alpha_b = b on chip 1021 - q and beta_b = const - b on chip 1022 - q move by +1 / -1 per step; they are
-        // subtracted from the count: -1 / +1 here
-        const int e5 = (int)((nxt >> 5) & 1u) - (int)((cur >> 5) & 1u), e6 = (int)((nxt >> 6) & 1u) - (int)((cur >> 6) & 1u);
-        packed = (packed & ~0x0FF00000u) | (fp4_code(-2 * e5 - 1) << 20) | (fp4_code(-2 * e6 + 1) << 24);
-      }
-    }
-    sh.base[iq][dw] = packed;
-  }
-  // extra K step: deltas of  c1022 * A'(q)  and  c1021 * B'(q)  (see mx_half_switch for the terms themselves), eight
-  // chip offsets per dword:
-  //   t0 = 1..7, 9..15:  A_b = 2 pop(byte_o & low_b) - b grows by 2 D(8 o + b) - 1 = 2 d[q] - 1
-  //   t0 = 9..15, q > 0: the tail word (o - 2, o - 1) of odd offsets, whose bit b is d[q - 1]: A' += 1 - 2 d[q - 1],
-  //                      B' grows by 2 d[q - 1] - 1
-  for (int m = tid; m < 2 * 128; m += nthreads) {
-    const int iq = m >> 7, dw = m & 127;
-    u32 ca = 0, cb = 0;
-    if (pass >= 2 && t0 != 8) {
-      const u32 *pl = sh.plane[iq][pass - 2];
-      // bits 8 dw - 1 .. 8 dw + 7 of the plane (bit -1 = 0)
-      const u32 w = dw ? plane_bits9(pl, 8 * dw - 1) : (pl[0] << 1) & 0x1FFu;
-      const u32 d = (w >> 1) & 0xFFu, dm = w & 0xFFu;   // d[q], d[q - 1] for the eight q of this dword
-      const u32 exist = dw == 127 ? 0x7Fu : 0xFFu;       // q = 1023 does not exist
-      if (t0 < 8) {
-        // +1 -> code 2, -1 -> code A
-        ca = (spread8(d & exist) << 1) | (spread8(~d & exist) * 0xAu);
+        for (int e = 0; e < 8; e++) {
+          const int k = wrap1023(8 * dw + e);
+          const int pos = 16 * k;
+          const u32 sum = pop16(__builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31)));
+          // pass 0: -2 (S & 3) = 0, -2, -4, -6 -> codes 0, C, E, F;  pass 1: -(S >> 2) = 0 .. -4 -> codes 0, A, C, D, E
+          const u32 code = pass == 0 ? (0xFEC0u >> (4u * (sum & 3u))) & 0xFu : (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;
+          packed |= code << (4 * e);
+        }
       } else {
-        const u32 tail = dw == 0 ? 0xFEu : 0xFFu;        // q = 0 has no tail word
-        const u32 plus2 = d & ~dm & tail, minus2 = ~d & dm & tail;   // 2 (d - dm): code 4 / C
-        const u32 q0p = d & ~tail, q0m = ~d & ~tail;                 // q = 0: 2 d - 1
-        ca = (spread8(plus2 & exist) << 2) | (spread8(minus2 & exist) * 0xCu) | (spread8(q0p) << 1) | (spread8(q0m & 1u) * 0xAu);
-        cb = (spread8(dm & tail & exist) << 1) | (spread8(~dm & tail & exist) * 0xAu);
+        const u32 w = plane_bits9(sh.plane[iq][pass - 2], 8 * dw);
+        packed = sh.t_diff[w];
+        if (dw == 127 && t0 >= 9) {
+          // entries 1021 / 1022 (nibbles 5 / 6 of this dword, first period only): the skipped wrap word's coefficients
+          // alpha_b = b on chip 1021 - q and beta_b = const - b on chip 1022 - q move by +1 / -1 per step; they are
+          // subtracted from the count: -1 / +1 here
+          const u32 cur = w & 0xFFu, nxt = (w >> 1) & 0xFFu;
+          const int e5 = (int)((nxt >> 5) & 1u) - (int)((cur >> 5) & 1u), e6 = (int)((nxt >> 6) & 1u) - (int)((cur >> 6) & 1u);
+          packed = (packed & ~0x0FF00000u) | (fp4_code(-2 * e5 - 1) << 20) | (fp4_code(-2 * e6 + 1) << 24);
+        }
       }
+      sh.base[iq][dw] = packed;
+    } else {
+      // extra K step: deltas of  c1022 * A'(q)  and  c1021 * B'(q)  (see mx_half_switch for the terms themselves), eight
+      // chip offsets per dword:
+      //   t0 = 1..7, 9..15:  A_b = 2 pop(byte_o & low_b) - b grows by 2 D(8 o + b) - 1 = 2 d[q] - 1
+      //   t0 = 9..15, q > 0: the tail word (o - 2, o - 1) of odd offsets, whose bit b is d[q - 1]: A' += 1 - 2 d[q - 1]
+      //                      (together 2 (d[q] - d[q - 1])), B' grows by 2 d[q - 1] - 1
+      const int mm = m - 2 * kVecDwords;
+      const int iq = mm >> 7, dw = mm & 127;
+      u32 ca = 0, cb = 0;
+      if (pass >= 2 && t0 != 8) {
+        const u32 *pl = sh.plane[iq][pass - 2];
+        // bits 8 dw - 1 .. 8 dw + 7 of the plane (bit -1 = 0): d[q] = bit k + 1, d[q - 1] = bit k for the eight q of this dword
+        const u32 w = dw ? plane_bits9(pl, 8 * dw - 1) : (pl[0] << 1) & 0x1FFu;
+        const u32 exist = dw == 127 ? 0x0FFFFFFFu : 0xFFFFFFFFu;   // q = 1023 does not exist
+        if (t0 < 8) {
+          ca = sh.t_sign[w >> 1] & exist;
+        } else {
+          const u32 diff = sh.t_diff[w];                            // -2 (d - dm)
+          ca = (diff ^ ((diff & 0x44444444u) << 1)) & exist;        // 2 (d - dm): the sign bit of the non-zero codes flips
+          cb = sh.t_sign[w & 0xFFu] & exist;                        // 2 dm - 1
+          if (dw == 0) {                                            // q = 0 has no tail word: A' grows by 2 d - 1, B' stays
+            ca = (ca & ~0xFu) | ((w & 2u) ? 0x2u : 0xAu);
+            cb &= ~0xFu;
+          }
+        }
+      }
+      sh.corr[buf][iq][0][dw] = ca;
+      sh.corr[buf][iq][1][dw] = cb;
     }
-    sh.corr[buf][iq][0][dw] = ca;
-    sh.corr[buf][iq][1][dw] = cb;
   }
 }
 
@@ -783,6 +801,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       sh.chip_t[i] = src_t[i];
     for (int i = tid; i < 8 * 32 * 2 * 32; i += kMxThreads)
       (&sh.part[0][0][0][0])[i] = 0;
+    mx_fill_tables(sh, tid);
   }
 
   __syncthreads();
@@ -827,8 +846,15 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     for (int hs = 0; hs <= 2 * kPasses; hs++) {
       __syncthreads();
       const int p_vec = (hs >> 1) + 1;
-      const bool build = p_vec < kPasses && !(ex & 8) && ((ex & 4) || ((ex & 32) ? role != (hs & 1) : role == (hs & 1)));
-      const int b_tid = (ex & 4) ? tid : (tid & 255), b_n = (ex & 4) ? kMxThreads : 256;
+      // (all eight waves, at the start of the half step: with the lookup tables a phase is ~20 instructions per thread)
+      const bool build = p_vec < kPasses && !(ex & 8);
+      const int b_tid = tid, b_n = kMxThreads;
+      if (build) {
+        if ((hs & 1) == 0)
+          mx_vector_phase1(sh, p_vec, p_vec & 1, b_tid, b_n);
+        else
+          mx_vector_phase2(sh, p_vec & 1, b_tid, b_n);
+      }
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
       const bool active = x >= 0 && x < 2 * kPasses;
       const int p = x >> 1;
@@ -846,12 +872,6 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         }
         if (p == 9)
           mx_half_switch(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-      }
-      if (build) {
-        if ((hs & 1) == 0)
-          mx_vector_phase1(sh, p_vec, p_vec & 1, b_tid, b_n);
-        else
-          mx_vector_phase2(sh, p_vec & 1, b_tid, b_n);
       }
       if (STORE) {
         if (active && (x & 1) && p >= 1) {
