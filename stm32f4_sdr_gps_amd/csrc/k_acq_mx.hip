@@ -78,8 +78,8 @@ struct MxShared {
   v4i chips_a[16][2][32];                // A fragments: [kappa][h][PRN] = 32 FP4 chips 64 kappa + 32 h ..
   u32 chip_t[1032];                      // chip_t[c + 1]: bit p = chip c of PRN p of this cluster; [0] = chip -1 = 0
   u32 ones[2];                           // pop(D) per stream
-  u32 t_diff[512];                       // 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7 (mx_fill_tables)
-  u32 t_sign[256];                       // 8 bits -> FP4 codes of 2 bit - 1
+  u32 t_lut[768];                        // [0, 512): 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7;
+                                         // [512, 768): 8 bits -> FP4 codes of 2 bit - 1 (mx_fill_tables)
   u32 part[8][32][2][32];                // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
                                          // PRN: every lane folds its own results in with LDS atomics (no return value, no
                                          // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
@@ -195,10 +195,10 @@ __device__ void mx_fill_tables(MxShared &sh, int tid)
   for (int w = tid; w < 512; w += kMxThreads) {
     const u32 cur = (u32)w & 0xFFu, nxt = ((u32)w >> 1) & 0xFFu;
     const u32 plus = spread8(nxt & ~cur), minus = spread8(cur & ~nxt);   // e = +1 -> -2 (code C), e = -1 -> +2 (code 4)
-    sh.t_diff[w] = (plus << 2) | (plus << 3) | (minus << 2);
+    sh.t_lut[w] = (plus << 2) | (plus << 3) | (minus << 2);
   }
   for (int x = tid; x < 256; x += kMxThreads)
-    sh.t_sign[x] = (spread8((u32)x) << 1) | (spread8(~(u32)x & 0xFFu) * 0xAu);   // +1 -> code 2, -1 -> code A
+    sh.t_lut[512 + x] = (spread8((u32)x) << 1) | (spread8(~(u32)x & 0xFFu) * 0xAu);   // +1 -> code 2, -1 -> code A
 }
 
 // ---- per pass: the nibble vector, copy 0 (phase 1), then its eight shifted copies (phase 2) --------------------------------
@@ -226,7 +226,7 @@ __device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid, int n
         }
       } else {
         const u32 w = plane_bits9(sh.plane[iq][pass - 2], 8 * dw);
-        packed = sh.t_diff[w];
+        packed = sh.t_lut[w];
         if (dw == 127 && t0 >= 9) {
           // entries 1021 / 1022 (nibbles 5 / 6 of this dword, first period only): the skipped wrap word's coefficients
           // alpha_b = b on chip 1021 - q and beta_b = const - b on chip 1022 - q move by +1 / -1 per step; they are
@@ -252,11 +252,11 @@ __device__ void mx_vector_phase1(MxShared &sh, int pass, int buf, int tid, int n
         const u32 w = dw ? plane_bits9(pl, 8 * dw - 1) : (pl[0] << 1) & 0x1FFu;
         const u32 exist = dw == 127 ? 0x0FFFFFFFu : 0xFFFFFFFFu;   // q = 1023 does not exist
         if (t0 < 8) {
-          ca = sh.t_sign[w >> 1] & exist;
+          ca = sh.t_lut[512 + (w >> 1)] & exist;
         } else {
-          const u32 diff = sh.t_diff[w];                            // -2 (d - dm)
+          const u32 diff = sh.t_lut[w];                             // -2 (d - dm)
           ca = (diff ^ ((diff & 0x44444444u) << 1)) & exist;        // 2 (d - dm): the sign bit of the non-zero codes flips
-          cb = sh.t_sign[w & 0xFFu] & exist;                        // 2 dm - 1
+          cb = sh.t_lut[512 + (w & 0xFFu)] & exist;                     // 2 dm - 1
           if (dw == 0) {                                            // q = 0 has no tail word: A' grows by 2 d - 1, B' stays
             ca = (ca & ~0xFu) | ((w & 2u) ? 0x2u : 0xAu);
             cb &= ~0xFu;
@@ -295,6 +295,53 @@ __device__ __forceinline__ lds_cu32 *lds_opaque(const u32 *p)
 __device__ __forceinline__ v4i lds_frag(lds_cu32 *w, int dw)   // four dwords, dword aligned only
 {
   return v4i{(int)w[dw], (int)w[dw + 1], (int)w[dw + 2], (int)w[dw + 3]};
+}
+
+// ---- the vector of pass p_vec >= 2 in one phase ------------------------------------------------------------------------
+// Same values as mx_vector_phase1 + phase2 (which build the first two vectors, before the loop), without the copy-0 round
+// trip through LDS: thread (stream, j) looks up dwords j and j + 1 of copy 0 itself and writes dword j of the eight shifted
+// copies; thread (stream, term, dw) one dword of the extra K step's vectors.  512 threads, three dependent LDS accesses.
+// dword 127 of a vector, sample offsets 9..15: the wrap word's impulses at entries 1021 / 1022 (see mx_vector_phase1)
+__device__ __forceinline__ u32 mx_patch_wrap(u32 packed, u32 w9, bool patch)
+{
+  const u32 i5 = 1u + ((w9 >> 6) & 1u) - ((w9 >> 5) & 1u), i6 = 1u + ((w9 >> 7) & 1u) - ((w9 >> 6) & 1u);   // e + 1
+  const u32 c5 = (0xDA2u >> (4u * i5)) & 0xFu;   // -2 e - 1 = 1, -1, -3 -> codes 2, A, D
+  const u32 c6 = (0xA25u >> (4u * i6)) & 0xFu;   // -2 e + 1 = 3, 1, -1 -> codes 5, 2, A
+  const u32 patched = (packed & ~0x0FF00000u) | (c5 << 20) | (c6 << 24);
+  return patch ? patched : packed;
+}
+
+__device__ __forceinline__ void mx_vector_build(MxShared &sh, int p_vec, int tid)
+{
+  const int t0 = p_vec - 1, buf = p_vec & 1;
+  const bool late = t0 >= 9;
+  const int iq = tid >> 8, j = tid & 255, which = (tid >> 7) & 1, dwc = tid & 127;
+  const u32 *pl = sh.plane[iq][p_vec - 2];
+  // 17 plane bits from 8 j: the 9-bit windows of dwords j and j + 1
+  const u32 x = __builtin_amdgcn_alignbit(pl[(j >> 2) + 1], pl[j >> 2], 8u * (u32)(j & 3));
+  // bits 8 dwc - 1 .. 8 dwc + 7 (bit -1 = 0) for the extra K step: d[q] = bit k + 1, d[q - 1] = bit k of the dword's eight q
+  const int pos = dwc ? 8 * dwc - 1 : 0;
+  const u32 y = __builtin_amdgcn_alignbit(pl[(pos >> 5) + 1], pl[pos >> 5], (u32)(pos & 31));
+  const u32 cw = (dwc ? y : y << 1) & 0x1FFu;
+  u32 lo = sh.t_lut[x & 0x1FFu], hi = sh.t_lut[(x >> 8) & 0x1FFu];
+  // term 0: A' deltas: 2 d - 1 before the half switch, 2 (d - dm) after it; term 1: B' deltas 2 dm - 1 (after it only)
+  u32 v = sh.t_lut[which ? 512u + (cw & 0xFFu) : (late ? cw : 512u + (cw >> 1))];
+  if (late) {
+    lo = mx_patch_wrap(lo, x & 0x1FFu, j == 127);
+    hi = mx_patch_wrap(hi, (x >> 8) & 0x1FFu, j == 126);
+    if (which == 0)
+      v ^= (v & 0x44444444u) << 1;                         // -2 (d - dm) -> 2 (d - dm): the sign of the non-zero codes
+    if (dwc == 0)                                          // q = 0 has no tail word: A' grows by 2 d - 1, B' stays
+      v = (v & ~0xFu) | (which ? 0u : ((cw & 2u) ? 0x2u : 0xAu));
+  }
+  v &= dwc == 127 ? 0x0FFFFFFFu : 0xFFFFFFFFu;             // q = 1023 does not exist
+  if ((which && !late) || t0 == 8)
+    v = 0;
+  sh.corr[buf][iq][which][dwc] = v;
+  u32 *dst = &sh.e8[buf][iq][0][j];
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi, lo, 4u * (u32)c) : lo;
 }
 
 // One anti-diagonal of a pass (fragment Q0 + 2 S): request the fragments of the next one, then the MFMAs of this one.
@@ -823,9 +870,14 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms + ms_store) * block_bytes,
                      prm.if_format, step_word, tid, lane);
     __syncthreads();
+    // the first two vectors (from the popcounts of sample offset 0), by the two-phase builders
     mx_vector_phase1(sh, 0, 0, tid, kMxThreads);
     __syncthreads();
     mx_vector_phase2(sh, 0, tid, kMxThreads);
+    __syncthreads();
+    mx_vector_phase1(sh, 1, 1, tid, kMxThreads);
+    __syncthreads();
+    mx_vector_phase2(sh, 1, tid, kMxThreads);
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
@@ -838,22 +890,17 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     }
     SumRec pre[MULTI ? 16 : 1];
 
-    // half steps: role 0 runs pass p in half step 2 p and the epilogue of sample offset p - 1 in 2 p + 1; role 1 one
-    // half step later.  The vector of pass p + 1 is built in half steps 2 p (copy 0) and 2 p + 1 (its shifted copies),
-    // into the buffer whose last reader (role 1, pass p - 1) finished in half step 2 p - 1 -- by the four waves whose
-    // turn it is on the matrix pipe, after their pass: that phase is the shorter one, the epilogue waves are not held up.
+    // Steps of two halves: role 0 runs pass p, then the epilogue of sample offset p - 1; role 1 the epilogue of sample
+    // offset p - 2, then pass p -- one wave of a SIMD on the matrix pipe while the other has the vector ALU, with nothing
+    // but their own pace between the halves: ONE barrier per step, where all eight waves build the vector of pass p + 1
+    // into the buffer that both roles read during step p - 1.
 #pragma unroll 1
     for (int hs = 0; hs <= 2 * kPasses; hs++) {
-      __syncthreads();
-      const int p_vec = (hs >> 1) + 1;
-      // (all eight waves, at the start of the half step: with the lookup tables a phase is ~20 instructions per thread)
-      const bool build = p_vec < kPasses && !(ex & 8);
-      const int b_tid = tid, b_n = kMxThreads;
-      if (build) {
-        if ((hs & 1) == 0)
-          mx_vector_phase1(sh, p_vec, p_vec & 1, b_tid, b_n);
-        else
-          mx_vector_phase2(sh, p_vec & 1, b_tid, b_n);
+      if ((hs & 1) == 0) {
+        __syncthreads();
+        const int p_vec = (hs >> 1) + 1;
+        if (p_vec >= 2 && p_vec < kPasses && !(ex & 8))
+          mx_vector_build(sh, p_vec, tid);
       }
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
       const bool active = x >= 0 && x < 2 * kPasses;

@@ -17,6 +17,8 @@ def main():
     searches = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     n_ms = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
+        capi.LIB_PATH = os.environ["GPSX_LIB"]
     eng = capi.Engine(0)
     blocks = synth.cold_start_block(searches * n_ms, seed=11, amp_scale=0.25, two_bit=True)
     eng.set_if_format(capi.IF_2BIT_SM)
