@@ -80,7 +80,7 @@ struct MxShared {
   u32 ones[2];                           // pop(D) per stream
   u32 t_lut[768];                        // [0, 512): 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7;
                                          // [512, 768): 8 bits -> FP4 codes of 2 bit - 1 (mx_fill_tables)
-  u32 part[8][32][2][32];                // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
+  alignas(16) u32 part[8][32][2][32];              // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
                                          // PRN: every lane folds its own results in with LDS atomics (no return value, no
                                          // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
 };
@@ -846,8 +846,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     const u32 *src_t = mx_t + (size_t)set * 1032;
     for (int i = tid; i < 1032; i += kMxThreads)
       sh.chip_t[i] = src_t[i];
-    for (int i = tid; i < 8 * 32 * 2 * 32; i += kMxThreads)
-      (&sh.part[0][0][0][0])[i] = 0;
+    for (int i = tid; i < 8 * 32 * 2 * 32 / 4; i += kMxThreads)
+      reinterpret_cast<uint4 *>(&sh.part[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
     mx_fill_tables(sh, tid);
   }
 
@@ -939,23 +939,30 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   if (STORE)
     return;   // k_acq_vals_search sums the blocks and searches
   __syncthreads();
-  // the finished triplets: one per (PRN, bit shift)
-  if (tid < 256) {
-    const int p = tid >> 3, b = tid & 7;
+  // the finished triplets: one per (PRN, bit shift); threads 0..255 fold the 32 lane slots of the maxima and write
+  // (max, phase), threads 256..511 those of the sums and write (sum, avr)
+  {
+    const int which = tid >> 8, p = (tid >> 3) & 31, b = tid & 7;
     const int slot = 32 * set + p;
+    const u32 *row = sh.part[b][p][which];
+    u32 vals[32];
+#pragma unroll
+    for (int l = 0; l < 32; l++)
+      vals[l] = row[(l + tid) & 31];   // (rotated start: the threads of a wave spread over the banks)
+    u32 k = 0, t = 0;
+#pragma unroll
+    for (int l = 0; l < 32; l++) {
+      k = vals[l] > k ? vals[l] : k;
+      t += vals[l];
+    }
     if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn) {
-      u32 k = 0, t = 0;
-      for (int l = 0; l < 32; l++) {
-        const u32 kl = sh.part[b][p][0][(l + tid) & 31];   // (rotated start: the 256 threads spread over the banks)
-        k = kl > k ? kl : k;
-        t += sh.part[b][p][1][(l + tid) & 31];
+      uint2 *pk = reinterpret_cast<uint2 *>(&peaks[((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * 8 + b]);
+      if (which == 0) {
+        const u32 max_val = k >> 11;
+        pk[0] = make_uint2(max_val, max_val ? 2047u - (k & 2047u) : 0u);   // gpsx_peak_t: max_val, phase
+      } else {
+        pk[1] = make_uint2(t, t / (2u * kChips));                          //              sum, avr
       }
-      gpsx_peak_t pk;
-      pk.max_val = k >> 11;
-      pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
-      pk.sum = t;
-      pk.avr = t / (2u * kChips);
-      peaks[((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * 8 + b] = pk;
     }
   }
 }

@@ -22,6 +22,8 @@ constexpr int kMfmaPerIter = 32;    // 8 accumulators x 4
 template <int OP, int ILP, int kValuPerIter>
 __device__ __forceinline__ void valu_iter(float (&x)[8], float c)
 {
+  float2 cp = make_float2(c, c);
+  asm volatile("" : "+v"(cp));
 #pragma unroll
   for (int i = 0; i < kValuPerIter; i++) {
     float &r = x[i % ILP];
@@ -33,6 +35,19 @@ __device__ __forceinline__ void valu_iter(float (&x)[8], float c)
       asm volatile("v_sqrt_f32 %0, %0" : "+v"(r));
     else if (OP == 3)
       asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(r) : "v"(c));
+    else if (OP == 4) {   // packed f32: two values per lane and instruction (register pairs x[0:1], x[2:3], ..)
+      float2 &rp = reinterpret_cast<float2 *>(x)[(i % ILP) % 4];
+      asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(rp) : "v"(cp));
+    } else if (OP == 5) {
+      float2 &rp = reinterpret_cast<float2 *>(x)[(i % ILP) % 4];
+      asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(rp) : "v"(cp));
+    } else if (OP == 6) {
+      float2 &rp = reinterpret_cast<float2 *>(x)[(i % ILP) % 4];
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(rp) : "v"(cp));
+    } else if (OP == 7)
+      asm volatile("v_mul_f32_e64 %0, %0, |%1| clamp" : "+v"(r) : "v"(c));
+    else if (OP == 8)
+      asm volatile("v_max3_u32 %0, %0, %1, %1" : "+v"(r) : "v"(c));
   }
 }
 
@@ -150,5 +165,11 @@ int main()
   run<2, 8, 64>("v_sqrt_f32", n_wg, it);
   run<3, 1, 192>("v_lshl_or_b32 (VOP3)", n_wg, it);
   run<3, 8, 192>("v_lshl_or_b32 (VOP3)", n_wg, it);
+  run<4, 4, 192>("v_pk_mul_f32 (2 values/lane)", n_wg, it);
+  run<5, 4, 192>("v_pk_fma_f32 (2 values/lane)", n_wg, it);
+  run<6, 4, 192>("v_pk_add_f32 (2 values/lane)", n_wg, it);
+  run<6, 4, 96>("v_pk_add_f32 (2 values/lane)", n_wg, it);
+  run<7, 8, 192>("v_mul_f32 |x| clamp (VOP3)", n_wg, it);
+  run<8, 8, 192>("v_max3_u32", n_wg, it);
   return 0;
 }
