@@ -1,20 +1,20 @@
 set -x
-python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r02f_gputests.log
-cat gpurun_out/r02f_gputests.log
+python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r02g_gputests.log
+cat gpurun_out/r02g_gputests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py > gpurun_out/r02f_bench.json 2> gpurun_out/r02f_bench.err
-tail -c 300 gpurun_out/r02f_bench.err
-python bench.py --searches 64 --no-cpu-baseline --no-tracking > gpurun_out/r02f_bench_64.json 2>> gpurun_out/r02f_bench.err
-python bench.py --n-ms 10 --no-cpu-baseline --no-tracking --steps 5 > gpurun_out/r02f_bench_10ms.json 2>> gpurun_out/r02f_bench.err
-python bench.py --amp-scale 1.0 --no-cpu-baseline --no-tracking --steps 10 > gpurun_out/r02f_bench_strong.json 2>> gpurun_out/r02f_bench.err
-bash tools/profile_bench.sh r02f > gpurun_out/r02f_prof.log 2>&1
-BENCH_ARGS="--n-ms 10" bash tools/profile_bench.sh r02f_10ms > gpurun_out/r02f_prof10.log 2>&1
-bash tools/profile_track.sh r02f_track > gpurun_out/r02f_proft.log 2>&1
-python tools/bench_track_kernel.py > gpurun_out/r02f_trackkernel.json 2>&1
-python tools/bench_tracking.py > gpurun_out/r02f_tracking_latency.json 2>/dev/null
+python bench.py > gpurun_out/r02g_bench.json 2> gpurun_out/r02g_bench.err
+tail -c 300 gpurun_out/r02g_bench.err
+python bench.py --searches 64 --no-cpu-baseline --no-tracking > gpurun_out/r02g_bench_64.json 2>> gpurun_out/r02g_bench.err
+python bench.py --n-ms 10 --no-cpu-baseline --no-tracking --steps 5 > gpurun_out/r02g_bench_10ms.json 2>> gpurun_out/r02g_bench.err
+python bench.py --amp-scale 1.0 --no-cpu-baseline --no-tracking --steps 10 > gpurun_out/r02g_bench_strong.json 2>> gpurun_out/r02g_bench.err
+bash tools/profile_bench.sh r02g > gpurun_out/r02g_prof.log 2>&1
+BENCH_ARGS="--n-ms 10" bash tools/profile_bench.sh r02g_10ms > gpurun_out/r02g_prof10.log 2>&1
+bash tools/profile_track.sh r02g_track > gpurun_out/r02g_proft.log 2>&1
+python tools/bench_track_kernel.py > gpurun_out/r02g_trackkernel.json 2>&1
+python tools/bench_tracking.py > gpurun_out/r02g_tracking_latency.json 2>/dev/null
 python - <<'PY'
 import json
-for f in ("r02f_bench", "r02f_bench_64", "r02f_bench_10ms", "r02f_bench_strong"):
+for f in ("r02g_bench", "r02g_bench_64", "r02g_bench_10ms", "r02g_bench_strong"):
     d = json.loads(open(f"gpurun_out/{f}.json").read().strip().splitlines()[-1])
     print(f, d["value"], d["ms_per_step"], d["roofline"]["kernel"], round(d["roofline"]["frac"],3), d.get("pcie_inclusive", {}).get("value"), (d.get("tracking") or {}).get("value"))
 PY
