@@ -13,20 +13,26 @@ beside it as `pcie_inclusive`.
 
 N > 1 (torchrun, one rank per GPU; BASELINE.json configs[3]): the same grid with 10 ms NON-COHERENT integration
 (--n-ms defaults to 10 there, 1 at N = 1; hypotheses are counted per 1 ms block, SURVEY.md 8(d) "Config 4").  The job
-holds N x searches ten-block searches; the (search, 8-PRN group, Doppler) units are dealt round-robin to the ranks
-(84 units per search; per-GPU work is constant: weak scaling) and ONE all-reduce(MAX) of the packed (energy, phase) key
-table over RCCL merges the peaks -- the only collective on the path.  `single_search` adds configs[3]'s literal shape:
-ONE ten-block search sharded over the N ranks, latency per search.
+holds N x searches ten-block searches; the (search, 8-PRN group, Doppler) units -- 84 per search -- are dealt to the
+ranks in contiguous runs of equal length (per-GPU work is constant: weak scaling) and ONE all-reduce(MAX) of the packed
+(energy, phase) key table over RCCL merges the peaks -- the only collective on the path.  `single_search` adds
+configs[3]'s literal shape: ONE ten-block search sharded over the N ranks, latency per search; `per_gpu_unsharded` is
+one GPU's own share at the same configuration without sharding or collective (N x it is what the job's `value` is to be
+held against: the N = 1 default of this script is configs[2], a different workload).
 
-Prints one JSON line on rank 0.  `roofline`: the grid kernel is bound by integer VALU issue (operands live in LDS;
-HBM traffic is ~0 by construction), so `achieved` is the ISSUED integer lane-operations per second -- SQ_INSTS_VALU per
-launch from the committed rocprofv3 PMC summary of this kernel and launch shape (profiles/kernel_counters.json) x 64
-lanes / this run's launch time -- against the micro-benchmarked issue peak (profiles/r01_valu_rates_microbench.txt:
-one wave64 integer op per 4 cycles per SIMD = 64 lanes/clk/CU); `frac` is therefore a true fraction (<= 1).  The
-reference-equivalent operand stream (6138 B/hypothesis as the reference re-reads its operands) is kept
-as information only.  `cpu_baseline` times the reference's own C (oracle/_ref, built in place from the reference tree)
--- or the CPU oracle port when that build is absent -- on a bounded sample.  `tracking` is BASELINE.json's second
-metric, bounded to a few hundred steps per channel count (N = 1 only).
+Prints one JSON line on rank 0.  `roofline` prices the resource of the kernel that ran (gpsx_last_kernel):
+  k_acq_mx<0> (default, n_ms = 1): the correlations are an MX-FP4 GEMM on the matrix cores, operands in LDS, HBM traffic
+    ~0 by construction: bound "mfma", achieved = algorithmic FP4 flops per hypothesis x hypotheses / this run's launch time
+    (HIP events on the engine's stream) against the dense FP4 peak; `mfma_busy_frac` (SQ_VALU_MFMA_BUSY_CYCLES) and
+    `roofline_valu` (SQ_INSTS_VALU) come from the committed rocprofv3 PMC summary of this kernel and launch shape
+    (profiles/kernel_counters.json) scaled to this run's launch time;
+  k_acq_mx<1> (n_ms > 1): the running sums' round trip through HBM binds: bound "hbm", achieved = 6 B per hypothesis and
+    block x (n_ms - 1) / n_ms / launch time, `traffic` = what rocprofv3 counted;
+  k_acq_poly (GPSX_ACQ_ALGO=poly, round 1's kernel): integer VALU issue.
+The reference-equivalent operand stream (6138 B/hypothesis as the reference re-reads its operands) is
+kept as information only.  `cpu_baseline` times the reference's own C (oracle/_ref, built in place from the reference
+tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.  `tracking` is BASELINE.json's second
+metric, 1000 steps per channel count (N = 1 only).
 """
 import argparse
 import json
@@ -399,6 +405,33 @@ def main():
                   "note": f"one {n_ms}-block search (32 PRN x 21 Doppler x 16368 phases) sharded over {world} ranks, "
                           "84 units round-robin, all-reduce(MAX) of 672 keys, synchronised per search"}
 
+    # N > 1: this rank's own share of the work as ONE GPU would run it -- `searches` captures x n_ms blocks, unsharded, no
+    # collective -- so that the sharded, all-reduced job can be compared with N x a single GPU at the SAME configuration
+    # (the N = 1 default of this script is configs[2], n_ms = 1: not the series to divide by)
+    local_ref = None
+    if use_dist:
+        g_loc = eng.grid_desc(prns, n_search=args.searches, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=DOPP_MIN,
+                              dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046))
+        reps_l = max(2, min(args.steps, 10))
+        with torch.cuda.stream(stream):
+            loc_keys = torch.zeros((args.searches, N_PRN, N_DOPP), dtype=torch.int64, device=dev)
+            for i in range(reps_l + 1):
+                if i == 1:
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    tl = time.perf_counter()
+                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_loc), d_if.data_ptr(), args.searches * n_ms,
+                                               d_peaks.data_ptr(), loc_keys.data_ptr(), None, None, None)
+                assert rc == 0
+            torch.cuda.synchronize()
+            dtl = torch.tensor([time.perf_counter() - tl], dtype=torch.float64, device=dev)
+        dist.all_reduce(dtl, op=dist.ReduceOp.MAX)
+        local_ref = {"value": reps_l * args.searches * n_ms * HYP_PER_SEARCH / float(dtl.item()), "unit": "hypotheses/s",
+                     "ms_per_step": float(dtl.item()) / reps_l * 1e3,
+                     "note": f"per GPU: each rank sweeps {args.searches} captures x {n_ms} block(s) of its own, unsharded, no "
+                             "collective, all ranks at once (slowest rank); the job's `value` divided by n_gpus x this is "
+                             "what sharding + the all-reduce cost at this configuration"}
+
     if rank == 0:
         total_hyp = float(args.steps) * n_search * n_ms * HYP_PER_SEARCH
         value = total_hyp / elapsed_s
@@ -530,6 +563,8 @@ def main():
                                               "(`serial`: one context, synchronous gpsx_acq_grid)"}
         if single is not None:
             line["single_search"] = single
+        if local_ref is not None:
+            line["per_gpu_unsharded"] = local_ref
         if not args.no_tracking and world == 1:
             line["tracking"] = tracking_channels(capi.Engine, dev_index)
         if not args.no_cpu_baseline and world == 1:

@@ -36,5 +36,6 @@ def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode,
     assert line["config"]["blocks_per_search"] == n_ms
     assert line["config"]["hypotheses_per_step"] == 2 * searches * n_ms * 32 * 21 * 16368
     assert 0 < line["roofline"]["frac"] <= 1.0
+    assert line["per_gpu_unsharded"]["value"] > 1e9   # one GPU's share at the same configuration, no sharding
     if n_ms > 1:
         assert line["single_search"]["ms_per_search"] > 0
