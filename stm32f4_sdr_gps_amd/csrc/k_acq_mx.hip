@@ -378,6 +378,9 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
     mx_pass_step<S + 1>(wi, wq, ca, a, fi, fq, acc, scale_b);
 }
 
+// AHEAD = false (the walk form, whose prefetched sums leave no registers for a second set of fragments): every fragment is
+// requested where the compiler sees fit before its use
+template <bool AHEAD>
 __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][kMxTiles],
                                         u32 scale_b, v4i a_corr, bool with_corr)
 {
@@ -386,18 +389,36 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
   lds_cu32 *wq = lds_opaque(&sh.e8[buf][1][n & 7][4 * (q0_tile + h) + (n >> 3)]);
   const v4i *ca = &sh.chips_a[0][h][n];
   v4i a[16];
-  v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
-  a[0] = ca[0];
-  mx_pass_step<0>(wi, wq, ca, a, fi, fq, acc, scale_b);
+  if constexpr (AHEAD) {
+    v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
+    a[0] = ca[0];
+    mx_pass_step<0>(wi, wq, ca, a, fi, fq, acc, scale_b);
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16 + kMxTiles - 1; s++) {
+      if (s < 16)
+        a[s] = ca[s * 64];                                   // chips_a[s][h][n]
+      const v4i fi = lds_frag(wi, 8 * s), fq = lds_frag(wq, 8 * s);   // fragment Q0 + 2 s
+#pragma unroll
+      for (int j = 0; j < kMxTiles; j++) {
+        const int kappa = s - j;
+        if (kappa < 0 || kappa >= 16)
+          continue;
+        acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
+        acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fq), acc[1][j], 4, 4, 0, kScaleA, 0, scale_b);
+      }
+    }
+  }
   if (with_corr) {   // wave-uniform
     // the extra K step: only column 0 of each lane half of A is set (chip 1022 / chip 1021 of the PRN), so only the first
     // nibble of a lane's B window counts: the step's delta for (stream, term h, q)
+    // (dword q >> 3 = 4 (q0_tile + 2 j) + n / 8 of the term's vector: one address, constant offsets per tile and stream)
+    lds_cu32 *cw = lds_opaque(&sh.corr[buf][0][h][4 * q0_tile + (n >> 3)]);
 #pragma unroll
     for (int j = 0; j < kMxTiles; j++) {
       // (nibble q & 7 of dword q >> 3 moved to nibble 0; what is left above it meets zero columns of A)
-      const int q = 32 * (q0_tile + 2 * j) + n;
-      const v4i gi = v4i{(int)(sh.corr[buf][0][h][q >> 3] >> (4 * (n & 7))), 0, 0, 0};
-      const v4i gq = v4i{(int)(sh.corr[buf][1][h][q >> 3] >> (4 * (n & 7))), 0, 0, 0};
+      const v4i gi = v4i{(int)(cw[8 * j] >> (4 * (n & 7))), 0, 0, 0};
+      const v4i gq = v4i{(int)(cw[8 * j + 2 * 128] >> (4 * (n & 7))), 0, 0, 0};
       acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gi), acc[0][j], 4, 4, 0, kScaleA, 0,
                                                                    kScaleOne);
       acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gq), acc[1][j], 4, 4, 0, kScaleA, 0,
@@ -858,7 +879,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     kq[j] = (u32)(2047 - 2 * (32 * (q0_tile + 2 * j) + (lane & 31)));
-    asm volatile("" : "+v"(kq[j]));
+    if constexpr (!MULTI && !STORE)
+      asm volatile("" : "+v"(kq[j]));   // (kept in registers, not rebuilt per group; the other forms do not use them)
   }
   u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * 3) : nullptr;   // SumRec = 3 dwords
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
@@ -913,7 +935,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         if (!(ex & 2)) {
           if (ex & 16)
             __builtin_amdgcn_s_setprio(3);
-          mx_pass(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && p != 9);
+          mx_pass<!MULTI>(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && p != 9);
           if (ex & 16)
             __builtin_amdgcn_s_setprio(0);
         }
