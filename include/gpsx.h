@@ -62,6 +62,19 @@ typedef struct {
 /* device: HIP device ordinal.  stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let
  * the context create its own. */
 int         gpsx_create(gpsx_ctx **ctx, int device, void *stream);
+/* Receiver constants (the reference fixes them at compile time, PM/config.h:23-28).  sample_rate_hz is structural: the
+ * 2046-byte millisecond and the 16368-phase grid are compiled into the kernels, any value but 16368000 is refused with
+ * GPSX_EINVAL.  if_hz -- the centre of the acquisition grid's Doppler axis and the frequency a tracking channel's
+ * if_freq_offset_hz is relative to -- is a run-time value of the context (front ends with another IF plan); entry points
+ * that take absolute frequencies (gpsx_acq_jobs, gpsx_wipeoff) and the reference-named calls of gpsx_compat.h, whose
+ * IF_FREQ_HZ is the reference's #define, do not look at it. */
+typedef struct {
+  uint32_t sample_rate_hz;   /* 16368000                                                                   */
+  int32_t  if_hz;            /* GPSX_IF_HZ by default; 0 < if_hz < sample_rate_hz / 2                      */
+} gpsx_config_t;
+void        gpsx_config_default(gpsx_config_t *cfg);
+int         gpsx_set_config(gpsx_ctx *ctx, const gpsx_config_t *cfg);
+int         gpsx_get_config(const gpsx_ctx *ctx, gpsx_config_t *cfg);
 void        gpsx_destroy(gpsx_ctx *ctx);
 int         gpsx_synchronize(gpsx_ctx *ctx);
 const char *gpsx_last_error(const gpsx_ctx *ctx);   /* text of the last failure on this context */

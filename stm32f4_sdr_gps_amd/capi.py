@@ -38,6 +38,10 @@ class AcqGrid(C.Structure):
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32)]
 
 
+class Config(C.Structure):   # gpsx_config_t
+    _fields_ = [("sample_rate_hz", C.c_uint32), ("if_hz", C.c_int32)]
+
+
 class GpsxError(RuntimeError):
     pass
 
@@ -85,6 +89,10 @@ def load_library() -> C.CDLL:
     lib.gpsx_corr_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
     lib.gpsx_set_if_format.argtypes = [C.c_void_p, C.c_int]
+    lib.gpsx_config_default.argtypes = [C.POINTER(Config)]
+    lib.gpsx_config_default.restype = None
+    lib.gpsx_set_config.argtypes = [C.c_void_p, C.POINTER(Config)]
+    lib.gpsx_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
     lib.gpsx_if_unpack2.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gpsx_mag8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_corr_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]
@@ -220,6 +228,16 @@ class Engine:
         ms = C.c_float()
         self._chk(self.lib.gpsx_event_elapsed_ms(self.h, ev0, ev1, C.byref(ms)), "gpsx_event_elapsed_ms")
         return ms.value
+
+    # -- receiver constants (gpsx_config_t) ---------------------------------------------------------------------
+    def get_config(self) -> Config:
+        cfg = Config()
+        self._chk(self.lib.gpsx_get_config(self.h, C.byref(cfg)), "gpsx_get_config")
+        return cfg
+
+    def set_config(self, if_hz: int = IF_HZ, sample_rate_hz: int = 16368000):
+        cfg = Config(sample_rate_hz, if_hz)
+        self._chk(self.lib.gpsx_set_config(self.h, C.byref(cfg)), "gpsx_set_config")
 
     # -- IF sample format (N3 ingest) ---------------------------------------------------------------------------
     def set_if_format(self, fmt: int):

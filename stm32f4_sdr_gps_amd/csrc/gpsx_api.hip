@@ -88,7 +88,7 @@ int check_grid(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, int n_blocks)
   const long long n_keys = (long long)g->n_search * g->n_prn * g->n_dopp;
   if (n_keys * 8 > 0x7FFFFFFFLL)
     return fail(ctx, GPSX_EINVAL, "n_search * n_prn * n_dopp too large for one call (split the searches)");
-  const long f_lo = (long)GPSX_IF_HZ + g->dopp_min_hz;
+  const long f_lo = (long)ctx->if_hz + g->dopp_min_hz;
   const long f_hi = f_lo + (long)(g->n_dopp - 1) * g->dopp_step_hz;
   if (f_lo <= 0 || f_hi <= 0 || f_lo >= 16368000 || f_hi >= 16368000)
     return fail(ctx, GPSX_EINVAL, "carrier frequency outside (0, fs)");
@@ -241,6 +241,41 @@ int gpsx_set_if_format(gpsx_ctx *ctx, int if_format)
   if (if_format != GPSX_IF_1BIT && if_format != GPSX_IF_2BIT_SM)
     return fail(ctx, GPSX_EINVAL, "unknown IF sample format");
   ctx->if_format = if_format;
+  return GPSX_OK;
+}
+
+void gpsx_config_default(gpsx_config_t *cfg)
+{
+  if (cfg) {
+    cfg->sample_rate_hz = 16368000u;
+    cfg->if_hz = GPSX_IF_HZ;
+  }
+}
+
+int gpsx_set_config(gpsx_ctx *ctx, const gpsx_config_t *cfg)
+{
+  if (!ctx || !cfg)
+    return GPSX_EINVAL;
+  if (cfg->sample_rate_hz != 16368000u)
+    return fail(ctx, GPSX_EINVAL, "sample_rate_hz: this build carries the 16.368 MHz geometry only (2046 bytes per ms)");
+  if (cfg->if_hz <= 0 || cfg->if_hz >= 16368000 / 2)
+    return fail(ctx, GPSX_EINVAL, "if_hz out of range (0, sample_rate_hz / 2)");
+  if (cfg->if_hz != ctx->if_hz) {
+    if (use_device(ctx) == GPSX_OK) {
+      (void)hipStreamSynchronize(ctx->stream);
+      track_graph_release(ctx);   // the captured tracking steps carry the old value as a kernel argument
+    }
+    ctx->if_hz = cfg->if_hz;
+  }
+  return GPSX_OK;
+}
+
+int gpsx_get_config(const gpsx_ctx *ctx, gpsx_config_t *cfg)
+{
+  if (!ctx || !cfg)
+    return GPSX_EINVAL;
+  cfg->sample_rate_hz = 16368000u;
+  cfg->if_hz = ctx->if_hz;
   return GPSX_OK;
 }
 
@@ -440,6 +475,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.win_start = g->win_start;
   prm.win_stop = g->win_stop;
   prm.if_format = ctx->if_format;
+  prm.if_hz = ctx->if_hz;
   {
     static const char *ex = std::getenv("GPSX_MX_EXPERIMENT");
     prm.experiment = ex ? std::atoi(ex) : 0;
@@ -633,6 +669,7 @@ int gpsx_acq_jobs(gpsx_ctx *ctx, const gpsx_acq_job_t *jobs, int n_jobs, const u
   prm.n_ms = n_ms;
   prm.n_bits = 1;
   prm.if_format = ctx->if_format;
+  prm.if_hz = ctx->if_hz;
   prm.jobs = d_jobs;
   prm.peaks = d_peaks;
   prm.energy = d_energy;
@@ -654,8 +691,8 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   if (int rc = use_device(ctx)) return rc;
   if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
-  launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, d_st, n_ch, ctx->d_chips_all,
-                   ctx->d_bits_all, d_iq_out);
+  launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, ctx->if_hz, d_st, n_ch,
+                   ctx->d_chips_all, ctx->d_bits_all, d_iq_out);
   LAUNCHCHK(ctx, "k_track_epl");
   return GPSX_OK;
 }
@@ -732,7 +769,8 @@ gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch_asked, size_t 
     ok = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
     if (ok) {
       ok = hipMemcpyAsync(t.d_buf, t.h_in, t.in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
-      launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all, d_iq);
+      launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, ctx->if_hz, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all,
+                       d_iq);
       ok = ok && hipGetLastError() == hipSuccess &&
            hipMemcpyAsync(t.h_out, d_st, t.out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
       ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;
@@ -807,7 +845,8 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
       const int n = std::min(per, n_ch - first);
       hipStream_t s = (c & 1) ? ctx->aux_stream : ctx->stream;
       HIPCHK(ctx, hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, s));
-      launch_track_epl(s, d_if, ctx->if_format, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all, d_iq + (size_t)first * 6);
+      launch_track_epl(s, d_if, ctx->if_format, ctx->if_hz, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all,
+                       d_iq + (size_t)first * 6);
       LAUNCHCHK(ctx, "k_track_epl");
       HIPCHK(ctx, hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, s));
       HIPCHK(ctx, hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost, s));
@@ -835,7 +874,7 @@ int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *st
   uint8_t *d_steps = arena_take<uint8_t>(ctx, n_ch);
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_steps, steps, n_ch, hipMemcpyHostToDevice, ctx->stream));
-  launch_rewind(ctx->stream, d_st, n_ch, d_steps);
+  launch_rewind(ctx->stream, ctx->if_hz, d_st, n_ch, d_steps);
   LAUNCHCHK(ctx, "k_rewind");
   HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

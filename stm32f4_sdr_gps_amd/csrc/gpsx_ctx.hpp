@@ -43,6 +43,7 @@ struct gpsx_ctx {
   uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
   uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
   int if_format = GPSX_IF_1BIT;
+  int if_hz = GPSX_IF_HZ;             // gpsx_config_t.if_hz
   int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: matrix cores when the launch fills the chip, else
                                            // poly) | poly | dot8 | sad, for A/B measurements
   bool algo_forced = false;                // $GPSX_ACQ_ALGO was given: no size heuristics

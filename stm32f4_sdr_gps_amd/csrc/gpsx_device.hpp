@@ -19,7 +19,6 @@ constexpr int kBytes = 2046;          // packed bytes per code period
 constexpr int kWords16 = 1023;        // 16-bit words per code period (one chip each at zero shift)
 constexpr int kWords32 = 511;         // whole 32-sample words the carrier NCO mixes (the last 16 samples are not)
 constexpr int kHalf = kSamples / 2;   // 8184: popcount centre
-constexpr int kIfHz = 4092000;
 
 typedef unsigned int u32;
 typedef unsigned long long u64;

@@ -44,6 +44,7 @@ struct AcqParams {
   int32_t unit_lo, unit_hi;   // this shard's run of sharding units
   int32_t win_start, win_stop;
   int32_t if_format;        // GPSX_IF_1BIT / GPSX_IF_2BIT_SM
+  int32_t if_hz;            // gpsx_config_t.if_hz: centre of the Doppler axis
   int32_t experiment;       // $GPSX_MX_EXPERIMENT: ablations of k_acq_mx for timing (results are then wrong); 0 in production
   // explicit job list (job mode)
   const AcqJobRec *jobs;
@@ -117,10 +118,10 @@ void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q
 void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int first_offset, gpsx_peak_t *d_peak);
 
 // K2+K3+K5 tracking correlators, one workgroup per channel
-void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
+void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
                       const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq);
 // N3: 2-bit sign/magnitude samples -> two 1-bit planes
 void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag);
-void launch_rewind(hipStream_t s, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps);
+void launch_rewind(hipStream_t s, int if_hz, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps);
 
 }  // namespace gpsx

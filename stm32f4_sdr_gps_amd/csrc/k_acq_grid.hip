@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kThreads, MULTI ? 2 : ((ALGO == kAlgoDot8 || GPW > 
     if (n_groups_here <= 0)
       return;   // odd number of groups: the last super group has one
     // int arithmetic, then one conversion: PM/GPS/acquisition.c:285-289
-    freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);
+    freq_hz = (float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);
     win_start = prm.win_start;
     win_stop = prm.win_stop;
   }

@@ -855,7 +855,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   group_mask = (u32)__builtin_amdgcn_readfirstlane((int)group_mask);
   if (group_mask == 0)
     return;
-  const float freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
+  const float freq_hz = (float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
   const u32 step_word = nco_step_per_word(freq_hz);
 
   // tables of the cluster

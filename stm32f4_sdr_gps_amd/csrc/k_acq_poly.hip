@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads, MODE == kPolyMulti ? 2 : 3) void k_acq_po
   const int slot0 = group * G;
   const int n_valid = prm.n_prn - slot0 < G ? prm.n_prn - slot0 : G;
   const int t0_first = seg * SEG;
-  const float freq_hz = (float)(kIfHz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
+  const float freq_hz = (float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
   const u32 step_word = nco_step_per_word(freq_hz);
   const u32 *cw_group = cw8 + (size_t)group * (kCodeWords / 2) * G;
   const u32 *chipbits_g = chipbits + (size_t)slot0 * 32;

@@ -194,7 +194,7 @@ void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int firs
 //   (wraps to 2045), late = prompt + 1 (wraps to 0)                                   PM/GPS/tracking.c:115-130
 //   carrier NCO continues from if_freq_accum at (float)IF + if_freq_offset_hz and is stored back  gps_misc.c:244-274
 // Wave w < 3 computes offset E/P/L; the IF block is read once per channel with coalesced 16-bit loads.
-__global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ if_block, int if_format,
+__global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ if_block, int if_format, int if_hz,
                                                    gpsx_trk_state_t *__restrict__ st, int n_ch,
                                                    const uint8_t *__restrict__ chips_all, int16_t *__restrict__ iq_out)
 {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
   const int fine = (int)(int16_t)(int)state.code_phase_fine;
   const u32 b = (u32)fine & 7u;
   const u32 low = (1u << b) - 1u, high = (0xFFFFu << b) & 0xFFFFu;
-  const float freq_hz = (float)kIfHz + state.if_freq_offset_hz;
+  const float freq_hz = (float)if_hz + state.if_freq_offset_hz;
   const u32 step = nco_step_per_word(freq_hz);
 
   for (int i = tid; i < 1024; i += 256) {
@@ -291,7 +291,7 @@ __device__ __forceinline__ uint4 lds_read_pairs(const uint2 *p)   // p[0], p[1]:
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restrict__ if_block, int if_format,
+__global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restrict__ if_block, int if_format, int if_hz,
                                                         gpsx_trk_state_t *__restrict__ st, int n_ch,
                                                         const u32 *__restrict__ chipbits_all,
                                                         int16_t *__restrict__ iq_out)
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
   const int fine = (int)(int16_t)(int)state.code_phase_fine;
   const u32 b = (u32)fine & 7u;
   const u32 low = (1u << b) - 1u, high = (0xFFFFu << b) & 0xFFFFu;
-  const float freq_hz = (float)kIfHz + state.if_freq_offset_hz;
+  const float freq_hz = (float)if_hz + state.if_freq_offset_hz;
   const u32 step = nco_step_per_word(freq_hz);
 
   // K3: wipe-off, word w sees NCO phase accum + w * step
@@ -439,15 +439,15 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
 
 constexpr int kTrackWaveFormFrom = 2048;
 
-void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, gpsx_trk_state_t *d_st, int n_ch,
+void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
                       const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq)
 {
   if (n_ch <= 0)
     return;
   if (n_ch < kTrackWaveFormFrom)
-    hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch, d_chips, d_iq);
+    hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch, d_chips, d_iq);
   else
-    hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, d_st, n_ch,
+    hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch,
                        d_chipbits, d_iq);
 }
 
@@ -477,21 +477,21 @@ void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d
 }
 
 // gps_rewind_if_phase: accum += (uint32)((uint64)step_per_sample * 16368 * steps)
-__global__ void k_rewind(gpsx_trk_state_t *__restrict__ st, int n_ch, const uint8_t *__restrict__ steps)
+__global__ void k_rewind(int if_hz, gpsx_trk_state_t *__restrict__ st, int n_ch, const uint8_t *__restrict__ steps)
 {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= n_ch)
     return;
-  const u32 step = nco_step_per_sample((float)kIfHz + st[ch].if_freq_offset_hz);
+  const u32 step = nco_step_per_sample((float)if_hz + st[ch].if_freq_offset_hz);
   const u64 adv = (u64)step * (u64)kSamples * (u64)steps[ch];
   st[ch].if_freq_accum += (u32)adv;
 }
 
-void launch_rewind(hipStream_t s, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps)
+void launch_rewind(hipStream_t s, int if_hz, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps)
 {
   if (n_ch <= 0)
     return;
-  hipLaunchKernelGGL(k_rewind, dim3((n_ch + 63) / 64), dim3(64), 0, s, d_st, n_ch, d_steps);
+  hipLaunchKernelGGL(k_rewind, dim3((n_ch + 63) / 64), dim3(64), 0, s, if_hz, d_st, n_ch, d_steps);
 }
 
 }  // namespace gpsx

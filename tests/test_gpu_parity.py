@@ -954,3 +954,50 @@ def test_both_multi_block_forms_match_the_oracle(oracle, stream, mode, algo, mon
             assert np.array_equal(halves[0][0]["max_val"] + halves[1][0]["max_val"], peaks["max_val"])
     finally:
         e.close()
+
+
+def test_config_if_hz_moves_the_doppler_axis_and_the_tracking_reference(oracle, stream):
+    """gpsx_config_t: the IF is a run-time value of the context (the reference compiles it in, PM/config.h:23).  A context
+    whose IF is 1500 Hz higher, asked for Doppler bins / frequency offsets 1500 Hz lower, generates the same carriers: same
+    triplets and accumulators as the oracle at the reference's IF.  The sample rate is structural and refused."""
+    from stm32f4_sdr_gps_amd import capi
+    e = capi.Engine(0)
+    try:
+        cfg = e.get_config()
+        assert (cfg.sample_rate_hz, cfg.if_hz) == (16368000, capi.IF_HZ)
+        with pytest.raises(capi.GpsxError):
+            e.set_config(sample_rate_hz=16367600)
+        with pytest.raises(capi.GpsxError):
+            e.set_config(if_hz=0)
+        e.set_config(if_hz=capi.IF_HZ + 1500)
+        assert e.get_config().if_hz == capi.IF_HZ + 1500
+        prns = np.array([1, 7, 19, 32], np.uint8)
+        peaks, keys = e.acq_grid(stream[0], prns, dopp_min_hz=-2000 - 1500, dopp_step_hz=500, n_dopp=5)
+        want = oracle.acq_grid(stream[0], 1, prns, -2000, 500, 5, 8, n_threads=4)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(peaks[0][f], want[f]), f
+        # tracking: one small (per-channel kernel, captured graph) and one large (wave kernel) batch
+        for n in (8, 2304):
+            rng = np.random.default_rng(n)
+            st = np.zeros(n, capi.TRK_DTYPE)
+            st["prn"] = (np.arange(n) % 32) + 1
+            st["code_phase_fine"] = rng.uniform(0, 16368, n).astype(np.float32)
+            off = rng.integers(-5000, 5000, n).astype(np.float32)
+            st["if_freq_offset_hz"] = off - 1500.0
+            st["if_freq_accum"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+            acc0 = st["if_freq_accum"].copy()
+            iq = e.track_epl(stream[1], st)
+            for c in range(0, n, max(1, n // 48)):
+                w, acc = oracle.track_epl(stream[1], oracle.ca_code(int(st["prn"][c])), float(st["code_phase_fine"][c]),
+                                          float(off[c]), int(acc0[c]))
+                assert np.array_equal(iq[c], w) and int(st["if_freq_accum"][c]) == acc, (n, c)
+        # back to the default: the captured tracking graphs of the other IF are gone, results follow
+        e.set_config()
+        st = np.zeros(8, capi.TRK_DTYPE)
+        st["prn"] = np.arange(1, 9)
+        st["if_freq_offset_hz"] = 250.0
+        iq = e.track_epl(stream[1], st)
+        w, _ = oracle.track_epl(stream[1], oracle.ca_code(3), 0.0, 250.0, 0)
+        assert np.array_equal(iq[2], w)
+    finally:
+        e.close()
