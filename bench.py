@@ -61,8 +61,9 @@ LANE_OPS_PER_HYP_MIN_MODEL = 146
 # chips: 2 * 32 * 1024 * 1024 flops each -> per hypothesis (32 PRN x 16368 phases per pair) 17 * 2 * 2 * 1024 * 1024 / 16368
 MFMA_FLOPS_PER_HYP = 17 * 2 * 2.0 * 32 * 1024 * 1024 / (32 * 16368)      # = 4356 algorithmic FP4 flops per hypothesis
 MFMA_FP4_PEAK_TFLOPS = 10000.0                       # MI355X_MICROARCH.md: ~10 PF dense MX-FP4 (9.1 PF micro-benchmarked)
-LANE_OPS_PER_HYP_MIN_MODEL_MX = 16                   # what is left to the vector ALU per hypothesis: clip x2, square x2, add,
-                                                     # sqrt (2 slots), fix-up 6, truncate, key, max, sum
+LANE_OPS_PER_HYP_MIN_MODEL_MX = 10.25                # the kernel's own formulation, per hypothesis: 2 clip-squares, add, fma,
+                                                     # root, rounding add, key, 1/2 max3, 1/2 add3 = 8 + the
+                                                     # MFMAs' own issue slots, 17 x 136 x 8 per 8192 lane-hypotheses = 2.25
 
 
 def _ref_prn_slice(ref, blk, prn_list, deadline):
@@ -488,6 +489,12 @@ def main():
                     "mfma_busy_frac": (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (launch_ms * 1e-3 * clk_khz * 1e3))
                                       if counters and counters.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                     "counter_source": counters.get("source") if counters else None}
+            if counters and counters.get("gpu_cycles_per_launch") and counters.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                # the profiled launch: shader cycles actually spent (the clock follows the power budget) -- the share of
+                # them the matrix pipe was busy, and the clock they imply; `frac` above is against the 2.4 GHz peak
+                roof["profiled_clock_ghz"] = counters["gpu_cycles_per_launch"] / counters["kernel_trace_avg_ns"]
+                roof["mfma_busy_frac_of_profiled_cycles"] = (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 /
+                                                             counters["gpu_cycles_per_launch"])
         elif valu is not None:
             roof = dict(valu)
             roof["bound"] = "valu-int-issue"

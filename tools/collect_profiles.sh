@@ -8,4 +8,18 @@ for p in "bench:bench_1gpu" "bench_64:bench_1gpu_64_captures" "bench_10ms:bench_
   tail -1 gpurun_out/${T}_${p%%:*}.json > profiles/${T}_${p##*:}.json
 done
 cp gpurun_out/${T}_tracking_latency.json profiles/${T}_tracking_latency.json
+if [ -f gpurun_out/${T}_sweep.txt ]; then
+python - "$T" <<'PY'
+import json, sys
+rows = []
+for l in open(f"gpurun_out/{sys.argv[1]}_sweep.txt"):
+    if l.startswith("{"):
+        d = json.loads(l)
+        rows.append({"captures": d["searches"], "blocks_per_search": d["n_ms"], "kernel": d["kernel"],
+                     "ms_per_launch": d["ms"], "hyp_per_s": d["hyp_per_s"]})
+json.dump({"command": "tools/gpu_sweep.sh (tools/bench_grid_kernel.py, $GPSX_ACQ_ALGO=mx|poly; 32 PRN x 21 Doppler x 16368 phases "
+                      "per capture, captures resident in HBM)", "tag": sys.argv[1], "rows": rows},
+          open("profiles/r02_launch_size_sweep.json", "w"), indent=1)
+PY
+fi
 ls profiles | grep "^$T"

@@ -84,6 +84,11 @@ def main(tag="r02", searches=256, n_ms=1, pattern=None):
                 entry[k] = c[k]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             summary["derived"]["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+        if "GRBM_GUI_ACTIVE" in c:
+            # the clock the chip actually ran this kernel at (it follows the power budget): shader cycles / kernel time
+            summary["derived"]["effective_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / summary["kernel_trace_avg_ns"]
+            entry["gpu_cycles_per_launch"] = c["GRBM_GUI_ACTIVE"] / 8.0
+            entry["kernel_trace_avg_ns"] = summary["kernel_trace_avg_ns"]
     with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     kc_path = os.path.join(dst, "kernel_counters.json")
