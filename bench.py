@@ -26,8 +26,9 @@ Prints one JSON line on rank 0.  `roofline` prices the resource of the kernel th
     (HIP events on the engine's stream) against the dense FP4 peak; `mfma_busy_frac` (SQ_VALU_MFMA_BUSY_CYCLES) and
     `roofline_valu` (SQ_INSTS_VALU) come from the committed rocprofv3 PMC summary of this kernel and launch shape
     (profiles/kernel_counters.json) scaled to this run's launch time;
-  k_acq_mx<1> (n_ms > 1): the running sums' round trip through HBM binds: bound "hbm", achieved = 6 B per hypothesis and
-    block x (n_ms - 1) / n_ms / launch time, `traffic` = what rocprofv3 counted;
+  k_acq_mx<3> (n_ms > 1): the running sums' round trip through HBM: bound "hbm", achieved = 4 B per hypothesis and block
+    (16-bit records) x (n_ms - 1) / n_ms / launch time, `traffic` = what rocprofv3 counted; the matrix-pipe fraction of
+    the same launch is reported beside it (`roofline_mfma`);
   k_acq_poly (GPSX_ACQ_ALGO=poly, round 1's kernel): integer VALU issue.
 The reference-equivalent operand stream (6138 B/hypothesis as the reference re-reads its operands) is
 kept as information only.  `cpu_baseline` times the reference's own C (oracle/_ref, built in place from the reference
@@ -468,16 +469,17 @@ def main():
         mfma_block = None
         if is_mx and n_ms > 1:
             # Non-coherent integration: the running sums of the 16368 x 32 x 21 hypotheses of a search do not fit on chip,
-            # they make a round trip through HBM per block -- 3 B read + 3 B written per hypothesis and block (a sum stays
-            # below 2^21: four of them are packed into three dwords), except the first block (nothing to read) and the
-            # last (nothing to write): that stream is what binds this form
-            alg_bytes = hyp_per_launch * 6.0 * (n_ms - 1) / n_ms
+            # they make a round trip through HBM per block -- 2 B read + 2 B written per hypothesis and block as 16-bit
+            # records (k_acq_mx<3>; the 24-bit records of k_acq_mx<1>, the form that redoes a cluster whose sums outgrew
+            # them, are 3 + 3 B), except the first block (nothing to read) and the last (nothing to write)
+            rec_bytes = 4.0 if kernel.endswith("<3>") else 6.0
+            alg_bytes = hyp_per_launch * rec_bytes * (n_ms - 1) / n_ms
             ach = alg_bytes / (launch_ms * 1e-3) / 1e9
             flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
             mfma_block = {"bound": "mfma", "achieved": flops / (launch_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
                           "unit": "TFLOP/s", "frac": flops / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS}
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "bytes_per_hyp_block": 6.0 * (n_ms - 1) / n_ms,
+                    "bytes_per_hyp_block": rec_bytes * (n_ms - 1) / n_ms,
                     "counter_source": counters.get("source") if counters else None}
         elif is_mx:
             # the GEMM on the matrix cores is the dominant operation of this kernel: algorithmic FP4 flops / launch time
@@ -517,9 +519,9 @@ def main():
             "kernel": "gpsx::" + kernel,
             "kernel_ms": launch_ms,
             "note": ("the captures stay in LDS and the correlations run as an MX-FP4 Toeplitz GEMM on the matrix cores; what binds "
-                     "the multi-block form is the running sums' round trip through HBM (6 B per hypothesis and block, first "
-                     "and last block 3 B): achieved = those algorithmic bytes / this run's launch time against 8 TB/s; "
-                     "`traffic` is what rocprofv3 counted" if (is_mx and n_ms > 1) else
+                     "the multi-block form most is the running sums' round trip through HBM (16-bit records: 4 B per hypothesis "
+                     "and block, first and last block 2 B): achieved = those algorithmic bytes / this run's launch time against "
+                     "8 TB/s; `traffic` is what rocprofv3 counted; the matrix pipe's share of the same launch is roofline_mfma" if (is_mx and n_ms > 1) else
                      "operands stay in LDS, HBM traffic is ~0 by construction.  The correlations run as an MX-FP4 Toeplitz GEMM "
                      "on the matrix cores: achieved = algorithmic flops (17 passes x 2 streams x 2*32*1024*1024 per (search, "
                      "Doppler) pair) / this run's launch time, peak = dense FP4; the vector ALU (clip, square, root, search) "

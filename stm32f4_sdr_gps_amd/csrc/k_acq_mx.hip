@@ -533,47 +533,70 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
   }
 }
 
-// MULTI: the running sums between blocks.  A sum stays below 128 x 11573 < 2^21 (kMaxMs blocks), so four of them travel
-// as three dwords: the scratch stream is what binds this form (bench.py `roofline` of the multi-block run), a quarter less
-// of it is worth the six shifts.
-struct SumRec {
-  u32 w[3];
+// MULTI: the running sums between blocks: the scratch stream is what binds this form (bench.py `roofline` of the
+// multi-block run), so its records are as small as exactness allows.
+//   S16 = true  (kMxWalk16, the form that runs first): four 16-bit sums in two dwords.  n_ms x 11573 fits 16 bits up to
+//               5 blocks; beyond that only hypotheses with magnitudes above 6553 in every block -- clean carriers, not
+//               signals in noise -- can overflow: every stored sum is OR-ed into a per-lane witness, a workgroup that saw
+//               bit 16 or above raises its flag, and the launcher's second kernel (kMxWalk, below), whose workgroups
+//               leave at once where no flag is up, does such a cluster again with
+//   S16 = false (kMxWalk): four sums of 24 bits (128 x 11573 < 2^21) in three dwords.
+template <bool S16>
+struct SumRecT {
+  u32 w[S16 ? 2 : 3];
 };
-__device__ __forceinline__ void sums_unpack(const SumRec &r, u32 (&s)[4])
+template <bool S16>
+__device__ __forceinline__ void sums_unpack(const SumRecT<S16> &r, u32 (&s)[4])
 {
-  s[0] = r.w[0] & 0xFFFFFFu;
-  s[1] = __builtin_amdgcn_alignbit(r.w[1], r.w[0], 24u) & 0xFFFFFFu;
-  s[2] = __builtin_amdgcn_alignbit(r.w[2], r.w[1], 16u) & 0xFFFFFFu;
-  s[3] = r.w[2] >> 8;
+  if constexpr (S16) {
+    s[0] = r.w[0] & 0xFFFFu;
+    s[1] = r.w[0] >> 16;
+    s[2] = r.w[1] & 0xFFFFu;
+    s[3] = r.w[1] >> 16;
+  } else {
+    s[0] = r.w[0] & 0xFFFFFFu;
+    s[1] = __builtin_amdgcn_alignbit(r.w[1], r.w[0], 24u) & 0xFFFFFFu;
+    s[2] = __builtin_amdgcn_alignbit(r.w[2], r.w[1], 16u) & 0xFFFFFFu;
+    s[3] = r.w[2] >> 8;
+  }
 }
-__device__ __forceinline__ SumRec sums_pack(const u32 (&s)[4])
+template <bool S16>
+__device__ __forceinline__ SumRecT<S16> sums_pack(const u32 (&s)[4])
 {
-  SumRec r;
-  r.w[0] = s[0] | (s[1] << 24);
-  r.w[1] = (s[1] >> 8) | (s[2] << 16);
-  r.w[2] = (s[2] >> 16) | (s[3] << 8);
+  SumRecT<S16> r;
+  if constexpr (S16) {
+    // (the low halves of two sums; a sum that does not fit has raised the workgroup's flag, what is stored is not used)
+    r.w[0] = __builtin_amdgcn_perm(s[1], s[0], 0x05040100u);
+    r.w[1] = __builtin_amdgcn_perm(s[3], s[2], 0x05040100u);
+  } else {
+    r.w[0] = s[0] | (s[1] << 24);
+    r.w[1] = (s[1] >> 8) | (s[2] << 16);
+    r.w[2] = (s[2] >> 16) | (s[3] << 8);
+  }
   return r;
 }
 
 // MULTI: request the running sums of sample offset t0, records [first, first + count) of this lane's 16; zero for the first
 // block.  The first tile's records are requested before the wave's MFMA pass, the next tile's at the start of each tile
 // of the epilogue: always ~1 us ahead of their use, never more than 8 records in registers.
-template <int FIRST, int COUNT>
-__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first, SumRec (&pre)[16])
+template <int FIRST, int COUNT, bool S16>
+__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first,
+                                                 SumRecT<S16> (&pre)[16])
 {
-  const SumRec *e4 = reinterpret_cast<const SumRec *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
+  const SumRecT<S16> *e4 = reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
 #pragma unroll
   for (int i = FIRST; i < FIRST + COUNT; i++)
-    pre[i] = ms_first ? SumRec{{0, 0, 0}} : e4[(size_t)i * 64];
+    pre[i] = ms_first ? SumRecT<S16>{} : e4[(size_t)i * 64];
 }
 
 // ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
 // SEARCH = false (MULTI, not the last block): only the running sums move on -- no key, no maximum, no window sum
-template <bool MULTI, bool SEARCH>
+template <bool MULTI, bool SEARCH, bool S16>
 __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
-                                            u32 group_mask, u32 *__restrict__ energy, SumRec (&pre)[MULTI ? 16 : 1],
-                                            bool ms_first)
+                                            u32 group_mask, u32 *__restrict__ energy, SumRecT<S16> (&pre)[MULTI ? 16 : 1],
+                                            bool ms_first, u32 &witness)
 {
+  typedef SumRecT<S16> SumRec;
   constexpr bool ms_last = SEARCH;
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
@@ -598,12 +621,13 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     const int q = 32 * (q0_tile + 2 * j) + n;
     const u32 key_lo = (u32)(2047 - (2 * q + half));   // 0 .. 2047 (q = 1023 does not exist: its magnitude is 0)
     if constexpr (MULTI) {
+      // (deeper -- two tiles ahead with the 16-bit records -- measured 3 % slower: more registers, nothing gained)
       if (j == 0)
-        mx_prefetch_sums<4, 4>(energy, lane, t0, ms_first, pre);
+        mx_prefetch_sums<4, 4, S16>(energy, lane, t0, ms_first, pre);
       if (j == 1)
-        mx_prefetch_sums<8, 4>(energy, lane, t0, ms_first, pre);
+        mx_prefetch_sums<8, 4, S16>(energy, lane, t0, ms_first, pre);
       if (j == 2)
-        mx_prefetch_sums<12, 4>(energy, lane, t0, ms_first, pre);
+        mx_prefetch_sums<12, 4, S16>(energy, lane, t0, ms_first, pre);
     }
     // (all four 8-PRN groups, whether this shard owns them or not: a workgroup that owns only some -- at the ends of a
     //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
@@ -619,11 +643,14 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       for (int i = 0; i < GS; i++)
         prev[i] = 0;
       if (MULTI) {
-        u32 p4[4];
-        sums_unpack(pre[MULTI ? j * 4 + r0 / 4 : 0], p4);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          prev[i] = p4[i];
+        for (int g = 0; g < GS / 4; g++) {
+          u32 p4[4];
+          sums_unpack<S16>(pre[MULTI ? j * 4 + r0 / 4 + g : 0], p4);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            prev[4 * g + i] = p4[i];
+        }
       }
       SumRec *e_rec = e4 + (size_t)(j * 4 + r0 / 4) * 64;
       u32 out[GS];
@@ -668,8 +695,13 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         }
       }
       if (MULTI && !ms_last) {
-        const u32 o4[4] = {out[0], out[1], out[2], out[3]};
-        *e_rec = sums_pack(o4);
+#pragma unroll
+        for (int g = 0; g < GS / 4; g++) {
+          const u32 o4[4] = {out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]};
+          e_rec[(size_t)g * 64] = sums_pack<S16>(o4);
+          if constexpr (S16)
+            witness |= (o4[0] | o4[1]) | (o4[2] | o4[3]);
+        }
       }
       if (SEARCH && !DIRECT) {   // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
 #pragma unroll
@@ -783,7 +815,7 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
   }
 }
 
-constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2;   // k_acq_mx's MODE
+constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3;   // k_acq_mx's MODE
 
 }  // namespace
 
@@ -821,14 +853,22 @@ void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slo
   hipLaunchKernelGGL(k_build_mx_tables, dim3((n + 255) / 256), dim3(256), 0, s, d_chipbits, n_slots, d_mx_a, d_mx_t);
 }
 
-// MODE: kMxSingle (n_ms == 1), kMxWalk (the workgroup walks the blocks of its searches, running sums in HBM scratch),
-// kMxStore (a workgroup per block, magnitudes out as u16 for k_acq_vals_search: the form for few multi-block searches)
+// MODE: kMxSingle (n_ms == 1), kMxWalk16 (the workgroup walks the blocks of its searches, running sums as 16-bit records in
+// HBM scratch; `flags`[workgroup] tells whether a sum outgrew them), kMxWalk (the same with 24-bit records: launched behind
+// kMxWalk16, a workgroup does its cluster again if its flag is up and leaves otherwise), kMxStore (a workgroup per block,
+// magnitudes out as u16 for k_acq_vals_search: the form for few multi-block searches)
 template <int MODE>
 __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ mx_a, const u32 *__restrict__ mx_t,
-                                                          gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy)
+                                                          gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
+                                                          u32 *__restrict__ flags)
 {
-  constexpr bool MULTI = MODE == kMxWalk, STORE = MODE == kMxStore;
+  constexpr bool MULTI = MODE == kMxWalk || MODE == kMxWalk16, STORE = MODE == kMxStore, S16 = MODE == kMxWalk16;
+  typedef SumRecT<S16> SumRec;
+  if constexpr (MODE == kMxWalk) {
+    if (flags && flags[blockIdx.x] == 0)   // (uniform: the 16-bit run of this cluster was exact)
+      return;
+  }
   __shared__ MxShared sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values in SGPRs)
@@ -882,7 +922,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     if constexpr (!MULTI && !STORE)
       asm volatile("" : "+v"(kq[j]));   // (kept in registers, not rebuilt per group; the other forms do not use them)
   }
-  u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * 3) : nullptr;   // SumRec = 3 dwords
+  u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * (S16 ? 2 : 3)) : nullptr;   // dwords per record
+  u32 witness = 0;   // S16: OR of every sum this lane stored
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const int n_ms = MULTI ? prm.n_ms : 1;
 #pragma unroll 1
@@ -930,7 +971,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       if (active && (x & 1) == 0) {
         if constexpr (MULTI) {
           if (p >= 1)
-            mx_prefetch_sums<0, 4>(e_wave, lane, p - 1, ms_first, pre);
+            mx_prefetch_sums<0, 4, S16>(e_wave, lane, p - 1, ms_first, pre);
         }
         if (!(ex & 2)) {
           if (ex & 16)
@@ -952,15 +993,29 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         if (!MULTI)
           mx_epilogue_single(sh, lane, kq, p - 1, acc);
         else if (!ms_last)
-          mx_epilogue<MULTI, false>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);
+          mx_epilogue<MULTI, false, S16>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
         else
-          mx_epilogue<MULTI, true>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first);
+          mx_epilogue<MULTI, true, S16>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
       }
     }
   }
   if (STORE)
     return;   // k_acq_vals_search sums the blocks and searches
+  if constexpr (S16) {
+    // did any stored sum need more than 16 bits?  (sh.ones is free after the last block's preamble)
+    if (tid == 0)
+      sh.ones[0] = 0;
+    __syncthreads();
+    if (__builtin_amdgcn_ballot_w64((witness >> 16) != 0) != 0 && lane == 0)
+      atomicOr(&sh.ones[0], 1u);
+  }
   __syncthreads();
+  if constexpr (S16) {
+    if (tid == 0)
+      flags[blockIdx.x] = sh.ones[0];
+    if (sh.ones[0])
+      return;   // (uniform) the second kernel does this cluster again and writes its triplets
+  }
   // the finished triplets: one per (PRN, bit shift); threads 0..255 fold the 32 lane slots of the maxima and write
   // (max, phase), threads 256..511 those of the sums and write (sum, avr)
   {
@@ -1016,17 +1071,24 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   mx_cluster_range(prm, &c_lo, &c_hi);
   if (prm.n_ms > 1 && block_parallel) {
     hipLaunchKernelGGL(k_acq_mx<kMxStore>, dim3((unsigned)((c_hi - c_lo) * prm.n_ms)), dim3(kMxThreads), 0, s, prm, c_lo, d_if,
-                       d_mx_a, d_mx_t, d_peaks, d_energy);
+                       d_mx_a, d_mx_t, d_peaks, d_energy, (u32 *)nullptr);
     launch_acq_vals_search(s, prm, reinterpret_cast<const uint16_t *>(d_energy), d_peaks, n_peaks);
     return "k_acq_mx<2>";
   }
   if (prm.n_ms > 1) {
-    hipLaunchKernelGGL(k_acq_mx<kMxWalk>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
-                       d_peaks, d_energy);
-    return "k_acq_mx<1>";
+    // 16-bit running sums first; where they cannot overflow (n_ms x 11573 < 2^16) that is all, otherwise the 24-bit form
+    // follows and redoes the clusters whose flag went up.  The flags sit behind the records.
+    const unsigned n_wg = (unsigned)(c_hi - c_lo);
+    u32 *d_flags = d_energy + acq_mx_energy_bytes(n_wg) / sizeof(u32) - n_wg;
+    hipLaunchKernelGGL(k_acq_mx<kMxWalk16>, dim3(n_wg), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
+                       d_energy, d_flags);
+    if (prm.n_ms * 11573 > 65535)
+      hipLaunchKernelGGL(k_acq_mx<kMxWalk>, dim3(n_wg), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
+                         d_energy, d_flags);
+    return "k_acq_mx<3>";
   }
   hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
-                     d_peaks, (u32 *)nullptr);
+                     d_peaks, (u32 *)nullptr, (u32 *)nullptr);
   return "k_acq_mx<0>";
 }
 

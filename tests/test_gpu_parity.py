@@ -1001,3 +1001,32 @@ def test_config_if_hz_moves_the_doppler_axis_and_the_tracking_reference(oracle, 
         assert np.array_equal(iq[2], w)
     finally:
         e.close()
+
+
+def test_walk_form_16_bit_running_sums_overflow_falls_back_exactly(oracle, stream, monkeypatch):
+    """The walk form keeps its running sums as 16-bit records first; a cluster in which a sum outgrows them raises its flag
+    and is done again by the 24-bit form launched behind it.  Ten copies of the reference simulator's noise-free block put
+    7904 per block on (PRN 1, IF + 2000 Hz): 71136 after nine blocks -- that cluster must overflow and come out exact; the
+    second search (signals in noise) never overflows and keeps its first result."""
+    from stm32f4_sdr_gps_amd import capi
+    monkeypatch.setenv("GPSX_ACQ_MS_MODE", "walk")
+    monkeypatch.setenv("GPSX_ACQ_ALGO", "mx")
+    e = capi.Engine(0)
+    monkeypatch.delenv("GPSX_ACQ_MS_MODE")
+    monkeypatch.delenv("GPSX_ACQ_ALGO")
+    try:
+        clean = load("f6_config1.npz")["blocks"][0]
+        blocks = np.concatenate([np.tile(clean, (10, 1)), stream[:10]])
+        prns = np.array([1, 7, 19], np.uint8)
+        peaks, keys = e.acq_grid(blocks, prns, n_search=2, n_ms=10, search_stride_blocks=10, dopp_min_hz=2000, dopp_step_hz=500,
+                                 n_dopp=2)
+        assert e.lib.gpsx_last_kernel(e.h) == b"k_acq_mx<3>"
+        assert int(peaks[0, 0, 0]["max_val"].max()) > 70000          # nine-block partial sums above 2^16 on the way
+        assert int(peaks[1]["max_val"].max()) < 30000
+        for s_ in range(2):
+            blk = blocks[10 * s_:10 * s_ + 10]
+            for p, d, b in ((0, 0, 0), (0, 0, 4), (0, 1, 7), (1, 0, 2), (2, 1, 5)):
+                pk, _, _ = oracle.search_job(blk, 10, oracle.ca_code(int(prns[p])), float(IF_HZ + 2000 + 500 * d), b, 0, 2046)
+                assert _peak_tuple(peaks[s_, p, d, b]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), (s_, p, d, b)
+    finally:
+        e.close()
