@@ -535,11 +535,12 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
 
 // MULTI: the running sums between blocks: the scratch stream is what binds this form (bench.py `roofline` of the
 // multi-block run), so its records are as small as exactness allows.
-//   S16 = true  (kMxWalk16, the form that runs first): four 16-bit sums in two dwords.  n_ms x 11573 fits 16 bits up to
-//               5 blocks; beyond that only hypotheses with magnitudes above 6553 in every block -- clean carriers, not
-//               signals in noise -- can overflow: every stored sum is OR-ed into a per-lane witness, a workgroup that saw
-//               bit 16 or above raises its flag, and the launcher's second kernel (kMxWalk, below), whose workgroups
-//               leave at once where no flag is up, does such a cluster again with
+//   S16 = true  (kMxWalk16, the form that runs first): four 16-bit sums in two dwords, moved on by SATURATING packed adds
+//               (v_pk_add_u16 clamp: two sums per instruction, no unpacking).  n_ms x 11573 fits 16 bits up to 5 blocks;
+//               beyond that only hypotheses with magnitudes above 6553 in every block -- clean carriers, not signals in
+//               noise -- can reach 0xFFFF, where a sum then stays: the last block's epilogue, which unpacks the sums for
+//               its keys, raises the workgroup's flag when it meets one, and the launcher's second kernel (kMxWalk,
+//               below), whose workgroups leave at once where no flag is up, does such a cluster again with
 //   S16 = false (kMxWalk): four sums of 24 bits (128 x 11573 < 2^21) in three dwords.
 template <bool S16>
 struct SumRecT {
@@ -574,6 +575,14 @@ __device__ __forceinline__ SumRecT<S16> sums_pack(const u32 (&s)[4])
     r.w[2] = (s[2] >> 16) | (s[3] << 8);
   }
   return r;
+}
+
+// two 16-bit sums + two magnitudes in one instruction, saturating: a half that reaches 0xFFFF stays there, and the last
+// block's epilogue, which unpacks the sums anyway, raises the flag when it meets one
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 pk_add_sat_u16(u32 a, u32 b)
+{
+  return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 
 // MULTI: request the running sums of sample offset t0, records [first, first + count) of this lane's 16; zero for the first
@@ -642,14 +651,17 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 #pragma unroll
       for (int i = 0; i < GS; i++)
         prev[i] = 0;
-      if (MULTI) {
+      if (MULTI && !(S16 && !SEARCH)) {
 #pragma unroll
         for (int g = 0; g < GS / 4; g++) {
           u32 p4[4];
           sums_unpack<S16>(pre[MULTI ? j * 4 + r0 / 4 + g : 0], p4);
 #pragma unroll
-          for (int i = 0; i < 4; i++)
+          for (int i = 0; i < 4; i++) {
             prev[4 * g + i] = p4[i];
+            if constexpr (S16)
+              witness = max(witness, p4[i]);   // (last block: a saturated sum, 0xFFFF, shows here)
+          }
         }
       }
       SumRec *e_rec = e4 + (size_t)(j * 4 + r0 / 4) * 64;
@@ -668,14 +680,27 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       }
       const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
       u32 mag[GS];
+      constexpr bool PACKED = MULTI && S16 && !SEARCH;   // 16-bit records, not the last block: sums move on in packed form
       if (small) {
 #pragma unroll
         for (int i = 0; i < GS; i++)
-          mag[i] = (u32)(int)__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f));
+          mag[i] = PACKED ? __float_as_uint(__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f)) + 8388607.5f)
+                          : (u32)(int)__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f));
       } else {
 #pragma unroll
         for (int i = 0; i < GS; i++)
           mag[i] = root_trunc(ev[i] * kUnscaleSq);
+      }
+      if constexpr (PACKED) {
+        // (magnitudes in the low halves of mag[] -- the rounding add's 0x4B000000 sits above them --, two per v_perm_b32,
+        //  then one saturating packed add per pair: 1 instruction per hypothesis instead of unpack, add, pack and witness)
+        const SumRec &pr = pre[j * 4 + r0 / 4];
+        SumRec nr;
+        nr.w[0] = pk_add_sat_u16(pr.w[0], __builtin_amdgcn_perm(mag[1], mag[0], 0x05040100u));
+        nr.w[1] = pk_add_sat_u16(pr.w[1], __builtin_amdgcn_perm(mag[3], mag[2], 0x05040100u));
+        *e_rec = nr;
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
       }
 #pragma unroll
       for (int i = 0; i < GS; i++) {
@@ -699,8 +724,6 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         for (int g = 0; g < GS / 4; g++) {
           const u32 o4[4] = {out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]};
           e_rec[(size_t)g * 64] = sums_pack<S16>(o4);
-          if constexpr (S16)
-            witness |= (o4[0] | o4[1]) | (o4[2] | o4[3]);
         }
       }
       if (SEARCH && !DIRECT) {   // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
@@ -1006,7 +1029,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     if (tid == 0)
       sh.ones[0] = 0;
     __syncthreads();
-    if (__builtin_amdgcn_ballot_w64((witness >> 16) != 0) != 0 && lane == 0)
+    if (__builtin_amdgcn_ballot_w64(witness >= 0xFFFFu) != 0 && lane == 0)
       atomicOr(&sh.ones[0], 1u);
   }
   __syncthreads();

@@ -48,6 +48,12 @@ __device__ __forceinline__ void valu_iter(float (&x)[8], float c)
       asm volatile("v_mul_f32_e64 %0, %0, |%1| clamp" : "+v"(r) : "v"(c));
     else if (OP == 8)
       asm volatile("v_max3_u32 %0, %0, %1, %1" : "+v"(r) : "v"(c));
+    else if (OP == 9)
+      asm volatile("v_pk_add_u16 %0, %0, %1 clamp" : "+v"(r) : "v"(c));
+    else if (OP == 10)
+      asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(r) : "v"(c));
+    else if (OP == 11)
+      asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(r) : "v"(c));
   }
 }
 
@@ -171,5 +177,8 @@ int main()
   run<6, 4, 96>("v_pk_add_f32 (2 values/lane)", n_wg, it);
   run<7, 8, 192>("v_mul_f32 |x| clamp (VOP3)", n_wg, it);
   run<8, 8, 192>("v_max3_u32", n_wg, it);
+  run<9, 8, 192>("v_pk_add_u16 clamp", n_wg, it);
+  run<10, 8, 192>("v_perm_b32", n_wg, it);
+  run<11, 8, 192>("v_or3_b32", n_wg, it);
   return 0;
 }
