@@ -99,6 +99,9 @@ def tracking_channels(eng_cls, dev_index, steps=1000):
     (gpsx_track_epl_batch: block + states in, one launch, states + accumulators out) keeps its p99 under 1 ms."""
     from stm32f4_sdr_gps_amd import capi, synth
     eng = eng_cls(dev_index)
+    # a real-time host keeps the thread that feeds the GPU, and the page-locked buffers it touches first, on the GPU's socket
+    affinity = os.sched_getaffinity(0)
+    bound = eng.bind_thread_to_device()
     stream = synth.default_four_sv(8, seed=7)
     rows, best = [], None
     blocks = eng.host_array(stream.shape, np.uint8)      # a real-time host keeps its per-millisecond buffers page-locked
@@ -124,9 +127,10 @@ def tracking_channels(eng_cls, dev_index, steps=1000):
         else:
             break
     eng.close()
+    os.sched_setaffinity(0, affinity)
     return {"metric": "real-time tracking channels (p99 of the E/P/L step per ms < 1 ms, host round trip included; block, states and "
                       "accumulators in page-locked host memory)",
-            "value": best, "steps_per_count": steps, "ladder": rows,
+            "value": best, "steps_per_count": steps, "ladder": rows, "thread_on_gpu_numa_node": bool(bound),
             "note": "10000-step measurements and the closed-loop figure are in profiles/r0N_tracking_*.json"}
 
 

@@ -67,6 +67,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_malloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
     lib.gpsx_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.gpsx_host_alloc.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t]
+    lib.gpsx_bind_thread_to_device.argtypes = [C.c_void_p]
     lib.gpsx_host_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.gpsx_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.gpsx_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -193,6 +194,10 @@ class Engine:
         p = C.c_void_p()
         self._chk(self.lib.gpsx_malloc(self.h, C.byref(p), nbytes), "gpsx_malloc")
         return p.value
+
+    def bind_thread_to_device(self) -> bool:
+        """Pin the calling thread to the CPUs local to this context's GPU; False when the topology is not exposed."""
+        return self.lib.gpsx_bind_thread_to_device(self.h) == 0
 
     def host_array(self, shape, dtype) -> np.ndarray:
         """A numpy array in page-locked host memory (gpsx_host_alloc); lives until the engine is closed."""

@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
+#include <sched.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -321,6 +323,48 @@ int gpsx_host_alloc(gpsx_ctx *ctx, void **hptr, size_t bytes)
     (void)hipGetLastError();
     return fail(ctx, GPSX_ENOMEM, "hipHostMalloc failed");
   }
+  return GPSX_OK;
+}
+
+int gpsx_bind_thread_to_device(gpsx_ctx *ctx)
+{
+  if (int rc = use_device(ctx)) return rc;
+  char bdf[32] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, ctx->device) != hipSuccess) {
+    (void)hipGetLastError();
+    return GPSX_ENODEV;
+  }
+  for (char *c = bdf; *c; c++)
+    *c = (char)std::tolower((unsigned char)*c);
+  char path[128];
+  std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  std::FILE *f = std::fopen(path, "r");
+  if (!f)
+    return GPSX_ENODEV;
+  char list[1024] = {0};
+  const bool got = std::fgets(list, (int)sizeof list, f) != nullptr;
+  std::fclose(f);
+  if (!got)
+    return GPSX_ENODEV;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n_set = 0;
+  for (const char *c = list; *c;) {        // "0-63,128-191"
+    char *end = nullptr;
+    const long lo = std::strtol(c, &end, 10);
+    if (end == c)
+      break;
+    long hi = lo;
+    if (*end == '-')
+      hi = std::strtol(end + 1, &end, 10);
+    for (long k = lo; k <= hi && k < CPU_SETSIZE; k++, n_set++)
+      CPU_SET((int)k, &set);
+    c = (*end == ',') ? end + 1 : end;
+    if (*end != ',')
+      break;
+  }
+  if (n_set == 0 || sched_setaffinity(0, sizeof set, &set) != 0)
+    return GPSX_ENODEV;
   return GPSX_OK;
 }
 

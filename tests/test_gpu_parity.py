@@ -1030,3 +1030,25 @@ def test_walk_form_16_bit_running_sums_overflow_falls_back_exactly(oracle, strea
                 assert _peak_tuple(peaks[s_, p, d, b]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), (s_, p, d, b)
     finally:
         e.close()
+
+
+def test_bind_thread_to_device_pins_to_the_gpus_numa_node():
+    """gpsx_bind_thread_to_device: the calling thread's affinity becomes the GPU's local CPU list (a subset of what it had),
+    or the call reports that the topology is not exposed and changes nothing."""
+    import os
+    from stm32f4_sdr_gps_amd import capi
+    before = os.sched_getaffinity(0)
+    e = capi.Engine(0)
+    try:
+        ok = e.bind_thread_to_device()
+        after = os.sched_getaffinity(0)
+        if ok:
+            assert after and after <= set(range(4096)) and len(after) <= os.cpu_count()
+            st = np.zeros(8, capi.TRK_DTYPE)
+            st["prn"] = np.arange(1, 9)
+            assert e.track_epl(np.zeros(2046, np.uint8), st).shape == (8, 6)     # the engine works from the pinned thread
+        else:
+            assert after == before
+    finally:
+        os.sched_setaffinity(0, before)
+        e.close()
