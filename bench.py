@@ -330,6 +330,8 @@ def main():
         g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
                            dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
         engs = [capi.Engine(dev_index), capi.Engine(dev_index)]     # own non-blocking streams
+        affinity = os.sched_getaffinity(0)
+        engs[0].bind_thread_to_device()      # the feeding thread and the pinned pages it touches first: the GPU's socket
         pins = []
         for e2 in engs:
             if two_bit:
@@ -362,6 +364,7 @@ def main():
         assert torch.equal(pins[0][2], pins[1][2]) and int(pins[0][2].min()) > 0     # both contexts returned the key table
         for e2 in engs:
             e2.close()
+        os.sched_setaffinity(0, affinity)
 
     # sanity outside the timed region: the merged key table must hold the six synthetic satellites' peaks
     d_keys = key_bufs[(step_no[0] - 1) & 1]

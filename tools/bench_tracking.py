@@ -27,6 +27,7 @@ def main():
     args = ap.parse_args()
     from stm32f4_sdr_gps_amd import capi, synth
     eng = capi.Engine(0)
+    eng.bind_thread_to_device()   # the step's thread on the GPU's NUMA node (gpsx_bind_thread_to_device)
     stream = synth.default_four_sv(64, seed=7)
     cap = capi.Capture(eng, 2) if args.ring else None
 
