@@ -176,8 +176,11 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
             hipMalloc((void **)&ctx->d_bits_all, (size_t)slots * 32 * 4) == hipSuccess &&
             hipMalloc((void **)&ctx->d_cw_all, (size_t)slots * kCodeWords * 4) == hipSuccess &&
             hipMalloc((void **)&ctx->d_cw8_all, (size_t)slots * (kCodeWords / 2) * 4) == hipSuccess &&
-            hipMemcpyAsync(d_prns, prns.data(), slots, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            hipMemcpyAsync(d_prns, prns.data(), slots, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+            hipHostMalloc((void **)&ctx->h_bad_prn, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void **)&ctx->d_bad_prn, ctx->h_bad_prn, 0) == hipSuccess;
   if (ok) {
+    *ctx->h_bad_prn = 0;
     launch_build_codes(ctx->stream, d_prns, slots, 1, ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
   }
@@ -212,6 +215,8 @@ void gpsx_destroy(gpsx_ctx *ctx)
     (void)hipStreamDestroy(ctx->aux_stream);
     (void)hipEventDestroy(ctx->aux_event);
   }
+  if (ctx->h_bad_prn)
+    (void)hipHostFree(ctx->h_bad_prn);
   if (ctx->own_stream && ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -221,6 +226,10 @@ int gpsx_synchronize(gpsx_ctx *ctx)
 {
   if (int rc = use_device(ctx)) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_bad_prn && *ctx->h_bad_prn) {   // a gpsx_track_epl_batch_dev since the last look
+    *ctx->h_bad_prn = 0;
+    return fail(ctx, GPSX_EINVAL, "a tracking batch held a prn outside 1..210 (correlated against the empty code)");
+  }
   return GPSX_OK;
 }
 
@@ -736,7 +745,7 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, ctx->if_hz, d_st, n_ch,
-                   ctx->d_chips_all, ctx->d_bits_all, d_iq_out);
+                   ctx->d_chips_all, ctx->d_bits_all, d_iq_out, ctx->d_bad_prn);
   LAUNCHCHK(ctx, "k_track_epl");
   return GPSX_OK;
 }
@@ -814,7 +823,7 @@ gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch_asked, size_t 
     if (ok) {
       ok = hipMemcpyAsync(t.d_buf, t.h_in, t.in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
       launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, ctx->if_hz, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all,
-                       d_iq);
+                       d_iq, ctx->d_bad_prn);
       ok = ok && hipGetLastError() == hipSuccess &&
            hipMemcpyAsync(t.h_out, d_st, t.out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
       ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;
@@ -837,14 +846,22 @@ gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch_asked, size_t 
 
 }  // namespace
 
+// what the kernels of the step just waited for said about its PRNs
+static int track_prn_verdict(gpsx_ctx *ctx)
+{
+  if (*ctx->h_bad_prn == 0)
+    return GPSX_OK;
+  *ctx->h_bad_prn = 0;
+  return fail(ctx, GPSX_EINVAL, "prn must be 1..210 (the channel was correlated against the empty code)");
+}
+
 int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out)
 {
   if (int rc = use_device(ctx)) return rc;
   if (!if_block || !st || !iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
-  for (int i = 0; i < n_ch; i++)
-    if (st[i].prn < 1 || st[i].prn > GPSX_MAX_PRN)
-      return fail(ctx, GPSX_EINVAL, "prn must be 1..210");
+  // (the PRNs are checked by the kernel: a host loop over 400 000 states costs a sixth of the millisecond)
+  *ctx->h_bad_prn = 0;
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
   // The real-time shape (a few channels to a few thousand, every millisecond): the whole step is ONE graph launch
   // between two small host copies into / out of pinned staging, instead of two copies in, a launch, two copies out.
@@ -853,13 +870,14 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
     gpsx_ctx::TrackGraph &t = *tg;   // t.n_ch = the capacity the graph was captured for (>= n_ch)
     std::memcpy(t.h_in + t.blk_off, if_block, blk_bytes);
     std::memcpy(t.h_in + t.st_off, st, (size_t)n_ch * sizeof(gpsx_trk_state_t));
-    if (t.n_ch > n_ch)   // padding channels: PRN 0, the empty code
-      std::memset(t.h_in + t.st_off + (size_t)n_ch * sizeof(gpsx_trk_state_t), 0, (size_t)(t.n_ch - n_ch) * sizeof(gpsx_trk_state_t));
+    gpsx_trk_state_t *pad = reinterpret_cast<gpsx_trk_state_t *>(t.h_in + t.st_off) + n_ch;
+    for (int i = n_ch; i < t.n_ch; i++, pad++)   // padding channels: the empty code
+      *pad = gpsx_trk_state_t{kTrackPadPrn, 0.0f, 0.0f, 0u};
     HIPCHK(ctx, hipGraphLaunch(t.exec, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(st, t.h_out, (size_t)n_ch * sizeof(gpsx_trk_state_t));
     std::memcpy(iq_out, t.h_out + (size_t)t.n_ch * sizeof(gpsx_trk_state_t), (size_t)n_ch * 12);
-    return GPSX_OK;
+    return track_prn_verdict(ctx);
   }
   if (int rc = arena_reset(ctx, arena_size(blk_bytes + 2) + arena_size(n_ch * sizeof(gpsx_trk_state_t)) +
                                     arena_size((size_t)n_ch * 12)))
@@ -873,10 +891,17 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
     d_if = d_if_copy;
   }
   // Very many channels: the step is mostly PCIe (16 B of state in, 28 B of state + accumulators out per channel), and the
-  // link is full duplex: the channels go through in chunks that alternate between the context's stream and a second one,
+  // link is full duplex: the channels go through in two chunks, one on the context's stream and one on a second one,
   // so that one chunk's correlators and copy-out run under the next chunk's copy-in (page-locked caller buffers assumed:
   // gpsx_host_alloc; with pageable ones the copies serialise in the runtime and nothing is lost).
-  constexpr int kChunkFrom = 131072, kChunks = 4;
+  constexpr int kChunkFrom = 131072;
+  // (two chunks: 1 / 2 / 4 / 8 chunks measured 900 / 896 / 934 / 970 us for 393216 channels -- every enqueued copy has its
+  //  price, and the kernel is the larger half of the step; $GPSX_TRACK_CHUNKS overrides)
+  static const int kChunks = [] {
+    const char *c = std::getenv("GPSX_TRACK_CHUNKS");
+    const int v = c ? std::atoi(c) : 0;
+    return v >= 1 && v <= 64 ? v : 2;
+  }();
   if (n_ch >= kChunkFrom) {
     if (!ctx->aux_stream) {
       HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
@@ -890,21 +915,21 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
       hipStream_t s = (c & 1) ? ctx->aux_stream : ctx->stream;
       HIPCHK(ctx, hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, s));
       launch_track_epl(s, d_if, ctx->if_format, ctx->if_hz, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all,
-                       d_iq + (size_t)first * 6);
+                       d_iq + (size_t)first * 6, ctx->d_bad_prn);
       LAUNCHCHK(ctx, "k_track_epl");
       HIPCHK(ctx, hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, s));
       HIPCHK(ctx, hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->aux_stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return GPSX_OK;
+    return track_prn_verdict(ctx);
   }
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
   if (int rc = gpsx_track_epl_batch_dev(ctx, d_if, d_st, n_ch, d_iq)) return rc;
   HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(iq_out, d_iq, (size_t)n_ch * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return GPSX_OK;
+  return track_prn_verdict(ctx);
 }
 
 int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *steps)

@@ -33,6 +33,8 @@ struct gpsx_ctx {
   bool own_stream = false;
   hipStream_t aux_stream = nullptr;   // second stream of the chunked tracking step (very many channels), created on first use
   hipEvent_t aux_event = nullptr;
+  uint32_t *h_bad_prn = nullptr;      // page-locked flag the tracking kernels raise on a PRN outside 1..210
+  uint32_t *d_bad_prn = nullptr;      // its device address
   std::string err;
   const char *last_kernel = "";      // dominant kernel of the last acquisition launch (gpsx_last_kernel)
   hipDeviceProp_t prop;

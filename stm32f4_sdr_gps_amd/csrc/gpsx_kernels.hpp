@@ -118,8 +118,10 @@ void launch_mag8(hipStream_t s, const uint16_t *d_cnt_i, const uint16_t *d_cnt_q
 void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int first_offset, gpsx_peak_t *d_peak);
 
 // K2+K3+K5 tracking correlators, one workgroup per channel
+// d_bad_prn (may be null): set to 1 by a channel whose PRN is outside 1..210 (it correlates against the empty code)
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
-                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq);
+                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq, uint32_t *d_bad_prn);
+constexpr int kTrackPadPrn = -2147483647 - 1;   // gpsx_trk_state_t.prn of a padding channel: the empty code, not an error
 // N3: 2-bit sign/magnitude samples -> two 1-bit planes
 void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag);
 void launch_rewind(hipStream_t s, int if_hz, gpsx_trk_state_t *d_st, int n_ch, const uint8_t *d_steps);

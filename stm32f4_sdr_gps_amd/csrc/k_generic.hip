@@ -193,10 +193,24 @@ void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int firs
 //   fine = (int16) code_phase_fine;  replica shift = fine & 7;  prompt offset = fine / 8, early = prompt - 1
 //   (wraps to 2045), late = prompt + 1 (wraps to 0)                                   PM/GPS/tracking.c:115-130
 //   carrier NCO continues from if_freq_accum at (float)IF + if_freq_offset_hz and is stored back  gps_misc.c:244-274
+// The PRN of a channel state as the tracking kernels use it.  Validation lives here, not in a host loop over the states (at
+// 400 000 channels that loop is a sixth of the millisecond): a PRN outside 1..210 correlates against the empty code and
+// raises *bad_prn -- page-locked host memory the step call looks at after its wait.  kTrackPadPrn marks the padding
+// channels of a captured step (gpsx_api.hip: graphs are cached per capacity) and raises nothing.
+__device__ __forceinline__ int track_prn(int prn, u32 *bad_prn, bool reporter)
+{
+  if (prn >= 1 && prn <= GPSX_MAX_PRN)
+    return prn;
+  if (prn != kTrackPadPrn && reporter && bad_prn)
+    *bad_prn = 1u;
+  return 0;
+}
+
 // Wave w < 3 computes offset E/P/L; the IF block is read once per channel with coalesced 16-bit loads.
 __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ if_block, int if_format, int if_hz,
                                                    gpsx_trk_state_t *__restrict__ st, int n_ch,
-                                                   const uint8_t *__restrict__ chips_all, int16_t *__restrict__ iq_out)
+                                                   const uint8_t *__restrict__ chips_all, int16_t *__restrict__ iq_out,
+                                                   u32 *__restrict__ bad_prn)
 {
   __shared__ __attribute__((aligned(4))) uint8_t s_i[2048];
   __shared__ __attribute__((aligned(4))) uint8_t s_q[2048];
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
     return;
   const int tid = threadIdx.x;
   const gpsx_trk_state_t state = st[ch];
-  const int prn = state.prn >= 0 && state.prn <= GPSX_MAX_PRN ? state.prn : 0;
+  const int prn = track_prn(state.prn, bad_prn, tid == 0);
   const uint8_t *chips = chips_all + (size_t)prn * 1024;
 
   const int fine = (int)(int16_t)(int)state.code_phase_fine;
@@ -294,7 +308,7 @@ __device__ __forceinline__ uint4 lds_read_pairs(const uint2 *p)   // p[0], p[1]:
 __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restrict__ if_block, int if_format, int if_hz,
                                                         gpsx_trk_state_t *__restrict__ st, int n_ch,
                                                         const u32 *__restrict__ chipbits_all,
-                                                        int16_t *__restrict__ iq_out)
+                                                        int16_t *__restrict__ iq_out, u32 *__restrict__ bad_prn)
 {
   __shared__ u32 s_x[512];
   __shared__ uint2 s_carrier[4];   // (in-phase, quadrature) carrier word per NCO quadrant: one LDS read instead of two selects
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
   if (threadIdx.x < 4)
     s_carrier[threadIdx.x] = uint2{carrier_i(threadIdx.x), carrier_q(threadIdx.x)};
   const gpsx_trk_state_t state = st[ch];
-  const int prn = state.prn >= 0 && state.prn <= GPSX_MAX_PRN ? state.prn : 0;
+  const int prn = track_prn(state.prn, bad_prn, live && lane == 0);
 
   // the block's sign plane as 32-bit words, once per workgroup (word 511 = 16-bit word 1022 alone)
   for (int w = threadIdx.x; w < 512; w += 256) {
@@ -440,15 +454,16 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
 constexpr int kTrackWaveFormFrom = 2048;
 
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
-                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq)
+                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq, uint32_t *d_bad_prn)
 {
   if (n_ch <= 0)
     return;
   if (n_ch < kTrackWaveFormFrom)
-    hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch, d_chips, d_iq);
+    hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch, d_chips, d_iq,
+                       d_bad_prn);
   else
     hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch,
-                       d_chipbits, d_iq);
+                       d_chipbits, d_iq, d_bad_prn);
 }
 
 // N3 ingest: MAX2769 sign/magnitude pairs -> sign plane and magnitude plane in the reference's 1-bit layout.

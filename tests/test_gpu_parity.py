@@ -1052,3 +1052,30 @@ def test_bind_thread_to_device_pins_to_the_gpus_numa_node():
     finally:
         os.sched_setaffinity(0, before)
         e.close()
+
+
+def test_track_epl_rejects_prns_outside_1_210_from_the_kernel(oracle, stream):
+    """The PRN check of gpsx_track_epl_batch lives in the kernels (a host loop over the states is a sixth of the millisecond
+    at 400 000 channels): a bad PRN makes the call fail after the step -- that channel saw the empty code --, the next call
+    with good states succeeds, and the padding channels of a captured step (5 channels in a graph of 8) raise nothing."""
+    from stm32f4_sdr_gps_amd import capi
+    e = capi.Engine(0)
+    try:
+        for n in (5, 3000, 140000):          # captured graph with padding, wave kernel, two-chunk step
+            st = np.zeros(n, capi.TRK_DTYPE)
+            st["prn"] = (np.arange(n) % 32) + 1
+            st["code_phase_fine"] = (61 * np.arange(n) % 16368).astype(np.float32)
+            st["if_freq_offset_hz"] = 250.0
+            good = st.copy()
+            iq = e.track_epl(stream[0], st)                      # good states: no complaint, padding included
+            w, _ = oracle.track_epl(stream[0], oracle.ca_code(int(good["prn"][n - 1])), float(good["code_phase_fine"][n - 1]), 250.0, 0)
+            assert np.array_equal(iq[n - 1], w)
+            for bad in (0, 211, -7):
+                st2 = good.copy()
+                st2["prn"][n // 2] = bad
+                with pytest.raises(capi.GpsxError, match="prn must be 1..210"):
+                    e.track_epl(stream[0], st2)
+            st3 = good.copy()
+            assert np.array_equal(e.track_epl(stream[0], st3), iq)   # the flag does not stick
+    finally:
+        e.close()
