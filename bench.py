@@ -107,7 +107,7 @@ def tracking_channels(eng_cls, dev_index, steps=1000):
     blocks = eng.host_array(stream.shape, np.uint8)      # a real-time host keeps its per-millisecond buffers page-locked
     blocks[:] = stream
     stream = blocks
-    for n in (256, 4096, 65536, 131072, 196608, 262144, 327680, 393216, 458752, 491520, 524288, 589824):
+    for n in (256, 4096, 65536, 131072, 262144, 393216, 524288, 589824, 655360, 688128, 720896, 786432):
         st = eng.host_array(n, capi.TRK_DTYPE)
         iq = eng.host_array((n, 6), np.int16)
         st["prn"] = (np.arange(n) % 32) + 1

@@ -213,7 +213,14 @@ void gpsx_destroy(gpsx_ctx *ctx)
   if (ctx->aux_stream) {
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->out_stream) {
+      (void)hipStreamSynchronize(ctx->out_stream);
+      (void)hipStreamDestroy(ctx->out_stream);
+    }
     (void)hipEventDestroy(ctx->aux_event);
+    for (hipEvent_t e : ctx->chunk_events)
+      if (e)
+        (void)hipEventDestroy(e);
   }
   if (ctx->h_bad_prn)
     (void)hipHostFree(ctx->h_bad_prn);
@@ -890,38 +897,50 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
     HIPCHK(ctx, hipMemcpyAsync(d_if_copy, if_block, blk_bytes, hipMemcpyHostToDevice, ctx->stream));
     d_if = d_if_copy;
   }
-  // Very many channels: the step is mostly PCIe (16 B of state in, 28 B of state + accumulators out per channel), and the
-  // link is full duplex: the channels go through in two chunks, one on the context's stream and one on a second one,
-  // so that one chunk's correlators and copy-out run under the next chunk's copy-in (page-locked caller buffers assumed:
+  // Very many channels: the step is the kernel plus PCIe (16 B of state in, 28 B of state + accumulators out per channel),
+  // and the link is full duplex: the channels go through in chunks on a three-stage pipeline -- copy-in on the context's
+  // stream, correlators on a second, copy-out on a third, chained by events -- so that chunk c + 1 arrives and chunk c - 1
+  // leaves while chunk c is correlated, each copy at the link's full rate (page-locked caller buffers assumed:
   // gpsx_host_alloc; with pageable ones the copies serialise in the runtime and nothing is lost).
-  constexpr int kChunkFrom = 131072;
-  // (two chunks: 1 / 2 / 4 / 8 chunks measured 900 / 896 / 934 / 970 us for 393216 channels -- every enqueued copy has its
-  //  price, and the kernel is the larger half of the step; $GPSX_TRACK_CHUNKS overrides)
-  static const int kChunks = [] {
+  constexpr int kChunkFrom = 131072, kMaxChunks = 16;
+  // (1 / 2 / 3 / 4 / 6 / 8 chunks: 905 / 747 / 699 / 675 / 673 / 701 us for 458752 channels, 1260 / 1021 / 950 / 915 / 896 /
+  //  905 us for 655360, 312 / 279 / 277 / 274 / 299 / 330 us for 131072; $GPSX_TRACK_CHUNKS overrides)
+  static const int kChunksEnv = [] {
     const char *c = std::getenv("GPSX_TRACK_CHUNKS");
     const int v = c ? std::atoi(c) : 0;
-    return v >= 1 && v <= 64 ? v : 2;
+    return v >= 1 && v <= kMaxChunks ? v : 0;
   }();
+  const int kChunks = kChunksEnv ? kChunksEnv : (n_ch >= 393216 ? 6 : 4);
   if (n_ch >= kChunkFrom) {
     if (!ctx->aux_stream) {
       HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming));
+      ctx->chunk_events.resize(2 * kMaxChunks, nullptr);
+      for (hipEvent_t &e : ctx->chunk_events)
+        HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    HIPCHK(ctx, hipEventRecord(ctx->aux_event, ctx->stream));          // the block (and everything before) is in place
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_event, 0));
     const int per = ((n_ch + kChunks - 1) / kChunks + 3) & ~3;
-    for (int c = 0, first = 0; first < n_ch; c++, first += per) {
+    int c = 0;
+    for (int first = 0; first < n_ch; c++, first += per) {
       const int n = std::min(per, n_ch - first);
-      hipStream_t s = (c & 1) ? ctx->aux_stream : ctx->stream;
-      HIPCHK(ctx, hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, s));
-      launch_track_epl(s, d_if, ctx->if_format, ctx->if_hz, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all,
+      hipEvent_t arrived = ctx->chunk_events[2 * c], done = ctx->chunk_events[2 * c + 1];
+      HIPCHK(ctx, hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipEventRecord(arrived, ctx->stream));      // (also: the block and everything before it on the stream)
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, arrived, 0));
+      launch_track_epl(ctx->aux_stream, d_if, ctx->if_format, ctx->if_hz, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all,
                        d_iq + (size_t)first * 6, ctx->d_bad_prn);
       LAUNCHCHK(ctx, "k_track_epl");
-      HIPCHK(ctx, hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, s));
-      HIPCHK(ctx, hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+      HIPCHK(ctx, hipEventRecord(done, ctx->aux_stream));
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->out_stream, done, 0));
+      HIPCHK(ctx, hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->out_stream));
+      HIPCHK(ctx, hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost,
+                                 ctx->out_stream));
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->aux_stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->out_stream));
+    // the context's stream stays the timeline of the context: what is enqueued on it next sees this step complete
+    HIPCHK(ctx, hipEventRecord(ctx->aux_event, ctx->out_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_event, 0));
     return track_prn_verdict(ctx);
   }
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));

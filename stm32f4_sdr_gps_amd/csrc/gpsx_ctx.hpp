@@ -31,8 +31,10 @@ struct gpsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  hipStream_t aux_stream = nullptr;   // second stream of the chunked tracking step (very many channels), created on first use
+  // the pipelined tracking step of very many channels: correlator and copy-out streams, events between the stages
+  hipStream_t aux_stream = nullptr, out_stream = nullptr;
   hipEvent_t aux_event = nullptr;
+  std::vector<hipEvent_t> chunk_events;
   uint32_t *h_bad_prn = nullptr;      // page-locked flag the tracking kernels raise on a PRN outside 1..210
   uint32_t *d_bad_prn = nullptr;      // its device address
   std::string err;
