@@ -118,9 +118,9 @@ int gpsx_event_destroy(gpsx_ctx *ctx, void *event);
  * A ring of n_slots 1 ms blocks in pinned host memory with a mirror in HBM.  The producer fills the write slot and
  * commits it -- what the DMA interrupt does: the ready pointer moves on, the packet counter counts, and the block goes
  * to the device by an asynchronous copy from pinned memory, enqueued on the context's stream (the call does not wait).
- * Host entry points of this library (gpsx_acq_grid, gpsx_acq_jobs, gpsx_track_epl_batch above 65536 channels, and the
+ * Host entry points of this library (gpsx_acq_grid, gpsx_acq_jobs, gpsx_track_epl_batch above 32768 channels, and the
  * reference-named step calls on top of them) recognise a pointer into a committed part of the ring and read the HBM
- * mirror instead of copying the block again.  (The per-millisecond tracking step of up to 65536 channels is one captured
+ * mirror instead of copying the block again.  (The per-millisecond tracking step of up to 32768 channels is one captured
  * graph that stages its own 2 KB block next to the channel states: one launch beats a saved 2 KB copy.)  The format is the context's if_format at creation time. */
 typedef struct gpsx_capture gpsx_capture;
 int            gpsx_capture_create(gpsx_ctx *ctx, int n_slots, gpsx_capture **cap);      /* 1 <= n_slots <= 4096 */
