@@ -895,7 +895,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __shared__ MxShared sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values in SGPRs)
-  const int ex = prm.experiment;   // timing ablations: 1 = no epilogue, 2 = no MFMA, 4 = no stagger, 8 = no vector prep
+  const int ex = prm.experiment;   // timing ablations: 1 = no epilogue, 2 = no MFMA (noise-sized counts instead), 4 = both roles in
+                                   // step, 8 = no vector building, 16 = raised priority for the MFMA passes
   const int role = (ex & 4) ? 0 : wave >> 2;             // waves w and w + 4 share a SIMD: half a step apart
   const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
 
