@@ -344,7 +344,7 @@ def main():
         reps = 12
 
         def pcie_loop(n_ctx):
-            warm = 2 * n_ctx                # every context's first calls (tables, scratch arena, first DMA into its pinned pages)
+            warm = max(6, 2 * n_ctx)        # every context's first calls (tables, scratch arena, first DMA into its pinned pages)
             for i in range(reps + warm):
                 if i == warm:
                     for e2 in engs[:n_ctx]:
