@@ -549,7 +549,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   const bool fine = (ctx->algo == kAlgoPoly || ctx->algo == kAlgoMx) && n_bits == 8 && !inspect;
   // The matrix-core kernel (one 512-thread workgroup per (search, Doppler, 32 PRNs), one per CU) is the faster one at
   // every launch size measured, a single capture included (0.155 ms against 0.166 ms, profiles/r02_launch_size_sweep.json).
-  bool mx = fine && ctx->algo == kAlgoMx;
+  // (and serves the byte-phase grid as sample offsets 0 and 8 of the fine one: ten of its seventeen passes, two epilogues)
+  bool mx = ctx->algo == kAlgoMx && !inspect && (n_bits == 8 || g->n_ms == 1);
   if (mx) {
     const long clusters = acq_mx_clusters(prm);
     // n_ms > 1, few searches: a workgroup per (cluster, block) instead of a workgroup walking its cluster's blocks -- a lone

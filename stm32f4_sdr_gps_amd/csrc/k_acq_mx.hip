@@ -950,6 +950,11 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   u32 witness = 0;   // S16: OR of every sum this lane stored
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const int n_ms = MULTI ? prm.n_ms : 1;
+  // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid:
+  // the passes stop after the one that leads to offset 8, and only those two offsets have an epilogue -- the recurrence
+  // steps between them are matrix-pipe work alone.
+  const bool byte_mode = MODE == kMxSingle && prm.n_bits == 1;
+  const int n_pass = byte_mode ? 10 : kPasses;
 #pragma unroll 1
   for (int ms = 0; ms < n_ms; ms++) {
     const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
@@ -982,15 +987,15 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     // but their own pace between the halves: ONE barrier per step, where all eight waves build the vector of pass p + 1
     // into the buffer that both roles read during step p - 1.
 #pragma unroll 1
-    for (int hs = 0; hs <= 2 * kPasses; hs++) {
+    for (int hs = 0; hs <= 2 * n_pass; hs++) {
       if ((hs & 1) == 0) {
         __syncthreads();
         const int p_vec = (hs >> 1) + 1;
-        if (p_vec >= 2 && p_vec < kPasses && !(ex & 8))
+        if (p_vec >= 2 && p_vec < n_pass && !(ex & 8))
           mx_vector_build(sh, p_vec, tid);
       }
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
-      const bool active = x >= 0 && x < 2 * kPasses;
+      const bool active = x >= 0 && x < 2 * n_pass;
       const int p = x >> 1;
       if (active && (x & 1) == 0) {
         if constexpr (MULTI) {
@@ -1013,7 +1018,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
                              ((size_t)((search * prm.n_ms + ms_store) * prm.n_prn + 32 * set) * prm.n_dopp + dopp) * (16 * 1024);
           mx_epilogue_store(lane, q0_tile, p - 1, acc, group_mask, plane0, (size_t)prm.n_dopp * (16 * 1024), 32 * set, prm.n_prn);
         }
-      } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
+      } else if (active && (x & 1) && p >= 1 && !(ex & 1) && (!byte_mode || p == 1 || p == 9)) {
         if (!MULTI)
           mx_epilogue_single(sh, lane, kq, p - 1, acc);
         else if (!ms_last)
@@ -1056,8 +1061,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       k = vals[l] > k ? vals[l] : k;
       t += vals[l];
     }
-    if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn) {
-      uint2 *pk = reinterpret_cast<uint2 *>(&peaks[((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * 8 + b]);
+    if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn && b < prm.n_bits) {
+      uint2 *pk = reinterpret_cast<uint2 *>(&peaks[((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits + b]);
       if (which == 0) {
         const u32 max_val = k >> 11;
         pk[0] = make_uint2(max_val, max_val ? 2047u - (k & 2047u) : 0u);   // gpsx_peak_t: max_val, phase

@@ -3,9 +3,9 @@
 (-7000 .. +7000 Hz @ 500 Hz, PM/GPS/acquisition.c:285-289) x 2046 byte-granular code phases, replica bit shift 0 --
 what acquisition_freq_search sweeps on the MCU, one (PRN, Doppler) per captured millisecond.
 
-Device-resident captures, HIP events on the engine's stream around K launches of gpsx_acq_grid_dev.  The byte-phase
-mode evaluates sample offsets t0 = 0 and 8 only, so there is no recurrence to exploit: it runs the direct dot8 kernel.
-Prints one JSON line.
+Device-resident captures, HIP events on the engine's stream around K launches of gpsx_acq_grid_dev.  The byte phases are
+sample offsets t0 = 0 and 8 of the fine grid: the matrix-core kernel runs the ten passes that lead there and two
+epilogues (GPSX_ACQ_ALGO=dot8: round 1's direct kernel).  Prints one JSON line.
 """
 import argparse
 import ctypes as C
@@ -63,7 +63,7 @@ def main():
     print(json.dumps({"metric": "acquisition hypotheses/sec, reference-native grid (32 PRN x 29 Doppler x 2046 byte phases)",
                       "value": hyp / (ms * 1e-3), "unit": "hypotheses/s", "ms_per_launch": ms,
                       "searches_per_launch": args.searches, "hypotheses_per_launch": hyp, "device": name,
-                      "kernel": "gpsx::k_acq<8,false,dot8> (byte-phase mode)",
+                      "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode() + " (byte-phase mode)",
                       "strongest_of_capture_0": {"prn": int(prns[p]), "doppler_hz": int(-7000 + 500 * d),
                                                  "max_val": int(k0[p, d] >> 14)},
                       "mcu_equivalent": "one (PRN, Doppler) per ~0.2 s on STM32F407 (SURVEY.md 3.2): 928 pairs = ~186 s "
