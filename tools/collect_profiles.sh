@@ -8,6 +8,8 @@ for p in "bench:bench_1gpu" "bench_64:bench_1gpu_64_captures" "bench_10ms:bench_
   tail -1 gpurun_out/${T}_${p%%:*}.json > profiles/${T}_${p##*:}.json
 done
 cp gpurun_out/${T}_tracking_latency.json profiles/${T}_tracking_latency.json
+[ -s gpurun_out/${T}_native.json ] && cp gpurun_out/${T}_native.json profiles/r02_native_grid_32x29x2046.json
+[ -s gpurun_out/${T}_pcie_probe.txt ] && grep contexts gpurun_out/${T}_pcie_probe.txt > profiles/r02_pcie_probe.txt
 if [ -f gpurun_out/${T}_sweep.txt ]; then
 python - "$T" <<'PY'
 import json, sys
