@@ -335,6 +335,10 @@ def main():
     # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
     # rotation through gpsx_acq_grid_async, so a call's transfers overlap the others' sweeps -- what a host streaming
     # captures through the engine does (tools/pcie_probe.py: 1 / 2 / 3 / 4 contexts = 0.98 / 1.02 / 1.13 / 1.18 x 10^12).  `serial` is the one-context, synchronous gpsx_acq_grid() loop of round 1.
+    # the secondary metric first: the legs below leave ~100 MB of page-locked host memory and four contexts' worth of
+    # state behind, and the tracking step measured after them is 60 us slower
+    tracking = tracking_channels(capi.Engine, dev_index) if (not args.no_tracking and world == 1) else None
+
     pcie = None
     if world == 1 and n_ms == 1 and not args.no_pcie:
         g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
@@ -592,8 +596,8 @@ def main():
             line["single_search"] = single
         if local_ref is not None:
             line["per_gpu_unsharded"] = local_ref
-        if not args.no_tracking and world == 1:
-            line["tracking"] = tracking_channels(capi.Engine, dev_index)
+        if tracking is not None:
+            line["tracking"] = tracking
         if not args.no_cpu_baseline and world == 1:
             line.update(cpu_baseline(blocks, args.cpu_budget_s))
             line["cpu_host"] = {"logical_cpus": os.cpu_count()}
