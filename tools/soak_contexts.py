@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Create / use / destroy contexts in a loop and watch device memory: every buffer a context grows (code tables, arena,
-scratch planes, multi-block scratch, Doppler-shared work buffers, capture rings, tracking graphs) must go with it."""
+scratch planes, multi-block scratch, capture rings, tracking graphs) must go with it."""
 import ctypes as C
 import os
 import sys
@@ -24,7 +24,7 @@ def main():
     prns = np.arange(1, 33, dtype=np.uint8)
     base = None
     for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
-        os.environ["GPSX_ACQ_ALGO"] = ("poly", "ds", "dot8")[it % 3]
+        os.environ["GPSX_ACQ_ALGO"] = ("poly", "mx", "dot8")[it % 3]
         os.environ["GPSX_ACQ_MS_MODE"] = ("walk", "blocks")[it % 2]
         e = capi.Engine(0)
         e.acq_grid(stream[:8], prns, n_search=2, n_ms=4, search_stride_blocks=4)
@@ -40,8 +40,9 @@ def main():
             cap.close()          # otherwise the context closes it
         e.close()
         now = free_mb()
-        if it == 2:
-            base = now           # after the runtime's own one-time allocations
+        if it == 6:
+            base = now           # after the runtime's own one-time allocations: every (kernel, form) pair has run once
+                                 # (code objects, and the queue's scratch for the kernels that spill)
         if base is not None:
             assert abs(now - base) < 64, f"iteration {it}: free memory moved by {now - base:.0f} MiB"
     print(f"ok: free device memory steady at {now:.0f} MiB")
