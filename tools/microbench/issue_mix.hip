@@ -54,6 +54,14 @@ __device__ __forceinline__ void valu_iter(float (&x)[8], float c)
       asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(r) : "v"(c));
     else if (OP == 11)
       asm volatile("v_or3_b32 %0, %0, %1, %1" : "+v"(r) : "v"(c));
+    else if (OP == 12)
+      asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r) : "v"(c));
+    else if (OP == 13)
+      asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(r) : "v"(c));
+    else if (OP == 14)   // (distance >= 2: the dot instructions need a wait state before a dependent read)
+      asm volatile("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(r) : "v"(c));
+    else if (OP == 15)
+      asm volatile("v_dot2c_f32_f16 %0, %1, %1" : "+v"(r) : "v"(c));
   }
 }
 
@@ -180,5 +188,9 @@ int main()
   run<9, 8, 192>("v_pk_add_u16 clamp", n_wg, it);
   run<10, 8, 192>("v_perm_b32", n_wg, it);
   run<11, 8, 192>("v_or3_b32", n_wg, it);
+  run<12, 8, 192>("v_cvt_pkrtz_f16_f32", n_wg, it);
+  run<13, 8, 192>("v_pk_max_f16", n_wg, it);
+  run<14, 8, 192>("v_dot2_f32_f16", n_wg, it);
+  run<15, 8, 192>("v_dot2c_f32_f16", n_wg, it);
   return 0;
 }
