@@ -154,8 +154,9 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
                 : std::strcmp(a, "dot8") == 0 ? kAlgoDot8
                 : std::strcmp(a, "poly") == 0 ? kAlgoPoly
                                               : kAlgoMx;
-    ctx->algo_forced = true;
   }
+  if (ctx->seg_force && ctx->algo == kAlgoMx)
+    ctx->algo = kAlgoPoly;   // $GPSX_ACQ_SEG names a form of the polyphase kernel: it selects that kernel too
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -176,12 +177,14 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
             hipMalloc((void **)&ctx->d_bits_all, (size_t)slots * 32 * 4) == hipSuccess &&
             hipMalloc((void **)&ctx->d_cw_all, (size_t)slots * kCodeWords * 4) == hipSuccess &&
             hipMalloc((void **)&ctx->d_cw8_all, (size_t)slots * (kCodeWords / 2) * 4) == hipSuccess &&
+            hipMalloc((void **)&ctx->d_trk_rep, (size_t)slots * kTrackRepStride * 4) == hipSuccess &&
             hipMemcpyAsync(d_prns, prns.data(), slots, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
-            hipHostMalloc((void **)&ctx->h_bad_prn, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+            hipHostMalloc((void **)&ctx->h_bad_prn, 2 * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void **)&ctx->d_bad_prn, ctx->h_bad_prn, 0) == hipSuccess;
   if (ok) {
-    *ctx->h_bad_prn = 0;
+    ctx->h_bad_prn[0] = ctx->h_bad_prn[1] = 0;
     launch_build_codes(ctx->stream, d_prns, slots, 1, ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all);
+    launch_build_track_rep(ctx->stream, ctx->d_bits_all, slots, ctx->d_trk_rep);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
   }
   if (d_prns)
@@ -205,7 +208,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
   track_graph_release(ctx);
   if (ctx->stream)
     (void)hipStreamSynchronize(ctx->stream);
-  void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_grid_prns, ctx->d_grid_chips,
+  void *bufs[] = {ctx->d_chips_all, ctx->d_bits_all, ctx->d_cw_all, ctx->d_cw8_all, ctx->d_trk_rep, ctx->d_grid_prns, ctx->d_grid_chips,
                   ctx->d_grid_bits, ctx->d_grid_cw, ctx->d_grid_cw8, ctx->d_grid_mx_a, ctx->d_grid_mx_t, ctx->d_arena, ctx->d_acc, ctx->d_energy};
   for (void *p : bufs)
     if (p)
@@ -233,8 +236,8 @@ int gpsx_synchronize(gpsx_ctx *ctx)
 {
   if (int rc = use_device(ctx)) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->h_bad_prn && *ctx->h_bad_prn) {   // a gpsx_track_epl_batch_dev since the last look
-    *ctx->h_bad_prn = 0;
+  if (ctx->h_bad_prn && ctx->h_bad_prn[1]) {   // a gpsx_track_epl_batch_dev since the last look (its own flag: the
+    ctx->h_bad_prn[1] = 0;                     // host-pointer step calls in between neither see nor clear it)
     return fail(ctx, GPSX_EINVAL, "a tracking batch held a prn outside 1..210 (correlated against the empty code)");
   }
   return GPSX_OK;
@@ -536,10 +539,12 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.win_stop = g->win_stop;
   prm.if_format = ctx->if_format;
   prm.if_hz = ctx->if_hz;
+#ifdef GPSX_MX_ABLATIONS   // timing ablations of k_acq_mx (results are then wrong): tools/build_variant.sh -DGPSX_MX_ABLATIONS only
   {
     static const char *ex = std::getenv("GPSX_MX_EXPERIMENT");
     prm.experiment = ex ? std::atoi(ex) : 0;
   }
+#endif
   prm.jobs = nullptr;
   prm.peaks = d_peaks;
   prm.per_ms = d_per_ms;
@@ -753,7 +758,7 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, ctx->if_hz, d_st, n_ch,
-                   ctx->d_chips_all, ctx->d_bits_all, d_iq_out, ctx->d_bad_prn);
+                   ctx->d_chips_all, ctx->d_bits_all, ctx->d_trk_rep, d_iq_out, ctx->d_bad_prn + 1);
   LAUNCHCHK(ctx, "k_track_epl");
   return GPSX_OK;
 }
@@ -832,7 +837,7 @@ gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch_asked, size_t 
     if (ok) {
       ok = hipMemcpyAsync(t.d_buf, t.h_in, t.in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
       launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, ctx->if_hz, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all,
-                       d_iq, ctx->d_bad_prn);
+                       ctx->d_trk_rep, d_iq, ctx->d_bad_prn);
       ok = ok && hipGetLastError() == hipSuccess &&
            hipMemcpyAsync(t.h_out, d_st, t.out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
       ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;
@@ -864,13 +869,46 @@ static int track_prn_verdict(gpsx_ctx *ctx)
   return fail(ctx, GPSX_EINVAL, "prn must be 1..210 (the channel was correlated against the empty code)");
 }
 
+// The side streams and events of the chunked tracking step, created on first use.  Failure-atomic: everything is made into
+// locals and committed to the context only when all of it exists, so a half-built set is never seen by a later call.
+static int track_pipeline_init(gpsx_ctx *ctx)
+{
+  constexpr int kMaxChunks = 16;
+  if (ctx->aux_stream)
+    return GPSX_OK;
+  hipStream_t aux = nullptr, out = nullptr;
+  hipEvent_t aux_event = nullptr;
+  std::vector<hipEvent_t> events(2 * kMaxChunks, nullptr);
+  bool ok = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&out, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&aux_event, hipEventDisableTiming) == hipSuccess;
+  for (size_t i = 0; ok && i < events.size(); i++)
+    ok = hipEventCreateWithFlags(&events[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    const hipError_t e = hipGetLastError();
+    for (hipEvent_t ev : events)
+      if (ev) (void)hipEventDestroy(ev);
+    if (aux_event) (void)hipEventDestroy(aux_event);
+    if (out) (void)hipStreamDestroy(out);
+    if (aux) (void)hipStreamDestroy(aux);
+    return fail(ctx, GPSX_EIO, std::string("tracking pipeline streams/events: ") + hipGetErrorString(e));
+  }
+  ctx->aux_stream = aux;
+  ctx->out_stream = out;
+  ctx->aux_event = aux_event;
+  ctx->chunk_events = std::move(events);
+  return GPSX_OK;
+}
+
 int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out)
 {
   if (int rc = use_device(ctx)) return rc;
   if (!if_block || !st || !iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
-  // (the PRNs are checked by the kernel: a host loop over 400 000 states costs a sixth of the millisecond)
-  *ctx->h_bad_prn = 0;
+  // (the PRNs are checked by the kernel: a host loop over 400 000 states costs a sixth of the millisecond; flag 0 is this
+  //  entry point's own -- every call waits for its kernels and reads it before it returns, so nothing can be pending in it;
+  //  a gpsx_track_epl_batch_dev still in flight reports through flag 1 and gpsx_synchronize)
+  ctx->h_bad_prn[0] = 0;
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
   // The real-time shape (a few channels to a few thousand, every millisecond): the whole step is ONE graph launch
   // between two small host copies into / out of pinned staging, instead of two copies in, a launch, two copies out.
@@ -914,31 +952,35 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   }();
   const int kChunks = kChunksEnv ? kChunksEnv : (n_ch >= 393216 ? 6 : 4);
   if (n_ch >= kChunkFrom) {
-    if (!ctx->aux_stream) {
-      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-      HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking));
-      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_event, hipEventDisableTiming));
-      ctx->chunk_events.resize(2 * kMaxChunks, nullptr);
-      for (hipEvent_t &e : ctx->chunk_events)
-        HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    if (int rc = track_pipeline_init(ctx)) return rc;
     const int per = ((n_ch + kChunks - 1) / kChunks + 3) & ~3;
+    // (a failure inside the loop must not return while copies into the caller's arrays are still in flight on the side streams)
+#define CHUNKCHK(call)                                                                           \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (void)hipStreamSynchronize(ctx->aux_stream);                                               \
+      (void)hipStreamSynchronize(ctx->out_stream);                                               \
+      return fail(ctx, GPSX_EIO, std::string(#call) + ": " + hipGetErrorString(e_));            \
+    }                                                                                            \
+  } while (0)
     int c = 0;
     for (int first = 0; first < n_ch; c++, first += per) {
       const int n = std::min(per, n_ch - first);
       hipEvent_t arrived = ctx->chunk_events[2 * c], done = ctx->chunk_events[2 * c + 1];
-      HIPCHK(ctx, hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
-      HIPCHK(ctx, hipEventRecord(arrived, ctx->stream));      // (also: the block and everything before it on the stream)
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, arrived, 0));
+      CHUNKCHK(hipMemcpyAsync(d_st + first, st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
+      CHUNKCHK(hipEventRecord(arrived, ctx->stream));      // (also: the block and everything before it on the stream)
+      CHUNKCHK(hipStreamWaitEvent(ctx->aux_stream, arrived, 0));
       launch_track_epl(ctx->aux_stream, d_if, ctx->if_format, ctx->if_hz, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all,
-                       d_iq + (size_t)first * 6, ctx->d_bad_prn);
-      LAUNCHCHK(ctx, "k_track_epl");
-      HIPCHK(ctx, hipEventRecord(done, ctx->aux_stream));
-      HIPCHK(ctx, hipStreamWaitEvent(ctx->out_stream, done, 0));
-      HIPCHK(ctx, hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->out_stream));
-      HIPCHK(ctx, hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost,
-                                 ctx->out_stream));
+                       ctx->d_trk_rep, d_iq + (size_t)first * 6, ctx->d_bad_prn);
+      CHUNKCHK(hipGetLastError());
+      CHUNKCHK(hipEventRecord(done, ctx->aux_stream));
+      CHUNKCHK(hipStreamWaitEvent(ctx->out_stream, done, 0));
+      CHUNKCHK(hipMemcpyAsync(st + first, d_st + first, n * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->out_stream));
+      CHUNKCHK(hipMemcpyAsync(iq_out + (size_t)first * 6, d_iq + (size_t)first * 6, (size_t)n * 12, hipMemcpyDeviceToHost,
+                              ctx->out_stream));
     }
+#undef CHUNKCHK
     HIPCHK(ctx, hipStreamSynchronize(ctx->out_stream));
     // the context's stream stays the timeline of the context: what is enqueued on it next sees this step complete
     HIPCHK(ctx, hipEventRecord(ctx->aux_event, ctx->out_stream));
@@ -946,7 +988,9 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
     return track_prn_verdict(ctx);
   }
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
-  if (int rc = gpsx_track_epl_batch_dev(ctx, d_if, d_st, n_ch, d_iq)) return rc;
+  launch_track_epl(ctx->stream, d_if, ctx->if_format, ctx->if_hz, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all, ctx->d_trk_rep, d_iq,
+                   ctx->d_bad_prn);
+  LAUNCHCHK(ctx, "k_track_epl");
   HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(iq_out, d_iq, (size_t)n_ch * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -46,14 +46,15 @@ struct gpsx_ctx {
   uint32_t *d_bits_all = nullptr;    // [211][32]
   uint32_t *d_cw_all = nullptr;      // [211][256] (group of 1)
   uint32_t *d_cw8_all = nullptr;     // [211][128] (group of 1)
+  uint32_t *d_trk_rep = nullptr;     // [211][kTrackRepStride]: replica bit streams for the tracking correlators
   int if_format = GPSX_IF_1BIT;
   int if_hz = GPSX_IF_HZ;             // gpsx_config_t.if_hz
-  int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: matrix cores when the launch fills the chip, else
-                                           // poly) | poly | dot8 | sad, for A/B measurements
-  bool algo_forced = false;                // $GPSX_ACQ_ALGO was given: no size heuristics
+  int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: the matrix-core kernel, at every launch size) | poly |
+                                           // dot8 | sad, for A/B measurements and the parity tests of the alternative kernels
   uint32_t *d_acc = nullptr;         // poly: packed-key and sum planes merged across workgroups
   size_t acc_entries = 0;
-  int seg_force = 0;                 // $GPSX_ACQ_SEG = 4 | 8 | 16: force the polyphase kernel's offsets per workgroup (tests, A/B)
+  int seg_force = 0;                 // $GPSX_ACQ_SEG = 4 | 8 | 16: the polyphase kernel at that many offsets per workgroup (tests, A/B);
+                                     // implies $GPSX_ACQ_ALGO=poly unless another algorithm was named
   int ms_mode = 0;                   // $GPSX_ACQ_MS_MODE = walk | blocks: force one multi-block form (tests, A/B); 0 = by size
   uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
   size_t energy_bytes = 0;

@@ -1,5 +1,6 @@
 // gpsx_group.hip -- the sharded sweep inside one process: contexts joined by RCCL communicators (include/gpsx.h), host code.
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // declarations only: the library is dlopen'ed
 
 #include <new>
 
@@ -12,16 +13,18 @@ using namespace gpsx_host;
 namespace {
 
 // the handful of RCCL entry points used, resolved at run time so that libgpsx.so itself does not depend on librccl
-// (a process that drives the ranks through torch.distributed already carries its own copy)
+// (a process that drives the ranks through torch.distributed already carries its own copy).  Types, prototypes and the
+// enumerators (ncclInt64, ncclMax) come from the image's <rccl/rccl.h> at build time -- nothing is restated here.
 struct Rccl {
-  typedef void *comm_t;
-  int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
-  int (*CommDestroy)(comm_t) = nullptr;
-  int (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(int) = nullptr;
-  static constexpr int kInt64 = 4, kMax = 2;   // ncclInt64, ncclMax (rccl.h)
+  typedef ncclComm_t comm_t;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  static constexpr ncclDataType_t kInt64 = ncclInt64;
+  static constexpr ncclRedOp_t kMax = ncclMax;
   bool ok = false;
 };
 
@@ -76,8 +79,8 @@ int gpsx_group_create(gpsx_ctx *const *ctxs, int n, gpsx_group **out)
     return fail(c0, GPSX_ENOMEM, "out of host memory");
   grp->ctxs.assign(ctxs, ctxs + n);
   grp->comms.assign(n, nullptr);
-  const int rc = r.CommInitAll(grp->comms.data(), n, devs.data());
-  if (rc != 0) {
+  const ncclResult_t rc = r.CommInitAll(grp->comms.data(), n, devs.data());
+  if (rc != ncclSuccess) {
     delete grp;
     return fail(c0, GPSX_EIO, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
   }
@@ -117,13 +120,13 @@ int gpsx_acq_grid_sharded(gpsx_group *grp, const gpsx_acq_grid_t *g, const void 
   // the one exchange step of the path: max over ranks of (energy << 14 | 16383 - phase), entries of foreign units are 0
   Rccl &r = rccl();
   const size_t n_keys = gpsx_acq_keys_count(g);
-  int rc = r.GroupStart();
-  for (int i = 0; i < n && rc == 0; i++) {
+  ncclResult_t rc = r.GroupStart();
+  for (int i = 0; i < n && rc == ncclSuccess; i++) {
     (void)hipSetDevice(grp->ctxs[i]->device);
     rc = r.AllReduce(d_keys[i], d_keys[i], n_keys, Rccl::kInt64, Rccl::kMax, grp->comms[i], grp->ctxs[i]->stream);
   }
-  const int rc_end = r.GroupEnd();
-  if (rc != 0 || rc_end != 0)
-    return fail(grp->ctxs[0], GPSX_EIO, std::string("ncclAllReduce: ") + r.GetErrorString(rc != 0 ? rc : rc_end));
+  const ncclResult_t rc_end = r.GroupEnd();
+  if (rc != ncclSuccess || rc_end != ncclSuccess)
+    return fail(grp->ctxs[0], GPSX_EIO, std::string("ncclAllReduce: ") + r.GetErrorString(rc != ncclSuccess ? rc : rc_end));
   return GPSX_OK;
 }

@@ -21,8 +21,8 @@ constexpr int kMaxMs = 128;       // keeps (energy << 11 | phase) and the window
 constexpr int kAlgoSad = 0;       // main loop: v_msad_u8 on 8-bit block sums, 4 chips per instruction
 constexpr int kAlgoDot8 = 1;      // main loop: v_dot8_u32_u4 on 4-bit block sums, 8 chips per instruction
 constexpr int kAlgoPoly = 2;      // fine grid only: polyphase recurrence across the 16 sample offsets, AND + popcount
-constexpr int kAlgoMx = 4;        // fine grid only: the same recurrence as a Toeplitz GEMM on the matrix cores, MX-FP4 (default for
-                                  // launches that fill the chip; smaller ones take the polyphase VALU kernel)
+constexpr int kAlgoMx = 4;        // the same recurrence as a Toeplitz GEMM on the matrix cores, MX-FP4: the default at every
+                                  // launch size, for fine grids and single-block byte-phase grids without inspection outputs
 
 // One search = one workgroup pass: `count` (<= group size) consecutive code-table slots, one carrier frequency,
 // one replica bit shift, n_ms consecutive blocks.
@@ -45,7 +45,8 @@ struct AcqParams {
   int32_t win_start, win_stop;
   int32_t if_format;        // GPSX_IF_1BIT / GPSX_IF_2BIT_SM
   int32_t if_hz;            // gpsx_config_t.if_hz: centre of the Doppler axis
-  int32_t experiment;       // $GPSX_MX_EXPERIMENT: ablations of k_acq_mx for timing (results are then wrong); 0 in production
+  int32_t experiment;       // ablations of k_acq_mx for timing (results are then wrong); always 0 unless the library was built
+                            // with -DGPSX_MX_ABLATIONS, which alone makes gpsx_api.hip read $GPSX_MX_EXPERIMENT
   // explicit job list (job mode)
   const AcqJobRec *jobs;
   // outputs (optional ones may be null)
@@ -119,8 +120,12 @@ void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int firs
 
 // K2+K3+K5 tracking correlators, one workgroup per channel
 // d_bad_prn (may be null): set to 1 by a channel whose PRN is outside 1..210 (it correlates against the empty code)
+// d_trk_rep: the replica bit streams of every PRN slot (launch_build_track_rep), read by the wave-per-channel form
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
-                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq, uint32_t *d_bad_prn);
+                      const uint8_t *d_chips, const uint32_t *d_chipbits, const uint32_t *d_trk_rep, int16_t *d_iq,
+                      uint32_t *d_bad_prn);
+constexpr int kTrackRepStride = 1032;   // words per PRN row of d_trk_rep
+void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n_slots, uint32_t *d_rep);
 constexpr int kTrackPadPrn = -2147483647 - 1;   // gpsx_trk_state_t.prn of a padding channel: the empty code, not an error
 // N3: 2-bit sign/magnitude samples -> two 1-bit planes
 void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag);

@@ -270,200 +270,290 @@ __global__ __launch_bounds__(256) void k_track_epl(const uint8_t *__restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K5, many channels: one WAVE per tracking channel and millisecond, four channels per workgroup (from 2048 channels on).
+// K5, many channels (from 2048 on): one WAVE per tracking channel and millisecond, `cpw` channels per wave one after the
+// other, four waves per workgroup.
 //   fine = (int16) code_phase_fine;  replica shift b = fine & 7;  prompt offset = fine / 8, early = prompt - 1
 //   (wraps to 2045), late = prompt + 1 (wraps to 0)                                   PM/GPS/tracking.c:115-130
 //   carrier NCO continues from if_freq_accum at (float)IF + if_freq_offset_hz and is stored back  gps_misc.c:244-274
-// Sample-stream formulation: gps_mult_and_summ at byte offset o pairs replica word i with data bytes (o + 2 i) mod 2046
-// (PM/GPS/gps_misc.c:60-90), i.e. replica BIT s with wiped sample (8 o + s) mod 16368 -- a rotation of the stream.  The
-// count over all 1023 words is therefore  pop(rot(D, 8 o) ^ R)  on 32-bit words: 512 XOR + popcount pairs per stream and
-// offset where the 16-bit form needs 1023 (plus their masks).  R, the replica as a bit stream -- chips delayed by b
-// samples, its first b bits zero (quirk Q5) -- is never stored: word j is cut from chips 2 j - 1 .. 2 j + 1 of the
-// packed code.  The wiped stream sits in LDS as 32-bit words with three words of continuation past the wrap (16368 =
-// 511.5 words: after the wrap the stream is 16 bits out of step), so any window starting before the wrap is two
-// neighbouring words.  Odd offsets then take back the two words the reference skips: p1 = (2045 - o) / 2, which pairs with
-// data bytes (2045, 0), and word 1022 (unless it is p1).  The four channels of a workgroup share one staging of the
-// block's sign plane (the 2-bit unpack happens once per workgroup, not once per channel).
-// r1 -> r2: 1231 -> 546 vector instructions per channel, 408 -> 223 us for 212 992 channels (profiles/r02_track_*).
+// Round 3 formulation (r2's kernel: 523 vector instructions per channel, vector-issue bound):
+//  * gps_mult_and_summ at byte offset o pairs replica bit s with wiped sample (8 o + s) mod 16368
+//    (PM/GPS/gps_misc.c:60-90): the count is  pop(D ^ rot(R, -8 o))  -- the DATA stay where they are, word-aligned, in the
+//    registers of the lane that mixed them (word j = x[j] ^ carrier(quadrant of acc + j step): no LDS round trip, no second
+//    period, no funnel shift per stream and offset), and the REPLICA is what gets rotated: one stream for I and Q.
+//  * The replica as a circular bit stream comes from a table in global memory (k_build_track_rep: per PRN the chips
+//    expanded to 16 samples, two and a bit periods back to back so that any window of one period is contiguous; 4 KB per
+//    PRN, L2-resident): a lane reads the six words that cover its four for all three offsets (Early / Prompt / Late sit 8
+//    samples apart) and cuts them with 5 + 4 + 4 funnel shifts -- no replica arithmetic at all.
+//  * What the reference's quirks change against that circular count touches at most three 16-bit words per offset: the
+//    first b samples of the non-circular replica shift (Q5) and the two words odd byte offsets skip (Q3).  They are not
+//    computed per channel by a whole wave: lane 3 c + k of the wave computes them for (channel c, offset k) after the
+//    loop -- as it computed the offsets, NCO step and table positions before it -- so every wave-uniform quantity of a
+//    channel costs 1/cpw of an instruction, and the results leave in one coalesced store.
+//  Per channel: 8 words x (5 wipe-off + 12 xor/popcount) + 26 funnel shifts + 3 reductions; see DESIGN.md 4.3.
+// The table: bit p of a PRN's row = chip[(p mod 16368) >> 4], kTrackRepWords words (+ padding to the row stride).
+constexpr int kTrackRepWords = 1028;    // 2 periods (1023 words) + what the last windows read past them
+static_assert(kTrackRepWords <= kTrackRepStride, "row stride");
+
+__global__ void k_build_track_rep(const u32 *__restrict__ chipbits_all, int n_slots, u32 *__restrict__ rep)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_slots * kTrackRepStride)
+    return;
+  const int slot = idx / kTrackRepStride, w = idx - slot * kTrackRepStride;
+  u32 v = 0;
+  if (w < kTrackRepWords) {
+    const u32 *cb = chipbits_all + (size_t)slot * 32;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int c = ((32 * w + 16 * half) % kSamples) >> 4;   // word boundaries are chip boundaries in every period
+      if ((cb[c >> 5] >> (c & 31)) & 1u)
+        v |= 0xFFFFu << (16 * half);
+    }
+  }
+  rep[idx] = v;
+}
+
+void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n_slots, uint32_t *d_rep)
+{
+  const int n = n_slots * kTrackRepStride;
+  hipLaunchKernelGGL(k_build_track_rep, dim3((n + 255) / 256), dim3(256), 0, s, d_chipbits_all, n_slots, d_rep);
+}
+
 namespace {
 
-struct TrackLds {
-  // the wiped streams as (I, Q) word pairs, two periods back to back (16368 samples = 511.5 words: the second period sits 16
-  // bits out of step), one zero pair in front: pair 1 + w = word w; words 0..510 mixed, the low half of 511 = the sixteen
-  // never-mixed (zero) samples, its high half = samples 0..15 again, and so on to word 1022.  Any 32-bit window of the
-  // circular stream that starts in the first period is two neighbouring pairs: one 16-byte read serves I and Q.
-  uint2 dd[1026];
-  u32 cb[36];       // packed chips with one zero word in front (chip -1 = 0) and zeros behind
-};
+struct alignas(4) TrkW4 { u32 w[4]; };   // four table words at a dword-aligned address: one global_load_dwordx4
+struct alignas(4) TrkW2 { u32 w[2]; };
 
-__device__ __forceinline__ uint4 lds_read_pairs(const uint2 *p)   // p[0], p[1]: 8-byte aligned, one LDS instruction
+// (I byte, Q byte) `pos` (0..2045) of the wiped streams of a channel, recomputed from the staged block: bytes 2044 / 2045 are
+// the sixteen samples the NCO loop never mixes and read as zero (PM/GPS/gps_misc.c:229,261)
+__device__ __forceinline__ uint2 trk_dbyte(const u32 *s_x, const uint2 *s_carrier, u32 acc0, u32 step, int pos)
 {
-  uint4 v;
-  __builtin_memcpy(&v, __builtin_assume_aligned(p, 8), 16);
-  return v;
+  const int w = pos >> 2;
+  const u32 x = s_x[w];
+  const uint2 c = s_carrier[(acc0 + step * (u32)w) >> 30];
+  const u32 sh = 8u * ((u32)pos & 3u);
+  uint2 r = uint2{((x ^ c.x) >> sh) & 0xFFu, ((x ^ c.y) >> sh) & 0xFFu};
+  if (pos >= 2 * kWords32 * 2)
+    r = uint2{0u, 0u};
+  return r;
+}
+
+// acc + pop(x): v_bcnt_u32_b32's own addend (left to itself the compiler counts into a zero and adds three at a time)
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc)
+{
+  u32 r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
+// pop(x ^ carrier ^ replica window) for NK offsets 8 samples apart (NK = 3: Late, Prompt, Early from ONE six-word read per
+// four data words) or one offset (NK = 1): `row` = the PRN's table row advanced to the word of the window's first bit,
+// `sh` = that bit's position in it.  cnt[k0 + k] += this lane's share, I in [0], Q in [1].  The wipe-off (x ^ carrier word
+// of the NCO quadrant) never exists by itself: the three-input XOR is one v_bitop3_b32.
+template <int NK>
+__device__ __forceinline__ void trk_correlate(const u32 *__restrict__ row, u32 sh, u32 lane4, const u32 (&x)[8], const uint2 (&cw)[8],
+                                              u32 (&cnt)[3][2], int k0)
+{
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const u32 *p = row + lane4 + 256 * it;
+    const TrkW4 t4 = *reinterpret_cast<const TrkW4 *>(p);
+    const TrkW2 t2 = *reinterpret_cast<const TrkW2 *>(p + 4);
+    const u32 t[6] = {t4.w[0], t4.w[1], t4.w[2], t4.w[3], t2.w[0], t2.w[1]};
+    u32 a[5];
+#pragma unroll
+    for (int u = 0; u < (NK == 3 ? 5 : 4); u++)
+      a[u] = __builtin_amdgcn_alignbit(t[u + 1], t[u], sh);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int k = 0; k < NK; k++) {
+        const u32 r = k == 0 ? a[u] : __builtin_amdgcn_alignbit(a[u + 1], a[u], 8u * (u32)k);
+        cnt[k0 + k][0] = bcnt_acc(__builtin_amdgcn_bitop3_b32(x[4 * it + u], cw[4 * it + u].x, r, 0x96), cnt[k0 + k][0]);
+        cnt[k0 + k][1] = bcnt_acc(__builtin_amdgcn_bitop3_b32(x[4 * it + u], cw[4 * it + u].y, r, 0x96), cnt[k0 + k][1]);
+      }
+    }
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_get(u32 v)
+{
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
 }  // namespace
 
 __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restrict__ if_block, int if_format, int if_hz,
-                                                        gpsx_trk_state_t *__restrict__ st, int n_ch,
-                                                        const u32 *__restrict__ chipbits_all,
+                                                        gpsx_trk_state_t *__restrict__ st, int n_ch, int cpw,
+                                                        const u32 *__restrict__ chipbits_all, const u32 *__restrict__ rep_all,
                                                         int16_t *__restrict__ iq_out, u32 *__restrict__ bad_prn)
 {
   __shared__ u32 s_x[512];
   __shared__ uint2 s_carrier[4];   // (in-phase, quadrature) carrier word per NCO quadrant: one LDS read instead of two selects
-  __shared__ TrackLds lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ch_raw = blockIdx.x * 4 + wave;
-  const bool live = ch_raw < n_ch;
-  const int ch = live ? ch_raw : n_ch - 1;   // idle waves of the last workgroup shadow a real channel (no early exit
-                                             // before the barrier) and write nothing
-  TrackLds &L = lds[wave];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int ch0 = ((int)blockIdx.x * 4 + wave) * cpw;   // this wave's channels: ch0 .. ch0 + cpw - 1
+
   if (threadIdx.x < 4)
     s_carrier[threadIdx.x] = uint2{carrier_i(threadIdx.x), carrier_q(threadIdx.x)};
-  const gpsx_trk_state_t state = st[ch];
-  const int prn = track_prn(state.prn, bad_prn, live && lane == 0);
-
   // the block's sign plane as 32-bit words, once per workgroup (word 511 = 16-bit word 1022 alone)
   for (int w = threadIdx.x; w < 512; w += 256) {
     const u32 lo = load_sign16(if_block, 2 * w, if_format);
     const u32 hi = 2 * w + 1 < kWords16 ? (u32)load_sign16(if_block, 2 * w + 1, if_format) : 0u;
     s_x[w] = lo | (hi << 16);
   }
-  if (lane < 36)
-    L.cb[lane] = (lane >= 1 && lane <= 32) ? chipbits_all[(size_t)prn * 32 + (lane - 1)] : 0u;
-  if (lane == 0)
-    L.dd[0] = uint2{0u, 0u};
   __syncthreads();
+  if (ch0 >= n_ch)   // (wave-uniform: an idle wave of the last workgroup)
+    return;
+  const int n_here = min(cpw, n_ch - ch0);
 
+  // ---- per (channel, offset): lane 4 c + k, k = 0 / 1 / 2 = Early / Prompt / Late (k = 3 idles) --------------------------
+  const int c_l = lane >> 2, k_l = lane & 3;
+  const bool mine = c_l < n_here && k_l < 3;
+  const int ch_l = ch0 + (c_l < n_here ? c_l : 0);
+  const gpsx_trk_state_t state = st[ch_l];
+  const int prn = track_prn(state.prn, bad_prn, mine && k_l == 0);
   const int fine = (int)(int16_t)(int)state.code_phase_fine;
   const u32 b = (u32)fine & 7u;
   const u32 low = (1u << b) - 1u, high = (0xFFFFu << b) & 0xFFFFu;
-  const float freq_hz = (float)if_hz + state.if_freq_offset_hz;
-  const u32 step = nco_step_per_word(freq_hz);
-
-  // K3: wipe-off, word w sees NCO phase accum + w * step
-  {
-    u32 acc = state.if_freq_accum + step * (u32)lane;
-    const u32 step64 = step * 64u;
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int w = lane + 64 * it;
-      u32 vi = 0, vq = 0;   // word 511: the 16 samples the NCO loop never mixes read as zero (PM/GPS/gps_misc.c:229,261)
-      if (w < kWords32) {
-        const u32 x = s_x[w];
-        const uint2 c = s_carrier[acc >> 30];
-        vi = c.x ^ x;
-        vq = c.y ^ x;
-      }
-      L.dd[1 + w] = uint2{vi, vq};
-      acc += step64;
-    }
-    // the second period: word 511 + m = word (m - 1) >> 16 | word m << 16, m = 0..511 (word -1 = the zero pair in front, word
-    // 511 of the first period = zero: its low half is all this needs, and its slot is being overwritten meanwhile)
-#pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int m = lane + 64 * it;
-      uint4 v = lds_read_pairs(&L.dd[m]);
-      if (it == 7 && lane == 63)
-        v.z = v.w = 0u;
-      L.dd[1 + kWords32 + m] = uint2{__builtin_amdgcn_alignbit(v.z, v.x, 16u), __builtin_amdgcn_alignbit(v.w, v.y, 16u)};
-    }
-  }
-
-  // offsets exactly as tracking.c forms them, then reduced to the circle
+  const u32 step = nco_step_per_word((float)if_hz + state.if_freq_offset_hz);
+  // the offset exactly as tracking.c forms it, then reduced to the circle
   const unsigned prompt = (unsigned)(uint16_t)(fine / 8);
-  unsigned off[3] = {(unsigned)(uint16_t)(prompt - 1u), prompt, (unsigned)(uint16_t)(prompt + 1u)};
-  if (off[0] >= 2u * kChips) off[0] = 2u * kChips - 1u;
-  if (off[2] >= 2u * kChips) off[2] = 0u;
+  unsigned off = (unsigned)(uint16_t)(prompt + (unsigned)k_l - 1u);
+  if (k_l == 0 && off >= 2u * kChips) off = 2u * kChips - 1u;
+  if (k_l == 2 && off >= 2u * kChips) off = 0u;
+  if (off >= 2u * kChips) off = 0u;   // beyond 2046 the reference would read out of bounds (kept in range); 2046 behaves as 0
+  // where the window of replica bit stream word 0 starts in the PRN's table row: bit (-8 off - b) mod 16368
+  const u32 t0 = (u32)(3 * kSamples - 8 * (int)off - (int)b) % (u32)kSamples;
+  const u32 info = ((u32)prn << 14) | t0;
+
+  const u32 lane4 = 4u * (u32)lane;
+  const int xor16 = (lane ^ 16) << 2, xor32 = (lane ^ 32) << 2;
+  u32 sums = 0;   // lane 4 c + k: (count_I | count_Q << 16) against the circular replica, before the quirk terms
+
+#pragma unroll 1
+  for (int c = 0; c < n_here; c++) {
+    const u32 acc0 = (u32)__builtin_amdgcn_readlane((int)state.if_freq_accum, 4 * c);
+    const u32 stp = (u32)__builtin_amdgcn_readlane((int)step, 4 * c);
+    const u32 inf_e = (u32)__builtin_amdgcn_readlane((int)info, 4 * c);
+    const u32 inf_p = (u32)__builtin_amdgcn_readlane((int)info, 4 * c + 1);
+    const u32 inf_l = (u32)__builtin_amdgcn_readlane((int)info, 4 * c + 2);
+    // K3: the carrier words of this lane's eight stream words, word w sees NCO phase accum + w step
+    // (PM/GPS/gps_misc.c:253-262); word 511 (lane 63's last) is taken back after the loop
+    u32 x[8];
+    uint2 cw[8];
+    {
+      u32 acc = acc0 + stp * lane4;
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    if (off[k] > 2u * kChips) off[k] = 0u;   // the reference would read out of bounds here; keep the access in range
-    if (off[k] == 2u * kChips) off[k] = 0u;  // offset 2046 behaves as 0
+      for (int it = 0; it < 2; it++) {
+        const uint4 x4 = *reinterpret_cast<const uint4 *>(&s_x[lane4 + 256 * it]);
+        x[4 * it] = x4.x; x[4 * it + 1] = x4.y; x[4 * it + 2] = x4.z; x[4 * it + 3] = x4.w;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          cw[4 * it + u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(s_carrier) + ((acc >> 27) & 0x18u));
+          acc += stp;
+        }
+        acc += stp * 252u;
+      }
+    }
+    u32 cnt[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+    const u32 t_e = inf_e & 0x3FFFu, t_p = inf_p & 0x3FFFu, t_l = inf_l & 0x3FFFu;
+    const u32 *row = rep_all + (size_t)(inf_l >> 14) * kTrackRepStride;
+    const u32 d_pl = t_p >= t_l ? t_p - t_l : t_p + (u32)kSamples - t_l, d_el = t_e >= t_l ? t_e - t_l : t_e + (u32)kSamples - t_l;
+    u32 p_e, p_p, p_l;   // I | Q << 16 (a lane's share is at most 8 x 32: the totals stay below 2^15)
+    if (d_pl == 8u && d_el == 16u) {
+      // Late at the window's first bit, Prompt 8 and Early 16 samples further on (cnt[0] = Late here)
+      trk_correlate<3>(row + (t_l >> 5), t_l & 31u, lane4, x, cw, cnt, 0);
+      p_l = cnt[0][0] | (cnt[0][1] << 16);
+      p_p = cnt[1][0] | (cnt[1][1] << 16);
+      p_e = cnt[2][0] | (cnt[2][1] << 16);
+    } else {   // (code phases outside [0, 16368): the three offsets are not neighbours)
+      trk_correlate<1>(row + (t_e >> 5), t_e & 31u, lane4, x, cw, cnt, 0);
+      trk_correlate<1>(row + (t_p >> 5), t_p & 31u, lane4, x, cw, cnt, 1);
+      trk_correlate<1>(row + (t_l >> 5), t_l & 31u, lane4, x, cw, cnt, 2);
+      p_e = cnt[0][0] | (cnt[0][1] << 16);
+      p_p = cnt[1][0] | (cnt[1][1] << 16);
+      p_l = cnt[2][0] | (cnt[2][1] << 16);
+    }
+    // Three wave sums in one transposing reduction: after the two quad steps lane class (lane & 3) = 0 / 1 / 2 / 3 carries
+    // Early / Prompt / Late / Late, the rest of the butterfly keeps the class -- 13 vector instructions instead of 3 x 8.
+    const bool odd = lane & 1, upper = lane & 2;
+    u32 ab = (odd ? p_p : p_e) + dpp_get<0xB1>(odd ? p_e : p_p);   // quad_perm [1,0,3,2]
+    u32 cc = p_l + dpp_get<0xB1>(p_l);
+    u32 v = (upper ? cc : ab) + dpp_get<0x4E>(upper ? ab : cc);    // quad_perm [2,3,0,1]
+    v += dpp_get<0x124>(v);                                        // row_ror:4
+    v += dpp_get<0x128>(v);                                        // row_ror:8
+    v += (u32)__builtin_amdgcn_ds_bpermute(xor16, (int)v);
+    v += (u32)__builtin_amdgcn_ds_bpermute(xor32, (int)v);
+    sums = c_l == c ? v : sums;
   }
 
-  // stream position of replica bit 32 lane at each offset: the window of iteration `it` starts 2048 it bits further on
-  const uint2 *win[3];
-  u32 sh[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const int t = 8 * (int)off[k] + 32 * lane;
-    win[k] = &L.dd[1 + (t >> 5)];
-    sh[k] = (u32)(t & 31);
+  // ---- the reference's quirks against the circular count, per (channel, offset) -----------------------------------------
+  if (!mine)
+    return;
+  const u32 acc0 = state.if_freq_accum;
+  const u32 *cb = chipbits_all + (size_t)prn * 32;
+  const u32 cb31 = cb[31];
+  const bool c1022 = (cb31 >> 30) & 1u, c1021 = (cb31 >> 29) & 1u;
+  u32 total = sums;
+  {
+    // stream word 511: only its low half exists, the sixteen samples the NCO loop never mixes, which read as zero
+    // (PM/GPS/gps_misc.c:229,261) -- the loop counted 32 mixed bits there: take them back, count the replica's sixteen
+    const u32 *rw = rep_all + (size_t)prn * kTrackRepStride + (t0 >> 5) + kWords32;
+    const u32 r = __builtin_amdgcn_alignbit(rw[1], rw[0], t0 & 31u);
+    const u32 x511 = s_x[kWords32];
+    const uint2 c511 = s_carrier[(acc0 + step * (u32)kWords32) >> 30];
+    const u32 right = pop16(r);
+    total += (right - (u32)__popc(x511 ^ c511.x ^ r)) + ((right - (u32)__popc(x511 ^ c511.y ^ r)) << 16);
   }
-  u32 ci[3] = {0, 0, 0}, cq[3] = {0, 0, 0};
-#pragma unroll
-  for (int it = 0; it < 8; it++) {
-    const int j = lane + 64 * it;
-    // replica word j = bits [32 j, 32 j + 32) of the delayed chip stream: chips 2 j - 1 (low b bits), 2 j, 2 j + 1
-    const int cbit = 2 * j - 1 + 32;
-    const u32 cw = __builtin_amdgcn_alignbit(L.cb[(cbit >> 5) + 1], L.cb[cbit >> 5], (u32)(cbit & 31));
-    // (an 8-entry LDS table of the replica words there are was measured 6 % slower: the lookup sits on the critical path)
-    u32 r = ((cw & 1u) ? low : 0u) | ((cw & 2u) ? (high | (low << 16)) : 0u) | ((cw & 4u) ? (high << 16) : 0u);
-    const u32 m = (it == 7 && lane == 63) ? 0xFFFFu : 0xFFFFFFFFu;   // word 511 is half a word (16-bit word 1022)
-    r &= m;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const uint4 v = lds_read_pairs(win[k] + 64 * it);
-      const u32 wi = __builtin_amdgcn_alignbit(v.z, v.x, sh[k]);
-      const u32 wq = __builtin_amdgcn_alignbit(v.w, v.y, sh[k]);
-      ci[k] += (u32)__popc((wi & m) ^ r);
-      cq[k] += (u32)__popc((wq & m) ^ r);
-    }
+  if (c1022 && b) {   // Q5: the replica's first b samples are zero, not the tail of chip 1022 (PM/GPS/gps_misc.c:290-297)
+    const uint2 by = trk_dbyte(s_x, s_carrier, acc0, step, (int)off);
+    total += (u32)(2 * (int)__popc(by.x & low) - (int)b) + ((u32)(2 * (int)__popc(by.y & low) - (int)b) << 16);
   }
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    // (both counts in one reduction: a lane's share is at most 8 x 32, the totals stay below 2^15)
-    const u32 both = wave_sum_to_lane63(ci[k] | (cq[k] << 16));
-    u32 si = both & 0xFFFFu, sq = both >> 16;
-    if (off[k] & 1u) {   // wave-uniform
-      const int o = (int)off[k];
-      const int p1 = (kBytes - o) >> 1;
-      auto rep16 = [&](int i) {   // replica word i of the 16-bit form: chip i - 1 below bit b, chip i from bit b on
-        const int cb0 = i - 1 + 32;
-        const u32 c2 = __builtin_amdgcn_alignbit(L.cb[(cb0 >> 5) + 1], L.cb[cb0 >> 5], (u32)(cb0 & 31));
-        return ((c2 & 1u) ? low : 0u) | ((c2 & 2u) ? high : 0u);
-      };
-      auto win16 = [&](int t, u32 &wi, u32 &wq) {
-        const uint4 v = lds_read_pairs(&L.dd[1 + (t >> 5)]);
-        wi = __builtin_amdgcn_alignbit(v.z, v.x, (u32)(t & 31)) & 0xFFFFu;
-        wq = __builtin_amdgcn_alignbit(v.w, v.y, (u32)(t & 31)) & 0xFFFFu;
-      };
-      const u32 r1 = rep16(p1);
-      u32 wi, wq;
-      win16(kSamples - 8, wi, wq);   // data bytes (2045, 0)
-      u32 sub_i = pop16(wi ^ r1), sub_q = pop16(wq ^ r1);
-      if (p1 != kWords16 - 1) {
-        const u32 r2 = rep16(kWords16 - 1);
-        win16(8 * (o - 2), wi, wq);   // data bytes (o - 2, o - 1); o >= 3 here
-        sub_i += pop16(wi ^ r2);
-        sub_q += pop16(wq ^ r2);
-      }
-      si -= sub_i;
-      sq -= sub_q;
+  if (off & 1u) {     // Q3: odd byte offsets skip the replica word at the wrap and the last one (PM/GPS/gps_misc.c:66-90)
+    const int o = (int)off;
+    const int p1 = (kBytes - o) >> 1;
+    // 16-bit replica word p1: chip p1 - 1 below bit b (chip -1 = 0), chip p1 from bit b on
+    const int i0 = p1 - 1;
+    const int wlo = i0 > 0 ? i0 >> 5 : 0;
+    u32 c2 = __builtin_amdgcn_alignbit(cb[wlo < 31 ? wlo + 1 : 31], cb[wlo], (u32)(i0 & 31));
+    if (i0 < 0)
+      c2 = cb[0] << 1;
+    const u32 r1 = ((c2 & 1u) ? low : 0u) | ((c2 & 2u) ? high : 0u);
+    const uint2 b0 = trk_dbyte(s_x, s_carrier, acc0, step, 0);   // data bytes (2045, 0): byte 2045 is never mixed
+    u32 sub_i = pop16((b0.x << 8) ^ r1), sub_q = pop16((b0.y << 8) ^ r1);
+    if (p1 != kWords16 - 1) {   // o >= 3
+      const u32 r2 = (c1021 ? low : 0u) | (c1022 ? high : 0u);
+      const uint2 ba = trk_dbyte(s_x, s_carrier, acc0, step, o - 2), bb = trk_dbyte(s_x, s_carrier, acc0, step, o - 1);
+      sub_i += pop16((ba.x | (bb.x << 8)) ^ r2);
+      sub_q += pop16((ba.y | (bb.y << 8)) ^ r2);
     }
-    if (lane == 63 && live) {
-      iq_out[ch * 6 + k * 2 + 0] = (int16_t)((int)si - kHalf);
-      iq_out[ch * 6 + k * 2 + 1] = (int16_t)((int)sq - kHalf);
-    }
+    total -= sub_i + (sub_q << 16);
   }
-  if (lane == 0 && live)
-    st[ch].if_freq_accum = state.if_freq_accum + step * (u32)kWords32;
+  const u32 res_i = (total & 0xFFFFu) - (u32)kHalf, res_q = (total >> 16) - (u32)kHalf;
+  reinterpret_cast<u32 *>(iq_out)[(size_t)ch_l * 3 + k_l] = (res_i & 0xFFFFu) | (res_q << 16);   // (IE,QE) (IP,QP) (IL,QL)
+  if (k_l == 0)
+    st[ch_l].if_freq_accum = acc0 + step * (u32)kWords32;
 }
 
 constexpr int kTrackWaveFormFrom = 2048;
 
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
-                      const uint8_t *d_chips, const uint32_t *d_chipbits, int16_t *d_iq, uint32_t *d_bad_prn)
+                      const uint8_t *d_chips, const uint32_t *d_chipbits, const uint32_t *d_trk_rep, int16_t *d_iq,
+                      uint32_t *d_bad_prn)
 {
   if (n_ch <= 0)
     return;
-  if (n_ch < kTrackWaveFormFrom)
+  if (n_ch < kTrackWaveFormFrom) {
     hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch, d_chips, d_iq,
                        d_bad_prn);
-  else
-    hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 3) / 4), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch,
-                       d_chipbits, d_iq, d_bad_prn);
+    return;
+  }
+  // channels per wave: as many as leave ~4 workgroups per CU (16 at most: lanes 3 c + k carry the per-channel values)
+  int cpw = n_ch / (4 * 256 * 4);
+  cpw = cpw < 1 ? 1 : (cpw > 16 ? 16 : cpw);
+  hipLaunchKernelGGL(k_track_epl_wave, dim3((n_ch + 4 * cpw - 1) / (4 * cpw)), dim3(256), 0, s, d_if_block, if_format, if_hz,
+                     d_st, n_ch, cpw, d_chipbits, d_trk_rep, d_iq, d_bad_prn);
 }
 
 // N3 ingest: MAX2769 sign/magnitude pairs -> sign plane and magnitude plane in the reference's 1-bit layout.
