@@ -10,7 +10,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <initializer_list>
+#include <mutex>
+#include <sched.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/gpsx_compat.h"
@@ -52,6 +58,161 @@ struct SlotState {
   uint8_t bits[TRACKING_CH_LENGTH] = {0, 0, 0, 0};
 };
 SlotState g_shared_slot;
+
+// ---- the batched step's host workers (gps_tracking_process_batch) ---------------------------------------------------------
+constexpr int kStepThreadsFrom = 2048;   // channels from which the per-channel host loops are spread over worker threads
+
+struct WorkerLists {   // what one worker's contiguous channel range contributes to the step's work lists
+  std::vector<gpsx_acq_job_t> jobs;
+  std::vector<gpsx_trk_state_t> st;
+  std::vector<uint8_t> skipped;
+  int job_base = 0, st_base = 0;
+  bool any_skipped = false;
+};
+
+// A fixed set of threads that run `fn(worker)` for worker = 0..n-1 (the caller is worker 0) and meet again.  Sized once, from
+// the CPUs the creating thread may run on ($GPSX_STEP_THREADS overrides; at most 64), so a process that pinned itself next to
+// its GPU (gpsx_bind_thread_to_device) gets workers on those cores.  Between steps the workers spin briefly -- the next
+// millisecond is never far -- then sleep on a condition variable.
+class StepPool {
+ public:
+  static StepPool &instance()
+  {
+    static StepPool pool;
+    return pool;
+  }
+  int size() const { return n_; }
+  template <typename F>
+  void run(int n_workers, F &&fn)
+  {
+    if (n_workers <= 1) {
+      fn(0);
+      return;
+    }
+    start_threads();
+    std::function<void(int)> f = std::ref(fn);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &f;
+      active_ = n_workers;
+      pending_.store(n_workers - 1, std::memory_order_relaxed);
+      generation_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    fn(0);
+    for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++)
+      if (spin > 64)
+        std::this_thread::yield();
+    std::lock_guard<std::mutex> lk(m_);
+    job_ = nullptr;
+    active_ = 0;
+  }
+
+ private:
+  StepPool()
+  {
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0)
+      n = CPU_COUNT(&set);
+    if (n <= 0)
+      n = (int)std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("GPSX_STEP_THREADS"))
+      n = std::atoi(e);
+    n_ = n < 1 ? 1 : (n > 64 ? 64 : n);
+  }
+  ~StepPool()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      quit_ = true;
+      generation_.fetch_add(1, std::memory_order_release);
+    }
+    cv_.notify_all();
+    for (std::thread &t : threads_)
+      t.join();
+  }
+  void start_threads()
+  {
+    if (!threads_.empty() || n_ <= 1)
+      return;
+    for (int w = 1; w < n_; w++)
+      threads_.emplace_back([this, w] { worker(w); });
+  }
+  void worker(int w)
+  {
+    unsigned seen = 0;
+    for (;;) {
+      // wait for the next generation: spin for a while (steps come every millisecond), then sleep
+      bool got = false;
+      for (int spin = 0; spin < 20000; spin++) {
+        if (generation_.load(std::memory_order_acquire) != seen) {
+          got = true;
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+      }
+      std::function<void(int)> *job;
+      int active;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        seen = generation_.load(std::memory_order_acquire);
+        if (quit_)
+          return;
+        job = job_;
+        active = active_;
+      }
+      if (job && w < active) {
+        (*job)(w);
+        pending_.fetch_sub(1, std::memory_order_release);
+      }
+    }
+  }
+  int n_ = 1;
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::atomic<unsigned> generation_{0};
+  std::atomic<int> pending_{0};
+  std::function<void(int)> *job_ = nullptr;
+  int active_ = 0;
+  bool quit_ = false;
+};
+
+// page-locked staging of the batched step's channel states and accumulators (grow-only; freed with the process)
+struct StepBuffers {
+  gpsx_trk_state_t *st = nullptr;
+  int16_t *iq = nullptr;
+  size_t cap = 0;
+  static StepBuffers &instance()
+  {
+    static StepBuffers b;
+    return b;
+  }
+  void reserve(gpsx_ctx *gx, size_t n)
+  {
+    if (n <= cap)
+      return;
+    if (st)
+      (void)gpsx_host_free(gx, st);
+    if (iq)
+      (void)gpsx_host_free(gx, iq);
+    st = nullptr;
+    iq = nullptr;
+    cap = 0;
+    const size_t want = n + n / 4 + 64;
+    void *a = nullptr, *b = nullptr;
+    if (gpsx_host_alloc(gx, &a, want * sizeof(gpsx_trk_state_t)) != GPSX_OK || gpsx_host_alloc(gx, &b, want * 12) != GPSX_OK)
+      gpsx_compat_die("gps_tracking_process_batch(page-locked staging)", GPSX_ENOMEM);
+    st = static_cast<gpsx_trk_state_t *>(a);
+    iq = static_cast<int16_t *>(b);
+    cap = want;
+  }
+};
 
 void reset_search_buffers()
 {
@@ -1086,73 +1247,130 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
     return;
   if ((int)slots.size() < n_ch)
     slots.resize(n_ch);
-  jobs.clear();
-  st.clear();
-  skipped.clear();
-  job_of.assign(n_ch, -1);
-  trk_of.assign(n_ch, -1);
-  bool any_skipped = false;
+  if ((int)job_of.size() < n_ch) {
+    job_of.resize(n_ch);
+    trk_of.resize(n_ch);
+  }
+  // The host side of the step -- the work lists before the correlators, the reference's float loops after them -- is
+  // independent per channel (each owns its gps_ch_t and its slot state): from kStepThreadsFrom channels on it is spread over
+  // the calling thread's CPUs (after gpsx_bind_thread_to_device: the cores next to the GPU), contiguous channel ranges per
+  // worker.  Below that -- the reference's four channels, the golden traces -- everything runs on the calling thread in
+  // channel order, as before.  (The one shared state on this path is rand() in the PLL's false-lock reseed,
+  // tracking.c:309-326: with several workers the channels draw from it in no fixed order.)
+  StepPool &pool = StepPool::instance();
+  const int n_workers = n_ch >= kStepThreadsFrom ? pool.size() : 1;
+  static std::vector<WorkerLists> lists;
+  if ((int)lists.size() < n_workers)
+    lists.resize(n_workers);
+  const uint32_t now = signal_capture_get_packet_cnt();   // (one read for all workers: the hook is the caller's)
+  (void)now;
 
-  // pass 1: state transitions that precede the correlators, and the work lists
-  for (int c = 0; c < n_ch; c++) {
-    gps_ch_t &ch = channel[c];
-    gps_tracking_t &t = ch.tracking_data;
-    enter_pre_track_if_needed(ch);
-    if (t.state == GPS_PRE_TRACK_RUN) {
-      uint16_t first, last;
-      if (index < TRACKING_CH_LENGTH && pre_track_window(ch, index, first, last)) {
-        job_of[c] = (int)jobs.size();
-        jobs.push_back(pre_track_job(ch, first, last));
-      }
-    } else {
-      if (t.state == GPS_PRE_TRACK_DONE)
-        t.state = GPS_TRACKING_RUN;
-      if (t.state == GPS_TRACKING_RUN && index < TRACKING_CH_LENGTH) {
-        gpsx_trk_state_t s1;
-        s1.prn = ch.prn;
-        s1.code_phase_fine = t.code_phase_fine;
-        s1.if_freq_offset_hz = t.if_freq_offset_hz;
-        s1.if_freq_accum = t.if_freq_accum;
-        trk_of[c] = (int)st.size();
-        st.push_back(s1);
-        skipped.push_back(tracking_skipped_ms(ch));
-        any_skipped |= skipped.back() != 0;
+  // pass 1: state transitions that precede the correlators, and the work lists (per worker, in channel order)
+  auto pass1 = [&](int w) {
+    WorkerLists &L = lists[w];
+    L.jobs.clear();
+    L.st.clear();
+    L.skipped.clear();
+    L.any_skipped = false;
+    const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
+    for (int c = lo; c < hi; c++) {
+      gps_ch_t &ch = channel[c];
+      gps_tracking_t &t = ch.tracking_data;
+      job_of[c] = trk_of[c] = -1;
+      enter_pre_track_if_needed(ch);
+      if (t.state == GPS_PRE_TRACK_RUN) {
+        uint16_t first, last;
+        if (index < TRACKING_CH_LENGTH && pre_track_window(ch, index, first, last)) {
+          job_of[c] = (int)L.jobs.size();
+          L.jobs.push_back(pre_track_job(ch, first, last));
+        }
+      } else {
+        if (t.state == GPS_PRE_TRACK_DONE)
+          t.state = GPS_TRACKING_RUN;
+        if (t.state == GPS_TRACKING_RUN && index < TRACKING_CH_LENGTH) {
+          gpsx_trk_state_t s1;
+          s1.prn = ch.prn;
+          s1.code_phase_fine = t.code_phase_fine;
+          s1.if_freq_offset_hz = t.if_freq_offset_hz;
+          s1.if_freq_accum = t.if_freq_accum;
+          trk_of[c] = (int)L.st.size();
+          L.st.push_back(s1);
+          L.skipped.push_back(tracking_skipped_ms(ch));
+          L.any_skipped |= L.skipped.back() != 0;
+        }
       }
     }
+  };
+  pool.run(n_workers, pass1);
+  // the workers' lists, one behind the other (their order is the channel order)
+  size_t n_jobs = 0, n_st = 0;
+  bool any_skipped = false;
+  for (int w = 0; w < n_workers; w++) {
+    lists[w].job_base = (int)n_jobs;
+    lists[w].st_base = (int)n_st;
+    n_jobs += lists[w].jobs.size();
+    n_st += lists[w].st.size();
+    any_skipped |= lists[w].any_skipped;
   }
-  // pass 2: the GPU work of this millisecond
   gpsx_ctx *gx = gpsx_compat_ctx();
-  if (!jobs.empty()) {
-    peaks.resize(jobs.size());
-    const int rc = gpsx_acq_jobs(gx, jobs.data(), (int)jobs.size(), data, 1, peaks.data(), nullptr);
+  StepBuffers &pin = StepBuffers::instance();
+  gpsx_trk_state_t *st_all = nullptr;
+  int16_t *iq_all = nullptr;
+  if (n_st) {   // page-locked (gpsx_host_alloc): the step's copies then run at the link's rate and can be chunked
+    pin.reserve(gx, n_st);
+    st_all = pin.st;
+    iq_all = pin.iq;
+  }
+  jobs.resize(n_jobs);
+  skipped.resize(n_st);
+  auto gather = [&](int w) {
+    WorkerLists &L = lists[w];
+    if (!L.jobs.empty())
+      std::memcpy(&jobs[L.job_base], L.jobs.data(), L.jobs.size() * sizeof(gpsx_acq_job_t));
+    if (!L.st.empty()) {
+      std::memcpy(st_all + L.st_base, L.st.data(), L.st.size() * sizeof(gpsx_trk_state_t));
+      std::memcpy(&skipped[L.st_base], L.skipped.data(), L.skipped.size());
+    }
+  };
+  pool.run(n_workers, gather);
+
+  // pass 2: the GPU work of this millisecond
+  if (n_jobs) {
+    peaks.resize(n_jobs);
+    const int rc = gpsx_acq_jobs(gx, jobs.data(), (int)n_jobs, data, 1, peaks.data(), nullptr);
     if (rc != GPSX_OK)
       gpsx_compat_die("gps_tracking_process_batch(pre-track)", rc);
   }
-  if (!st.empty()) {
+  if (n_st) {
     if (any_skipped) {
-      const int rc = gpsx_rewind(gx, st.data(), (int)st.size(), skipped.data());
+      const int rc = gpsx_rewind(gx, st_all, (int)n_st, skipped.data());
       if (rc != GPSX_OK)
         gpsx_compat_die("gps_tracking_process_batch(rewind)", rc);
     }
-    iq.resize(st.size() * 6);
-    const int rc = gpsx_track_epl_batch(gx, data, st.data(), (int)st.size(), iq.data());
+    const int rc = gpsx_track_epl_batch(gx, data, st_all, (int)n_st, iq_all);
     if (rc != GPSX_OK)
       gpsx_compat_die("gps_tracking_process_batch", rc);
   }
-  // pass 3: per-channel serial logic, in channel order
-  for (int c = 0; c < n_ch; c++) {
-    gps_ch_t &ch = channel[c];
-    gps_tracking_t &t = ch.tracking_data;
-    if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
-      if (index < TRACKING_CH_LENGTH)
-        pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[job_of[c]] : nullptr, slots[c]);
-      // a channel whose pre-tracking just settled starts tracking on the NEXT millisecond (its correlators were not
-      // part of this launch); the reference's single-channel call does the same one call later
-    } else if (trk_of[c] >= 0) {
-      t.if_freq_accum = st[trk_of[c]].if_freq_accum;
-      tracking_apply(ch, index, &iq[(size_t)trk_of[c] * 6], &slots[c]);
+  // pass 3: per-channel serial logic, in channel order within a worker
+  auto pass3 = [&](int w) {
+    const WorkerLists &L = lists[w];
+    const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
+    for (int c = lo; c < hi; c++) {
+      gps_ch_t &ch = channel[c];
+      gps_tracking_t &t = ch.tracking_data;
+      if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
+        if (index < TRACKING_CH_LENGTH)
+          pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[L.job_base + job_of[c]] : nullptr, slots[c]);
+        // a channel whose pre-tracking just settled starts tracking on the NEXT millisecond (its correlators were not
+        // part of this launch); the reference's single-channel call does the same one call later
+      } else if (trk_of[c] >= 0) {
+        const size_t k = (size_t)L.st_base + trk_of[c];
+        t.if_freq_accum = st_all[k].if_freq_accum;
+        tracking_apply(ch, index, &iq_all[k * 6], &slots[c]);
+      }
     }
-  }
+  };
+  pool.run(n_workers, pass3);
 }
 
 }  // extern "C"

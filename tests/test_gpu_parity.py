@@ -1084,6 +1084,80 @@ def test_in_process_group_sharded_sweep_over_rccl(eng, stream):
         other.close()
 
 
+def _device_count():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+@pytest.mark.parametrize("n_dev", [2, 4, 8])
+def test_in_process_group_of_n_devices_all_reduces_over_rccl(stream, oracle, n_dev):
+    """gpsx_group_create / gpsx_acq_grid_sharded with n > 1 REAL ranks: one context per device, RCCL communicators from
+    ncclCommInitAll, each device sweeps its contiguous run of (search, Doppler, 8-PRN group) units, ONE ncclAllReduce(MAX,
+    int64) over xGMI merges the key tables -- every device must then hold the oracle's keys for the whole grid, and its own
+    units' triplets.  Skips on a box with fewer devices (the one-GPU boxes these tests usually see): it runs the moment a
+    multi-GPU node collects it."""
+    if _device_count() < n_dev:
+        pytest.skip(f"needs {n_dev} GPUs in one node")
+    from stm32f4_sdr_gps_amd import capi
+    engs = [capi.Engine(d) for d in range(n_dev)]
+    lib = engs[0].lib
+    grp = C.c_void_p()
+    bufs = []
+    try:
+        prns = np.arange(1, 33, dtype=np.uint8)
+        kw = dict(n_search=2, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
+        g = engs[0].grid_desc(prns, **kw)
+        n_pk, n_keys = 2 * 32 * 21 * 8, 2 * 32 * 21
+        blocks = np.concatenate([np.ascontiguousarray(stream[:2]).reshape(-1), np.zeros(2, np.uint8)])
+        for e in engs:
+            d_if, d_pk, d_keys = e.malloc(blocks.nbytes), e.malloc(n_pk * 16), e.malloc(n_keys * 8)
+            e.h2d(d_if, blocks)
+            bufs.append((e, d_if, d_pk, d_keys))
+        handles = (C.c_void_p * n_dev)(*[e.h for e in engs])
+        assert lib.gpsx_group_create(handles, n_dev, C.byref(grp)) == 0, lib.gpsx_last_error(engs[0].h)
+        ifs = (C.c_void_p * n_dev)(*[b[1] for b in bufs])
+        pks = (C.c_void_p * n_dev)(*[b[2] for b in bufs])
+        ks = (C.c_void_p * n_dev)(*[b[3] for b in bufs])
+        for rep in range(3):      # the communicators are reused across sweeps
+            assert lib.gpsx_acq_grid_sharded(grp, C.byref(g), ifs, 2, pks, ks) == 0, lib.gpsx_last_error(engs[0].h)
+        want_keys = np.zeros((2, 32, 21), np.int64)
+        want_pk = []
+        for s_ in range(2):
+            w = oracle.acq_grid(stream[s_:s_ + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+            fine = 8 * w["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+            want_keys[s_] = ((w["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)
+            want_pk.append(w)
+        n_units = 2 * 21 * 4
+        owned = np.zeros((2, 32, 21), np.int32)
+        for r, (e, _, d_pk, d_keys) in enumerate(bufs):
+            e.synchronize()
+            keys = np.zeros((2, 32, 21), np.int64)
+            pk = np.zeros((2, 32, 21, 8), capi.PEAK_DTYPE)
+            e.d2h(keys, d_keys)
+            e.d2h(pk, d_pk)
+            assert np.array_equal(keys, want_keys), r            # the merged table, on every device
+            lo, hi = n_units * r // n_dev, n_units * (r + 1) // n_dev
+            for u in range(lo, hi):                               # this device's own units: full triplets
+                s_, d, grp8 = u // (21 * 4), (u // 4) % 21, u % 4
+                owned[s_, 8 * grp8:8 * grp8 + 8, d] += 1
+                for f in ("max_val", "phase", "sum", "avr"):
+                    assert np.array_equal(pk[s_, 8 * grp8:8 * grp8 + 8, d][f], want_pk[s_][f][8 * grp8:8 * grp8 + 8, d]), (r, u, f)
+        assert (owned == 1).all()
+    finally:
+        if grp:
+            lib.gpsx_group_destroy(grp)
+        for e, d_if, d_pk, d_keys in bufs:
+            for p in (d_if, d_pk, d_keys):
+                e.free(p)
+        for e in engs:
+            e.close()
+
+
 @pytest.mark.parametrize("algo", ["mx", "poly"])
 @pytest.mark.parametrize("mode", ["walk", "blocks"])
 def test_both_multi_block_forms_match_the_oracle(oracle, stream, mode, algo, monkeypatch):
