@@ -765,10 +765,12 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
 
 namespace {
 
-constexpr int kTrackGraphMaxCh = 32768;   // measured (page-locked caller buffers): graph + staging copies 70 / 116 / 238 us for
-                                          // 16384 / 32768 / 65536 channels, plain copies and a launch 81 / 111 / 170 us
+constexpr int kTrackGraphMaxCh = 4096;    // measured (page-locked caller buffers): graph + staging copies 70 / 116 / 238 us for
+                                          // 16384 / 32768 / 65536 channels, plain copies and a launch 81 / 111 / 170 us -- the graph
+                                          // only pays where the step is launch-bound, and every new shape costs ~10 ms to
+                                          // instantiate: a miss of ten deadlines in a closed loop whose channel count drifts
 
-constexpr size_t kTrackGraphShapes = 4;
+constexpr size_t kTrackGraphShapes = 12;  // every capacity there is (4, 8, .. 4096): a shape is instantiated once per context
 
 void track_graph_free(gpsx_ctx::TrackGraph &t)
 {
@@ -786,19 +788,16 @@ void track_graph_release(gpsx_ctx *ctx)
   ctx->trk_graphs.clear();
 }
 
-// Channel capacity a graph is captured for: counts are rounded up (to 4 below 64, to 1/8 of the next power of two above)
-// so that a receiver whose channels come and go between pre-tracking and tracking (gps_tracking_process_batch) keeps
-// hitting the same few graphs instead of re-instantiating one per count.  The padding channels carry PRN 0 (the empty
-// code) and are computed and copied like the others.
+// Channel capacity a graph is captured for: the next power of two (4 at least), so that a receiver whose channels come and
+// go between pre-tracking and tracking (gps_tracking_process_batch) keeps hitting the same few graphs -- eleven shapes in
+// all, each instantiated once -- instead of re-instantiating one per count.  The padding channels carry kTrackPadPrn (the
+// empty code) and are computed and copied like the others.
 int track_graph_capacity(int n_ch)
 {
-  if (n_ch <= 64)
-    return (n_ch + 3) & ~3;
-  int p2 = 64;
+  int p2 = 4;
   while (p2 < n_ch)
     p2 <<= 1;
-  const int step = p2 / 16;   // n_ch is in (p2 / 2, p2]: steps of 1/8 of p2 / 2
-  return (n_ch + step - 1) / step * step;
+  return p2;
 }
 
 // H2D(block + states) -> k_track_epl -> D2H(states + accumulators), captured once per (channel capacity, format) shape;

@@ -62,6 +62,20 @@ SlotState g_shared_slot;
 // ---- the batched step's host workers (gps_tracking_process_batch) ---------------------------------------------------------
 constexpr int kStepThreadsFrom = 2048;   // channels from which the per-channel host loops are spread over worker threads
 
+// the cache lines of a channel record the batched step touches: tracking_data (offset 60, 152 bytes) and, after the
+// correlators, the head of nav_data behind it
+inline void prefetch_channel(const gps_ch_t &ch, bool with_nav)
+{
+  const char *p = reinterpret_cast<const char *>(&ch.tracking_data);
+  __builtin_prefetch(p, 1);
+  __builtin_prefetch(p + 64, 1);
+  __builtin_prefetch(p + 128, 1);
+  if (with_nav) {
+    __builtin_prefetch(p + 192, 1);
+    __builtin_prefetch(p + 256, 1);
+  }
+}
+
 struct WorkerLists {   // what one worker's contiguous channel range contributes to the step's work lists
   std::vector<gpsx_acq_job_t> jobs;
   std::vector<gpsx_trk_state_t> st;
@@ -117,9 +131,37 @@ class StepPool {
       n = CPU_COUNT(&set);
     if (n <= 0)
       n = (int)std::thread::hardware_concurrency();
+    // A container's CPU quota (cgroup cpu.max / cfs_quota_us): workers that spin between steps burn it, and a group that
+    // exhausts its quota is frozen until the next 100 ms period -- measured on the GPU box (16 CPUs of quota): 64 workers = a 75 ms stall
+    // every 100 ms.
+    const double quota = cgroup_cpu_quota();
+    if (quota > 0.0 && n > (int)quota - 2)
+      n = (int)quota - 2;   // (two CPUs' worth left for the HIP runtime's own threads and the caller's other work)
     if (const char *e = std::getenv("GPSX_STEP_THREADS"))
       n = std::atoi(e);
     n_ = n < 1 ? 1 : (n > 64 ? 64 : n);
+  }
+  static double cgroup_cpu_quota()   // CPUs' worth of quota, 0 = unlimited / unknown
+  {
+    if (std::FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2: "<quota|max> <period>"
+      char q[32] = {0};
+      long period = 0;
+      const int got = std::fscanf(f, "%31s %ld", q, &period);
+      std::fclose(f);
+      if (got == 2 && period > 0 && std::strcmp(q, "max") != 0)
+        return std::atof(q) / (double)period;
+      return 0.0;
+    }
+    long quota = -1, period = 0;
+    if (std::FILE *f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      if (std::fscanf(f, "%ld", &quota) != 1) quota = -1;
+      std::fclose(f);
+    }
+    if (std::FILE *f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(f, "%ld", &period) != 1) period = 0;
+      std::fclose(f);
+    }
+    return quota > 0 && period > 0 ? (double)quota / (double)period : 0.0;
   }
   ~StepPool()
   {
@@ -143,9 +185,12 @@ class StepPool {
   {
     unsigned seen = 0;
     for (;;) {
-      // wait for the next generation: spin for a while (steps come every millisecond), then sleep
+      // wait for the next generation: spin briefly (the phases of a step follow each other within microseconds), then sleep --
+      // a worker that spins through the GPU's part of the millisecond burns the CPU quota the step needs (measured on a
+      // 16-CPU quota: 2000 pauses -> deadline misses at 65536 channels, 200 -> none)
+      static const int kSpin = [] { const char *e = std::getenv("GPSX_STEP_SPIN"); return e ? std::atoi(e) : 200; }();
       bool got = false;
-      for (int spin = 0; spin < 20000; spin++) {
+      for (int spin = 0; spin < kSpin; spin++) {
         if (generation_.load(std::memory_order_acquire) != seen) {
           got = true;
           break;
@@ -1276,6 +1321,8 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
     for (int c = lo; c < hi; c++) {
       gps_ch_t &ch = channel[c];
       gps_tracking_t &t = ch.tracking_data;
+      if (c + 2 < hi)   // (a gps_ch_t is 1688 bytes: every channel's state is a fresh set of cache lines)
+        prefetch_channel(channel[c + 2], false);
       job_of[c] = trk_of[c] = -1;
       enter_pre_track_if_needed(ch);
       if (t.state == GPS_PRE_TRACK_RUN) {
@@ -1358,6 +1405,8 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
     for (int c = lo; c < hi; c++) {
       gps_ch_t &ch = channel[c];
       gps_tracking_t &t = ch.tracking_data;
+      if (c + 2 < hi)
+        prefetch_channel(channel[c + 2], true);
       if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
         if (index < TRACKING_CH_LENGTH)
           pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[L.job_base + job_of[c]] : nullptr, slots[c]);

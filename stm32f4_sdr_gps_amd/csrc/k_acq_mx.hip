@@ -114,13 +114,19 @@ __device__ __forceinline__ u32 plane_bits9(const u32 *pl, int pos)
 }
 
 // ---- per block: capture -> LDS, wipe-off, polyphase planes -------------------------------------------------------------
-__device__ void mx_prepare_block(MxShared &sh, const uint8_t *blk, int if_format, u32 step_word, int tid, int lane)
+// PLANES = false (byte-phase grid): the polyphase planes are what the recurrence vectors are cut from; a form that starts
+// every offset from its block sums does not need them
+// (in two parts: the block's load goes out together with the cluster's tables -- one global-memory latency, not two)
+__device__ __forceinline__ void mx_load_block(MxShared &sh, const uint8_t *blk, int if_format, int tid)
 {
   for (int i = tid; i < 1024; i += kMxThreads)
     sh.x[i] = i < kWords16 ? load_sign16(blk, i, if_format) : (uint16_t)0;
   if (tid < 2)
     sh.ones[tid] = 0;
-  __syncthreads();
+}
+template <bool PLANES>
+__device__ void mx_wipe_block(MxShared &sh, u32 step_word, int tid, int lane)
+{
   {
     const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
     u32 ones_i = 0, ones_q = 0;
@@ -147,6 +153,8 @@ __device__ void mx_prepare_block(MxShared &sh, const uint8_t *blk, int if_format
   if (tid < 2)
     sh.d[tid][511] = sh.d[tid][0] << 16;   // samples 16352..16367 are zero, then the stream wraps to sample 0
   __syncthreads();
+  if constexpr (!PLANES)
+    return;
   // plane[iq][t0] bit i = D(16 (i mod 1023) + t0), i < 2112.  First period: word w of offset t0 takes bit t0 and bit 16 + t0
   // of the stream words 16 w .. 16 w + 15 (bit 1023 = D(16368 + t0) is the wrap-around copy in word 511: D(t0), as it has
   // to be); the 16 threads of a word read the same 16 addresses (LDS broadcast).
@@ -344,6 +352,77 @@ __device__ __forceinline__ void mx_vector_build(MxShared &sh, int p_vec, int tid
     dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi, lo, 4u * (u32)c) : lo;
 }
 
+// ---- the two vectors of a DIRECT start at sample offset t0s, in one phase ---------------------------------------------------
+// M_t0s(q) = sum_c chip[c] S_t0s[q + c] from the block sums S_t0s[k] = pop(D[16 k + t0s, +16)) themselves, as passes 0 and 1
+// do it for t0s = 0 (mx_vector_phase1): which = 0: -2 (S & 3), which = 1: -(S >> 2) at block scale 2^3.  Thread (stream, j)
+// builds dwords j and j + 1 of copy 0 (sixteen block sums) and writes dword j of the eight shifted copies -- no round trip
+// through sh.base, no second barrier.  Used where a workgroup does not walk to an offset but starts there: offset 8 of the
+// byte-phase grid (the reference's own search, PM/GPS/acquisition.c:280-312) and the second half of a split fine grid.
+__device__ __forceinline__ void mx_vector_build_direct(MxShared &sh, int which, int t0s, u32 *e8_dst, int tid)
+{
+  const int iq = tid >> 8, j = tid & 255;
+  const u32 *dd = sh.d[iq];
+  u32 w2[2] = {0, 0};
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k = wrap1023(8 * j + e);
+    const int pos = 16 * k + t0s;
+    const u32 sum = pop16(__builtin_amdgcn_alignbit(dd[(pos >> 5) + 1], dd[pos >> 5], (u32)(pos & 31)));
+    const u32 code = which == 0 ? (0xFEC0u >> (4u * (sum & 3u))) & 0xFu : (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;
+    w2[e >> 3] |= code << (4 * (e & 7));
+  }
+  u32 *dst = e8_dst + (iq * 8) * kCopyDwords + j;   // [stream][copy][dword]
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(w2[1], w2[0], 4u * (u32)c) : w2[0];
+}
+
+// The four vectors of the byte-phase form (sample offsets 0 and 8, low and high part each) in two phases: the block sums
+// S_t0[k] = pop(D[16 k + t0, +16)) once, as bytes (in the polyphase planes' LDS, which this form does not use), then thread
+// (stream, j) looks up its sixteen sums per offset and writes dword j of the eight shifted copies of all four vectors: a
+// third of the instructions of four mx_vector_build_direct calls (which recount every sum for each vector).
+//   vectors: sh.e8[0] / sh.e8[1] = offset 0 low / high, e8x / e8x + one vector = offset 8 low / high
+__device__ __forceinline__ void mx_build_byte_vectors(MxShared &sh, u32 *e8x, int tid)
+{
+  uint8_t *sums = reinterpret_cast<uint8_t *>(&sh.plane[0][0][0]);   // [stream][offset 0 / 8][1024]
+  static_assert(sizeof(sh.plane) >= 2 * 2 * 1024, "block sums fit the planes");
+  for (int m = tid; m < 2 * 512; m += kMxThreads) {
+    const int iq = m >> 9, w = m & 511;
+    const u32 x0 = sh.d[iq][w], x8 = __builtin_amdgcn_alignbit(sh.d[iq][w + 1], x0, 8u);
+    // (word 511: its low half = the sixteen never-mixed samples, then the stream wraps; sums 1023 do not exist and are not read)
+    reinterpret_cast<uint16_t *>(sums + (2 * iq) * 1024)[w] = (uint16_t)(pop16(x0) | ((u32)__popc(x0 >> 16) << 8));
+    reinterpret_cast<uint16_t *>(sums + (2 * iq + 1) * 1024)[w] = (uint16_t)(pop16(x8) | ((u32)__popc(x8 >> 16) << 8));
+  }
+  __syncthreads();
+  const int iq = tid >> 8, j = tid & 255;
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const uint8_t *sv = sums + (2 * iq + o) * 1024;
+    u32 lo[2] = {0, 0}, hi[2] = {0, 0};   // [which]: dwords j and j + 1 of copy 0
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const u32 sum = sv[wrap1023(8 * j + e)];
+      const u32 c0 = (0xFEC0u >> (4u * (sum & 3u))) & 0xFu;      // -2 (S & 3) = 0, -2, -4, -6 -> codes 0, C, E, F
+      const u32 c1 = (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;    // -(S >> 2) = 0 .. -4 -> codes 0, A, C, D, E
+      if (e < 8) {
+        lo[0] |= c0 << (4 * e);
+        lo[1] |= c1 << (4 * e);
+      } else {
+        hi[0] |= c0 << (4 * (e - 8));
+        hi[1] |= c1 << (4 * (e - 8));
+      }
+    }
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+      u32 *base = o ? e8x + which * (2 * 8 * kCopyDwords) : &sh.e8[which][0][0][0];
+      u32 *dst = base + (iq * 8) * kCopyDwords + j;
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi[which], lo[which], 4u * (u32)c) : lo[which];
+    }
+  }
+}
+
 // One anti-diagonal of a pass (fragment Q0 + 2 S): request the fragments of the next one, then the MFMAs of this one.
 // The sched_group_barriers pin that order -- the DS reads first, (8 MFMAs = 260 cycles ahead of their use) -- which the
 // scheduler, short of registers, would otherwise turn into "requested one MFMA before the wait": the LDS is kept busy by
@@ -382,11 +461,13 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
 // requested where the compiler sees fit before its use
 template <bool AHEAD>
 __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][kMxTiles],
-                                        u32 scale_b, v4i a_corr, bool with_corr)
+                                        u32 scale_b, v4i a_corr, bool with_corr, const u32 *e8_buf = nullptr)
 {
   const int n = lane & 31, h = lane >> 5;
-  lds_cu32 *wi = lds_opaque(&sh.e8[buf][0][n & 7][4 * (q0_tile + h) + (n >> 3)]);
-  lds_cu32 *wq = lds_opaque(&sh.e8[buf][1][n & 7][4 * (q0_tile + h) + (n >> 3)]);
+  // (e8_buf: a vector's eight shifted copies somewhere else than sh.e8[buf] -- the byte-phase form keeps four vectors)
+  const u32 *e8 = e8_buf ? e8_buf : &sh.e8[buf][0][0][0];
+  lds_cu32 *wi = lds_opaque(e8 + (n & 7) * kCopyDwords + 4 * (q0_tile + h) + (n >> 3));
+  lds_cu32 *wq = lds_opaque(e8 + (8 + (n & 7)) * kCopyDwords + 4 * (q0_tile + h) + (n >> 3));
   const v4i *ca = &sh.chips_a[0][h][n];
   v4i a[16];
   if constexpr (AHEAD) {
@@ -489,6 +570,9 @@ __device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0
 // A_b = 2 pop(byte_o & low_b) - b (quirk Q5); W = data bytes (2045, 0), the word at the wrap; P = data bytes (o - 2, o - 1),
 // T = [q > 0]: the two replica words odd offsets skip (quirk Q3); alpha_b = b, beta_b = 16 - 2 pop(W) - b because the low
 // byte of W (data byte 2045, never mixed) is zero.  At b = 0: A = 0, alpha = 0.
+// DIRECT: the accumulators were started afresh for sample offset 8 (mx_vector_build_direct) -- they never held A_7 of the even
+// offsets, so only the odd offset's own terms are put in.
+template <bool DIRECT>
 __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int win_start,
                                                int win_stop)
 {
@@ -505,8 +589,8 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
     const bool in0 = exists && 2 * q >= win_start && 2 * q < win_stop;
     const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
     // A_7 of the even offset goes, A_0 = 0 of the odd one comes
-    int fa_i = -(2 * (int)__popc(lds_byte(sh.d[0], 2 * qc) & 0x7Fu) - 7);
-    int fa_q = -(2 * (int)__popc(lds_byte(sh.d[1], 2 * qc) & 0x7Fu) - 7);
+    int fa_i = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(sh.d[0], 2 * qc) & 0x7Fu) - 7);
+    int fa_q = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(sh.d[1], 2 * qc) & 0x7Fu) - 7);
     int fk_i = -popw_i, fk_q = -popw_q;
     if (q > 0 && exists) {
       const u32 prev_i = lds_byte(sh.d[0], 2 * qc - 1) | (lds_byte(sh.d[0], 2 * qc) << 8);
@@ -838,7 +922,7 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
   }
 }
 
-constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3;   // k_acq_mx's MODE
+constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4;   // k_acq_mx's MODE
 
 }  // namespace
 
@@ -887,6 +971,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
                                                           u32 *__restrict__ flags)
 {
   constexpr bool MULTI = MODE == kMxWalk || MODE == kMxWalk16, STORE = MODE == kMxStore, S16 = MODE == kMxWalk16;
+  constexpr bool BYTE = MODE == kMxByte;   // single block, byte-phase grid (its own instantiation: branches around the
+                                           // accumulator arrays in the fine grid's loop cost that form its registers)
   typedef SumRecT<S16> SumRec;
   if constexpr (MODE == kMxWalk) {
     if (flags && flags[blockIdx.x] == 0)   // (uniform: the 16-bit run of this cluster was exact)
@@ -931,10 +1017,14 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     const u32 *src_t = mx_t + (size_t)set * 1032;
     for (int i = tid; i < 1032; i += kMxThreads)
       sh.chip_t[i] = src_t[i];
-    for (int i = tid; i < 8 * 32 * 2 * 32 / 4; i += kMxThreads)
+    for (int i = tid; i < (BYTE ? 1 : 8) * 32 * 2 * 32 / 4; i += kMxThreads)   // (BYTE: bit shift 0 only, the rest holds vectors)
       reinterpret_cast<uint4 *>(&sh.part[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
-    mx_fill_tables(sh, tid);
+    if constexpr (!BYTE)
+      mx_fill_tables(sh, tid);
   }
+  const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
+  const uint8_t *block0 = if_blocks + (size_t)(search * prm.search_stride_blocks + (STORE ? (int)blockIdx.x % prm.n_ms : 0)) * block_bytes;
+  mx_load_block(sh, block0, prm.if_format, tid);
 
   __syncthreads();
   // A operand of the extra K step: column 0 of lane half 0 = chip 1022 of PRN (lane & 31), of half 1 = chip 1021
@@ -948,28 +1038,54 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   }
   u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * (S16 ? 2 : 3)) : nullptr;   // dwords per record
   u32 witness = 0;   // S16: OR of every sum this lane stored
-  const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const int n_ms = MULTI ? prm.n_ms : 1;
-  // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid:
-  // the passes stop after the one that leads to offset 8, and only those two offsets have an epilogue -- the recurrence
-  // steps between them are matrix-pipe work alone.
-  const bool byte_mode = MODE == kMxSingle && prm.n_bits == 1;
-  const int n_pass = byte_mode ? 10 : kPasses;
+  // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid;
+  // MODE kMxByte starts each from its own block sums: four passes, two epilogues (round 2 walked ten of the seventeen passes
+  // to get from offset 0 to offset 8).
+  constexpr int n_pass = kPasses;
 #pragma unroll 1
   for (int ms = 0; ms < n_ms; ms++) {
     const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
-    __syncthreads();   // the previous block's readers are done
-    mx_prepare_block(sh, if_blocks + (size_t)(search * prm.search_stride_blocks + ms + ms_store) * block_bytes,
-                     prm.if_format, step_word, tid, lane);
-    __syncthreads();
-    // the first two vectors (from the popcounts of sample offset 0), by the two-phase builders
-    mx_vector_phase1(sh, 0, 0, tid, kMxThreads);
-    __syncthreads();
-    mx_vector_phase2(sh, 0, tid, kMxThreads);
-    __syncthreads();
-    mx_vector_phase1(sh, 1, 1, tid, kMxThreads);
-    __syncthreads();
-    mx_vector_phase2(sh, 1, tid, kMxThreads);
+    if (ms > 0) {
+      __syncthreads();   // the previous block's readers are done
+      mx_load_block(sh, block0 + (size_t)ms * block_bytes, prm.if_format, tid);
+      __syncthreads();
+    }
+    mx_wipe_block<!BYTE>(sh, step_word, tid, lane);
+    if constexpr (BYTE) {
+      // Byte-phase grid: sample offsets 0 and 8, each from its own block sums -- all four vectors are built here (the third
+      // and fourth in the search-result slots of bit shifts 1..7, which this form does not have), and then every wave runs
+      // its six stages with no barrier at all: waves 4..7 start one pass late, so that on every SIMD one wave's epilogue runs
+      // under the other's matrix passes.
+      u32 *e8x = &sh.part[1][0][0][0];   // 7 x 8 KB free; two vectors take 2 x 16.25 KB
+      static_assert(sizeof(sh.part) - sizeof(sh.part[0]) >= 2 * 2 * 8 * kCopyDwords * sizeof(u32), "room for two vectors");
+      mx_build_byte_vectors(sh, e8x, tid);
+      __syncthreads();
+      if (role == 1)
+        __builtin_amdgcn_s_sleep(72);   // ~4.6 K cycles: one pass
+      v16f acc[2][kMxTiles];
+#pragma unroll 1
+      for (int o = 0; o < 2; o++) {      // sample offset 8 o (one copy of the stages: two unrolled ones spill)
+        const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + 2 * 8 * kCopyDwords : &sh.e8[1][0][0][0];
+        mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
+        mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
+        if (o)
+          mx_half_switch<true>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        mx_epilogue_single(sh, lane, kq, 8 * o, acc);
+      }
+      continue;
+    } else {
+      __syncthreads();
+      // the first two vectors (from the popcounts of sample offset 0), by the two-phase builders
+      mx_vector_phase1(sh, 0, 0, tid, kMxThreads);
+      __syncthreads();
+      mx_vector_phase2(sh, 0, tid, kMxThreads);
+      __syncthreads();
+      mx_vector_phase1(sh, 1, 1, tid, kMxThreads);
+      __syncthreads();
+      mx_vector_phase2(sh, 1, tid, kMxThreads);
+    }
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
@@ -1010,7 +1126,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
             __builtin_amdgcn_s_setprio(0);
         }
         if (p == 9)
-          mx_half_switch(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+          mx_half_switch<false>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
       }
       if (STORE) {
         if (active && (x & 1) && p >= 1) {
@@ -1018,7 +1134,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
                              ((size_t)((search * prm.n_ms + ms_store) * prm.n_prn + 32 * set) * prm.n_dopp + dopp) * (16 * 1024);
           mx_epilogue_store(lane, q0_tile, p - 1, acc, group_mask, plane0, (size_t)prm.n_dopp * (16 * 1024), 32 * set, prm.n_prn);
         }
-      } else if (active && (x & 1) && p >= 1 && !(ex & 1) && (!byte_mode || p == 1 || p == 9)) {
+      } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
         if (!MULTI)
           mx_epilogue_single(sh, lane, kq, p - 1, acc);
         else if (!ms_last)
@@ -1115,6 +1231,11 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
       hipLaunchKernelGGL(k_acq_mx<kMxWalk>, dim3(n_wg), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
                          d_energy, d_flags);
     return "k_acq_mx<3>";
+  }
+  if (prm.n_bits == 1) {   // byte-phase grid: sample offsets 0 and 8, each started from its own block sums
+    hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+                       d_peaks, (u32 *)nullptr, (u32 *)nullptr);
+    return "k_acq_mx<4>";
   }
   hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                      d_peaks, (u32 *)nullptr, (u32 *)nullptr);

@@ -272,12 +272,26 @@ def test_acq_grid_full_cold_start_grid_vs_oracle(eng, oracle):
 
 
 def test_acq_grid_reference_native_grid_29_bins_byte_phases(eng, oracle, stream):
-    prns = np.array([5, 14, 20, 30, 1], np.uint8)
+    """The reference's own search grid (PM/GPS/acquisition.c:280-312, PM/config.h:41-44): 2046 byte phases x 29 Doppler bins
+    (+-7 kHz at 500 Hz), all 32 PRNs, two captures -- k_acq_mx<4>: sample offsets 0 and 8 of the fine grid, each started
+    directly from its own block sums (four matrix passes).  Then windows that cut through the even / odd offsets of one chip
+    offset, and a PRN list that is not a multiple of the cluster."""
     from stm32f4_sdr_gps_amd.capi import PHASES_BYTE
-    peaks, _ = eng.acq_grid(stream[4:5], prns, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=PHASES_BYTE)
-    want = oracle.acq_grid(stream[4:5], 1, prns, -7000, 500, 29, 1, n_threads=4)
-    for f in ("max_val", "phase", "sum", "avr"):
-        assert np.array_equal(peaks[0][f], want[f]), f
+    prns = np.arange(1, 33, dtype=np.uint8)
+    peaks, _ = eng.acq_grid(stream[4:6], prns, n_search=2, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=PHASES_BYTE)
+    assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<4>"
+    for s_ in range(2):
+        want = oracle.acq_grid(stream[4 + s_:5 + s_], 1, prns, -7000, 500, 29, 1, n_threads=8)
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(peaks[s_][f], want[f]), (s_, f)
+    prns5 = np.array([5, 14, 20, 30, 1, 33, 210], np.uint8)
+    for win in ((0, 1), (1, 2), (1, 2046), (0, 2045), (777, 778), (778, 779), (100, 1901), (2045, 2046), (3, 3)):
+        peaks, _ = eng.acq_grid(stream[2:3], prns5, dopp_min_hz=-1000, dopp_step_hz=1000, n_dopp=3, phase_mode=PHASES_BYTE, win=win)
+        assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<4>"
+        for p, prn in enumerate(prns5):
+            for d in range(3):
+                pk, _, _ = oracle.search_job(stream[2:3], 1, oracle.ca_code(int(prn)), float(IF_HZ - 1000 + 1000 * d), 0, win[0], win[1])
+                assert _peak_tuple(peaks[0, p, d, 0]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), (win, p, d)
 
 
 def test_acq_grid_non_coherent_10ms_and_per_ms_triplets(eng, oracle, stream):
@@ -466,8 +480,9 @@ def test_track_epl_graph_cache_alternating_shapes_and_formats(oracle, stream):
         one = synth.make_if(2, sats, seed=21)
         two = synth.make_if(2, sats, seed=21, two_bit=True)
         rng = np.random.default_rng(3)
-        for trial in range(24):
-            n = (1, 4, 2, 7, 1, 33, 4, 300)[trial % 8]              # eight shapes, cache of four
+        for trial in range(44):
+            # capacities 4, 8, .. 4096 (next power of two) x two formats = up to 20 shapes, a cache of twelve
+            n = (1, 5, 9, 17, 33, 65, 300, 600, 1500, 3000, 2)[trial % 11]
             two_bit = trial % 3 == 0
             e.set_if_format(capi.IF_2BIT_SM if two_bit else capi.IF_1BIT)
             st = np.zeros(n, capi.TRK_DTYPE)
