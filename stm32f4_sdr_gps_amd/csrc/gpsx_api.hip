@@ -147,6 +147,7 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     const int v = std::atoi(sg);
     ctx->seg_force = (v == 4 || v == 8 || v == 16) ? v : 0;
   }
+  ctx->no_split = std::getenv("GPSX_ACQ_NO_SPLIT") != nullptr;
   if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
     ctx->ms_mode = std::strcmp(m, "walk") == 0 ? 1 : (std::strcmp(m, "blocks") == 0 ? 2 : 0);
   if (const char *a = std::getenv("GPSX_ACQ_ALGO")) {
@@ -583,8 +584,13 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
       }
     }
     if (mx) {
+      uint32_t *d_planes = nullptr;
+      if (g->n_ms == 1 && n_bits == 8 && shard_count == 1 && !ctx->no_split && 2 * clusters <= ctx->prop.multiProcessorCount &&
+          ensure_acc(ctx, gpsx_acq_peaks_count(g)) == GPSX_OK)
+        d_planes = ctx->d_acc;
       ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
-                                       ctx->d_grid_mx_t, d_peaks, ctx->d_energy, mx_blocks, gpsx_acq_peaks_count(g));
+                                       ctx->d_grid_mx_t, d_peaks, ctx->d_energy, mx_blocks, gpsx_acq_peaks_count(g), d_planes,
+                                       ctx->prop.multiProcessorCount);
       LAUNCHCHK(ctx, "k_acq_mx");
       if (d_keys) {
         launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,

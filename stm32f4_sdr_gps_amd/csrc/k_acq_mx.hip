@@ -922,7 +922,7 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
   }
 }
 
-constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4;   // k_acq_mx's MODE
+constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5;   // k_acq_mx's MODE
 
 }  // namespace
 
@@ -971,6 +971,10 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
                                                           u32 *__restrict__ flags)
 {
   constexpr bool MULTI = MODE == kMxWalk || MODE == kMxWalk16, STORE = MODE == kMxStore, S16 = MODE == kMxWalk16;
+  // SPLIT: the single-block fine grid for launches that leave most of the chip idle -- two workgroups per cluster, sample offsets
+  // 0..7 and 8..15, the second one started directly at offset 8 (as the byte-phase form does); their search results meet in
+  // two global u32 planes (`energy` = packed keys, behind them the sums: atomicMax / atomicAdd) that k_acq_finalize converts
+  constexpr bool SPLIT = MODE == kMxSplit;
   constexpr bool BYTE = MODE == kMxByte;   // single block, byte-phase grid (its own instantiation: branches around the
                                            // accumulator arrays in the fine grid's loop cost that form its registers)
   typedef SumRecT<S16> SumRec;
@@ -989,7 +993,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   // ---- decode: cluster = (search, Doppler, set of 32 PRN slots); its four 8-PRN groups are sharding units -----------
   const int n_sets = (prm.n_groups + 3) / 4;
   const int ms_store = STORE ? (int)blockIdx.x % prm.n_ms : 0;
-  const int cluster = cluster_lo + (STORE ? (int)blockIdx.x / prm.n_ms : (int)blockIdx.x);
+  const int seg = SPLIT ? (int)blockIdx.x & 1 : 0;       // SPLIT: which half of the sample offsets
+  const int cluster = cluster_lo + (STORE ? (int)blockIdx.x / prm.n_ms : SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x);
   const int set = cluster % n_sets;
   const int sd = cluster / n_sets;
   const int dopp = sd % prm.n_dopp;
@@ -1042,7 +1047,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid;
   // MODE kMxByte starts each from its own block sums: four passes, two epilogues (round 2 walked ten of the seventeen passes
   // to get from offset 0 to offset 8).
-  constexpr int n_pass = kPasses;
+  constexpr int n_pass = SPLIT ? 9 : kPasses;   // SPLIT: passes 0..8 (offsets 0..7), or two direct passes + seven steps (8..15)
+  const int pbase = seg ? 8 : 0;                // SPLIT, second half: local pass lp >= 2 is pass 8 + lp of the full walk
 #pragma unroll 1
   for (int ms = 0; ms < n_ms; ms++) {
     const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
@@ -1075,6 +1081,12 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         mx_epilogue_single(sh, lane, kq, 8 * o, acc);
       }
       continue;
+    } else if (SPLIT && seg) {
+      // second half: the first two vectors from the block sums of sample offset 8 (the planes' barrier is the loop's first)
+      mx_vector_build_direct(sh, 0, 8, &sh.e8[0][0][0][0], tid);
+      mx_vector_build_direct(sh, 1, 8, &sh.e8[1][0][0][0], tid);
+      for (int i = tid; i < 2 * 2 * 2 * 128; i += kMxThreads)
+        (&sh.corr[0][0][0][0])[i] = 0;
     } else {
       __syncthreads();
       // the first two vectors (from the popcounts of sample offset 0), by the two-phase builders
@@ -1108,7 +1120,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         __syncthreads();
         const int p_vec = (hs >> 1) + 1;
         if (p_vec >= 2 && p_vec < n_pass && !(ex & 8))
-          mx_vector_build(sh, p_vec, tid);
+          mx_vector_build(sh, pbase + p_vec, tid);
       }
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
       const bool active = x >= 0 && x < 2 * n_pass;
@@ -1121,12 +1133,17 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         if (!(ex & 2)) {
           if (ex & 16)
             __builtin_amdgcn_s_setprio(3);
-          mx_pass<!MULTI>(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && p != 9);
+          mx_pass<!MULTI>(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && (SPLIT || p != 9));
           if (ex & 16)
             __builtin_amdgcn_s_setprio(0);
         }
-        if (p == 9)
-          mx_half_switch<false>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        if constexpr (SPLIT) {
+          if (p == 1 && seg)
+            mx_half_switch<true>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        } else {
+          if (p == 9)
+            mx_half_switch<false>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        }
       }
       if (STORE) {
         if (active && (x & 1) && p >= 1) {
@@ -1136,7 +1153,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         }
       } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
         if (!MULTI)
-          mx_epilogue_single(sh, lane, kq, p - 1, acc);
+          mx_epilogue_single(sh, lane, kq, SPLIT && seg ? (p == 1 ? 8 : 7 + p) : p - 1, acc);
         else if (!ms_last)
           mx_epilogue<MULTI, false, S16>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
         else
@@ -1178,8 +1195,15 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       t += vals[l];
     }
     if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn && b < prm.n_bits) {
-      uint2 *pk = reinterpret_cast<uint2 *>(&peaks[((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits + b]);
-      if (which == 0) {
+      const size_t idx = ((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits + b;
+      uint2 *pk = reinterpret_cast<uint2 *>(&peaks[idx]);
+      if constexpr (SPLIT) {   // `flags` = the planes' length: keys [0, n), sums [n, 2 n)
+        const size_t n_planes = (size_t)(uintptr_t)flags;
+        if (which == 0)
+          atomicMax(&energy[idx], k);
+        else
+          atomicAdd(&energy[n_planes + idx], t);
+      } else if (which == 0) {
         const u32 max_val = k >> 11;
         pk[0] = make_uint2(max_val, max_val ? 2047u - (k & 2047u) : 0u);   // gpsx_peak_t: max_val, phase
       } else {
@@ -1208,7 +1232,8 @@ long acq_mx_clusters(const AcqParams &prm)
 }
 
 const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
-                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks)
+                          const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks,
+                          uint32_t *d_planes, int n_cus)
 {
   if (prm.unit_hi <= prm.unit_lo)
     return "";
@@ -1236,6 +1261,14 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                        d_peaks, (u32 *)nullptr, (u32 *)nullptr);
     return "k_acq_mx<4>";
+  }
+  if (d_planes && 2 * (c_hi - c_lo) <= n_cus) {
+    // fewer clusters than half the chip (a lone cold start is 21): two workgroups per cluster, eight sample offsets each
+    (void)hipMemsetAsync(d_planes, 0, 2 * n_peaks * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(2 * (c_hi - c_lo))), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a,
+                       d_mx_t, d_peaks, d_planes, reinterpret_cast<u32 *>((uintptr_t)n_peaks));
+    launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks);
+    return "k_acq_mx<5>";
   }
   hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                      d_peaks, (u32 *)nullptr, (u32 *)nullptr);

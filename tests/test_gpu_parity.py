@@ -259,7 +259,7 @@ def test_acq_grid_full_cold_start_grid_vs_oracle(eng, oracle):
     blk = synth.cold_start_block(1, seed=11)
     prns = np.arange(1, 33, dtype=np.uint8)
     peaks, keys = eng.acq_grid(blk, prns, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
-    assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<0>"       # the default engine's fine grid = the bench's kernel
+    assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<5>"       # a lone capture: 21 clusters as 42 workgroups (split form)
     want = oracle.acq_grid(blk, 1, prns, -5000, 500, 21, 8, n_threads=8)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(peaks[0][f], want[f]), f
@@ -799,7 +799,7 @@ def capi_peak_dtype():
 
 
 _ALT_KERNELS = {   # what gpsx_last_kernel must report per algorithm for (single-block, multi-block) fine grids
-    "mx": (b"k_acq_mx<0>", b"k_acq_mx<"), "poly": (b"k_acq_poly<", b"k_acq_poly<"), "dot8": (b"k_acq<8,false,dot8>", b"k_acq<8,true,dot8>"),
+    "mx": (b"k_acq_mx<5>", b"k_acq_mx<"), "poly": (b"k_acq_poly<", b"k_acq_poly<"), "dot8": (b"k_acq<8,false,dot8>", b"k_acq<8,true,dot8>"),
     "sad": (b"k_acq<8,false,sad>", b"k_acq<8,true,sad>"), "seg4": (b"k_acq_poly<", b"k_acq_poly<"), "seg8": (b"k_acq_poly<", b"k_acq_poly<"),
     "seg16": (b"k_acq_poly<", b"k_acq_poly<")}
 
@@ -863,18 +863,22 @@ def eng_poly():
 
 @pytest.fixture(scope="module")
 def eng_mx():
-    """An engine whose fine grids all run on the matrix cores (k_acq_mx.hip), whatever their size."""
+    """An engine whose single-block fine grids all run k_acq_mx<0> -- the bench's kernel, one workgroup per cluster -- whatever
+    their size ($GPSX_ACQ_NO_SPLIT: small launches would otherwise take the split form k_acq_mx<5>, which the default
+    engine's tests cover)."""
     import os
     from stm32f4_sdr_gps_amd import capi
-    old = os.environ.get("GPSX_ACQ_ALGO")
+    old = {k: os.environ.get(k) for k in ("GPSX_ACQ_ALGO", "GPSX_ACQ_NO_SPLIT")}
     os.environ["GPSX_ACQ_ALGO"] = "mx"
+    os.environ["GPSX_ACQ_NO_SPLIT"] = "1"
     try:
         e = capi.Engine(0)
     finally:
-        if old is None:
-            del os.environ["GPSX_ACQ_ALGO"]
-        else:
-            os.environ["GPSX_ACQ_ALGO"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     yield e
     e.close()
 
