@@ -550,6 +550,12 @@ def main():
                     "mfma_busy_frac": (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (launch_ms * 1e-3 * clk_khz * 1e3))
                                       if counters and counters.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
                     "counter_source": counters.get("source") if counters else None}
+            roof["frac_live"] = roof["frac"]           # this run: HIP events on the engine's stream around the K launches
+            if counters and counters.get("kernel_trace_avg_ns"):
+                # the committed rocprofv3 kernel trace of the same command (profiles/<tag>_kernel_stats.csv): the profiled run
+                # clocks a few per cent lower, so its fraction is the smaller one -- both are reported, neither is hidden
+                roof["profiled_kernel_ms"] = counters["kernel_trace_avg_ns"] * 1e-6
+                roof["frac_profiled"] = flops / (counters["kernel_trace_avg_ns"] * 1e-9) / 1e12 / MFMA_FP4_PEAK_TFLOPS
             if counters and counters.get("gpu_cycles_per_launch") and counters.get("SQ_VALU_MFMA_BUSY_CYCLES"):
                 # the profiled launch: shader cycles actually spent (the clock follows the power budget) -- the share of
                 # them the matrix pipe was busy, and the clock they imply; `frac` above is against the 2.4 GHz peak

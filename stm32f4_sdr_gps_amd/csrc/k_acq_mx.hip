@@ -142,9 +142,9 @@ __device__ void mx_wipe_block(MxShared &sh, u32 step_word, int tid, int lane)
       ones_i += __popc(vi);
       ones_q += __popc(vq);
     }
-    ones_i = wave_sum_u32(ones_i);
-    ones_q = wave_sum_u32(ones_q);
-    if (lane == 0) {
+    ones_i = wave_sum_to_lane63(ones_i);   // (DPP: no lane-address constants to keep in -- or spill from -- registers)
+    ones_q = wave_sum_to_lane63(ones_q);
+    if (lane == 63) {
       atomicAdd(&sh.ones[0], ones_i);
       atomicAdd(&sh.ones[1], ones_q);
     }
@@ -985,7 +985,12 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __shared__ MxShared sh;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values in SGPRs)
-  const int ex = prm.experiment;   // timing ablations: 1 = no epilogue, 2 = no MFMA (noise-sized counts instead), 4 = both roles in
+#ifdef GPSX_MX_ABLATIONS
+  const int ex = prm.experiment;
+#else
+  constexpr int ex = 0;            // (production builds carry none of it: its hoisted constants cost the walk form 16 registers)
+#endif
+                                   // timing ablations: 1 = no epilogue, 2 = no MFMA (noise-sized counts instead), 4 = both roles in
                                    // step, 8 = no vector building, 16 = raised priority for the MFMA passes
   const int role = (ex & 4) ? 0 : wave >> 2;             // waves w and w + 4 share a SIMD: half a step apart
   const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
@@ -1052,12 +1057,17 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 #pragma unroll 1
   for (int ms = 0; ms < n_ms; ms++) {
     const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
+    // (the walk forms: thread indices made opaque per block, so that the preamble's per-thread address arithmetic is redone
+    //  per block instead of being hoisted out of this loop into registers that the step loop below then has to spill)
+    int tid_p = tid, lane_p = lane;
+    if constexpr (MULTI)
+      asm volatile("" : "+v"(tid_p), "+v"(lane_p));
     if (ms > 0) {
       __syncthreads();   // the previous block's readers are done
-      mx_load_block(sh, block0 + (size_t)ms * block_bytes, prm.if_format, tid);
+      mx_load_block(sh, block0 + (size_t)ms * block_bytes, prm.if_format, tid_p);
       __syncthreads();
     }
-    mx_wipe_block<!BYTE>(sh, step_word, tid, lane);
+    mx_wipe_block<!BYTE>(sh, step_word, tid_p, lane_p);
     if constexpr (BYTE) {
       // Byte-phase grid: sample offsets 0 and 8, each from its own block sums -- all four vectors are built here (the third
       // and fourth in the search-result slots of bit shifts 1..7, which this form does not have), and then every wave runs
@@ -1090,17 +1100,17 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     } else {
       __syncthreads();
       // the first two vectors (from the popcounts of sample offset 0), by the two-phase builders
-      mx_vector_phase1(sh, 0, 0, tid, kMxThreads);
+      mx_vector_phase1(sh, 0, 0, tid_p, kMxThreads);
       __syncthreads();
-      mx_vector_phase2(sh, 0, tid, kMxThreads);
+      mx_vector_phase2(sh, 0, tid_p, kMxThreads);
       __syncthreads();
-      mx_vector_phase1(sh, 1, 1, tid, kMxThreads);
+      mx_vector_phase1(sh, 1, 1, tid_p, kMxThreads);
       __syncthreads();
-      mx_vector_phase2(sh, 1, tid, kMxThreads);
+      mx_vector_phase2(sh, 1, tid_p, kMxThreads);
     }
 
     v16f acc[2][kMxTiles];
-    mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+    mx_init_acc(sh, lane_p, q0_tile, acc, prm.win_start, prm.win_stop);
     if (ex & 2) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
 #pragma unroll
       for (int j = 0; j < kMxTiles; j++)
@@ -1119,16 +1129,23 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       if ((hs & 1) == 0) {
         __syncthreads();
         const int p_vec = (hs >> 1) + 1;
-        if (p_vec >= 2 && p_vec < n_pass && !(ex & 8))
-          mx_vector_build(sh, pbase + p_vec, tid);
+        if (p_vec >= 2 && p_vec < n_pass && !(ex & 8)) {
+          int tid_v = tid;
+          if constexpr (MULTI)
+            asm volatile("" : "+v"(tid_v));   // (as above: the builder's addresses are not worth registers across the passes)
+          mx_vector_build(sh, pbase + p_vec, tid_v);
+        }
       }
+      int lane_s = lane;         // (walk forms: opaque per half step, see tid_p -- record addresses are recomputed, not spilled)
+      if constexpr (MULTI)
+        asm volatile("" : "+v"(lane_s));
       const int x = hs - role;   // role-local half step: even = MFMA pass x / 2, odd = epilogue after pass (x - 1) / 2
       const bool active = x >= 0 && x < 2 * n_pass;
       const int p = x >> 1;
       if (active && (x & 1) == 0) {
         if constexpr (MULTI) {
           if (p >= 1)
-            mx_prefetch_sums<0, 4, S16>(e_wave, lane, p - 1, ms_first, pre);
+            mx_prefetch_sums<0, 4, S16>(e_wave, lane_s, p - 1, ms_first, pre);
         }
         if (!(ex & 2)) {
           if (ex & 16)
@@ -1142,7 +1159,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
             mx_half_switch<true>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
         } else {
           if (p == 9)
-            mx_half_switch<false>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+            mx_half_switch<false>(sh, lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
         }
       }
       if (STORE) {
@@ -1155,9 +1172,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         if (!MULTI)
           mx_epilogue_single(sh, lane, kq, SPLIT && seg ? (p == 1 ? 8 : 7 + p) : p - 1, acc);
         else if (!ms_last)
-          mx_epilogue<MULTI, false, S16>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
+          mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
         else
-          mx_epilogue<MULTI, true, S16>(sh, lane, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
+          mx_epilogue<MULTI, true, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
       }
     }
   }
