@@ -630,6 +630,32 @@ template <bool S16>
 struct SumRecT {
   u32 w[S16 ? 2 : 3];
 };
+// The records are a stream: written once per block, read once a block later, a megabyte per workgroup in between -- nothing
+// a cache keeps.  GPSX_MX_NT: non-temporal loads / stores for them (A/B: tools/build_variant.sh).
+template <bool S16>
+__device__ __forceinline__ SumRecT<S16> rec_load(const SumRecT<S16> *p)
+{
+#ifdef GPSX_MX_NT
+  SumRecT<S16> r;
+#pragma unroll
+  for (int i = 0; i < (S16 ? 2 : 3); i++)
+    r.w[i] = __builtin_nontemporal_load(&p->w[i]);
+  return r;
+#else
+  return *p;
+#endif
+}
+template <bool S16>
+__device__ __forceinline__ void rec_store(SumRecT<S16> *p, const SumRecT<S16> &r)
+{
+#ifdef GPSX_MX_NT
+#pragma unroll
+  for (int i = 0; i < (S16 ? 2 : 3); i++)
+    __builtin_nontemporal_store(r.w[i], &p->w[i]);
+#else
+  *p = r;
+#endif
+}
 template <bool S16>
 __device__ __forceinline__ void sums_unpack(const SumRecT<S16> &r, u32 (&s)[4])
 {
@@ -679,7 +705,7 @@ __device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy,
   const SumRecT<S16> *e4 = reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
 #pragma unroll
   for (int i = FIRST; i < FIRST + COUNT; i++)
-    pre[i] = ms_first ? SumRecT<S16>{} : e4[(size_t)i * 64];
+    pre[i] = ms_first ? SumRecT<S16>{} : rec_load<S16>(&e4[(size_t)i * 64]);
 }
 
 // ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
@@ -782,7 +808,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         SumRec nr;
         nr.w[0] = pk_add_sat_u16(pr.w[0], __builtin_amdgcn_perm(mag[1], mag[0], 0x05040100u));
         nr.w[1] = pk_add_sat_u16(pr.w[1], __builtin_amdgcn_perm(mag[3], mag[2], 0x05040100u));
-        *e_rec = nr;
+        rec_store<S16>(e_rec, nr);
         __builtin_amdgcn_sched_barrier(0);
         continue;
       }
@@ -807,7 +833,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 #pragma unroll
         for (int g = 0; g < GS / 4; g++) {
           const u32 o4[4] = {out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]};
-          e_rec[(size_t)g * 64] = sums_pack<S16>(o4);
+          rec_store<S16>(&e_rec[(size_t)g * 64], sums_pack<S16>(o4));
         }
       }
       if (SEARCH && !DIRECT) {   // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/../stm32f4_sdr_gps_amd/csrc"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -fno-fast-math -Wno-unused-function"
-/opt/rocm/bin/hipcc $F -fno-slp-vectorize -DMX_VARIANT_B -DGPSX_MX_ABLATIONS -c k_acq_mx.hip -o ../build/k_acq_mx_b.o
+/opt/rocm/bin/hipcc $F -fno-slp-vectorize -DMX_VARIANT_B ${VARIANT_DEFS:--DGPSX_MX_ABLATIONS} -c k_acq_mx.hip -o ../build/k_acq_mx_b.o
 OBJS=$(ls ../build/*.o | grep -v k_acq_mx)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgpsx_b.so $OBJS ../build/k_acq_mx_b.o -Wl,-rpath,/opt/rocm/lib -ldl
 echo built ../lib/libgpsx_b.so

@@ -8,8 +8,10 @@ for p in "bench:bench_1gpu" "bench_64:bench_1gpu_64_captures" "bench_10ms:bench_
   tail -1 gpurun_out/${T}_${p%%:*}.json > profiles/${T}_${p##*:}.json
 done
 cp gpurun_out/${T}_tracking_latency.json profiles/${T}_tracking_latency.json
-[ -s gpurun_out/${T}_native.json ] && cp gpurun_out/${T}_native.json profiles/r02_native_grid_32x29x2046.json
-[ -s gpurun_out/${T}_pcie_probe.txt ] && grep contexts gpurun_out/${T}_pcie_probe.txt > profiles/r02_pcie_probe.txt
+[ -s gpurun_out/${T}_native.json ] && cp gpurun_out/${T}_native.json profiles/${T}_native_grid_32x29x2046.json
+[ -s gpurun_out/${T}_pcie_probe.txt ] && grep contexts gpurun_out/${T}_pcie_probe.txt > profiles/${T}_pcie_probe.txt
+[ -d gpurun_out/prof_${T}_track ] && python tools/summarize_track_profile.py ${T}_track 212992 > /dev/null
+[ -s gpurun_out/${T}_gputests.log ] && cp gpurun_out/${T}_gputests.log profiles/${T}_gputests.log
 if [ -f gpurun_out/${T}_sweep.txt ]; then
 python - "$T" <<'PY'
 import json, sys
@@ -21,7 +23,7 @@ for l in open(f"gpurun_out/{sys.argv[1]}_sweep.txt"):
                      "ms_per_launch": d["ms"], "hyp_per_s": d["hyp_per_s"]})
 json.dump({"command": "tools/gpu_sweep.sh (tools/bench_grid_kernel.py, $GPSX_ACQ_ALGO=mx|poly; 32 PRN x 21 Doppler x 16368 phases "
                       "per capture, captures resident in HBM)", "tag": sys.argv[1], "rows": rows},
-          open("profiles/r02_launch_size_sweep.json", "w"), indent=1)
+          open(f"profiles/{sys.argv[1]}_launch_size_sweep.json", "w"), indent=1)
 PY
 fi
 ls profiles | grep "^$T"
