@@ -298,6 +298,8 @@ void ecef2pos(const double *r /* ECEF m */, double *pos /* lat, lon (rad), ellip
 void    gps_pos_solve_init(gps_ch_t *channels /* [GPS_SAT_CNT] */);
 void    gps_pos_solve(obsd_t *obs /* [GPS_SAT_CNT] */);
 uint8_t solving_is_busy(void);
+/* obs_data / eph_data / tracking_data of ns channels -> observation records (PM/GPS/RTK/rtklib_common.c:75-92) */
+void    sdrobs2obsd(gps_ch_t *channels, int ns, obsd_t *out);
 extern sol_t  gps_sol;
 extern double final_pos[3];
 /* azimuth / elevation (deg) of the four satellites of the last solution (the reference's global `azel`) */

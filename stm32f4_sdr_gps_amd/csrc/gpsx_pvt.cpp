@@ -414,4 +414,30 @@ void gps_pos_solve(obsd_t *obs)
 
 uint8_t solving_is_busy(void) { return g_phase; }
 
+// Channel observations -> the solver's observation records (rtklib_common.c:75-92): the step between the pseudorange
+// calculation and gps_pos_solve.  The time of reception is week + tow_s (gpst2time: out-of-range seconds read as 0, whole
+// seconds into .time, the fraction into .sec); the SNR byte is the reference's `(unsigned char)(snr + 20.0f) * 4` -- the cast
+// binds to the sum, the product is then truncated to a byte.
+void sdrobs2obsd(gps_ch_t *channels, int ns, obsd_t *out)
+{
+  for (int i = 0; i < ns; i++) {
+    const gps_ch_t &ch = channels[i];
+    double sec = ch.obs_data.tow_s;
+    if (sec < -1E9 || 1E9 < sec)
+      sec = 0.0;
+    gtime_t t;
+    t.time = (time_t)315964800 + (time_t)(86400 * 7 * ch.eph_data.week_gpst + (int)sec);   // (int arithmetic, as the reference's)
+    t.sec = sec - (int)sec;
+    out[i].time = t;
+    out[i].rcv = 1;
+    out[i].sat = ch.prn;
+    out[i].P[0] = ch.obs_data.pseudorange_m;
+    out[i].L[0] = 0;
+    out[i].D[0] = (float)ch.tracking_data.if_freq_offset_hz;
+    out[i].SNR[0] = (unsigned char)((unsigned char)(ch.tracking_data.snr_value + 20.0f) * 4);
+    out[i].LLI[0] = 0;
+    out[i].code[0] = 1;   // CODE_L1C
+  }
+}
+
 }  // extern "C"

@@ -154,3 +154,33 @@ def test_position_solution_against_the_reference_build_on_fresh_scenarios(lib):
             worst = max(worst, d)
             assert d < 1e-6 and abs(sa.dtr[0] - sb.dtr[0]) < 1e-14, (seed, d)
     assert worst < 1e-6
+
+
+def test_sdrobs2obsd_vs_reference(lib_path):
+    """sdrobs2obsd (PM/GPS/RTK/rtklib_common.c:75-92: channel observations -> the solver's observation records, the step
+    between the pseudorange calculation and gps_pos_solve) against tests/golden/f10_obs.npz -- 64 random channel records
+    through the reference's own function (oracle/gen_golden_obs.py) -- byte for byte, and, where the in-place build exists,
+    against it live on fresh records.  Covers gpst2time's out-of-range seconds, negative and fractional seconds, and the SNR
+    byte's cast-then-multiply truncation."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden_obs as G
+    L = C.CDLL(lib_path)
+    off = G.channel_offsets()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "f10_obs.npz"))
+    assert list(g["offsets"]) == off                     # the fixture was made for this layout
+    size, o_pr, o_tow, o_week, o_prn, o_freq, o_snr, obsd_size = off
+    table = np.zeros((len(g["inputs"]), size), np.uint8)
+    for i, (pr, tow, week, prn, freq, snr) in enumerate(g["inputs"]):
+        table[i, o_pr:o_pr + 8] = np.frombuffer(np.float64(pr).tobytes(), np.uint8)
+        table[i, o_tow:o_tow + 8] = np.frombuffer(np.float64(tow).tobytes(), np.uint8)
+        table[i, o_week:o_week + 4] = np.frombuffer(np.int32(week).tobytes(), np.uint8)
+        table[i, o_prn] = int(prn)
+        table[i, o_freq:o_freq + 4] = np.frombuffer(np.float32(freq).tobytes(), np.uint8)
+        table[i, o_snr:o_snr + 4] = np.frombuffer(np.float32(snr).tobytes(), np.uint8)
+    assert np.array_equal(G.run(L, table, obsd_size), g["obsd"])
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libref_pvt.so")
+    if os.path.exists(ref_path):
+        ref = T.load_lazy(ref_path)
+        table2, _ = G.random_table(np.random.default_rng(77), 200, off)
+        assert np.array_equal(G.run(L, table2, obsd_size), G.run(ref, table2, obsd_size))
