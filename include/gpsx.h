@@ -243,7 +243,12 @@ typedef struct {
   uint32_t if_freq_accum;      /* gps_tracking_t.if_freq_accum: read, advanced, written  */
 } gpsx_trk_state_t;
 
-/* if_block: the current 1 ms block (2046 bytes, shared by all channels).  iq_out: n_ch x {IE,QE,IP,QP,IL,QL}. */
+/* if_block: the current 1 ms block (2046 bytes, shared by all channels).  iq_out: n_ch x {IE,QE,IP,QP,IL,QL}.
+ * PRNs are validated BY THE KERNELS, not before the launch (a host loop over the states costs a sixth of the millisecond at
+ * 400 000 channels): a channel whose prn is outside 1..210 is correlated against the empty code, every channel's
+ * if_freq_accum and accumulators ARE written, and the call then returns GPSX_EINVAL.  gpsx_track_epl_batch reports it
+ * itself (it waits for its kernels); gpsx_track_epl_batch_dev only enqueues: its report comes from the next
+ * gpsx_synchronize() on the context (a separate flag: step calls in between neither consume nor clear it). */
 int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out);
 int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_state_t *d_st, int n_ch,
                              int16_t *d_iq_out);
