@@ -141,3 +141,50 @@ def test_batched_tracking_step_matches_per_channel_reference(gpsx_lib):
     assert all(r["trk_state"] == sd.TRK_RUN for r in end)
     for r, truth in zip(end, (1600.0, 4000.0, 9000.0, 13000.0)):
         assert abs(r["code_phase_fine"] - truth) < 1.5
+
+
+_POOL_SCRIPT = r"""
+import ctypes as C, os, sys, zlib
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import steps_driver as sd
+from stm32f4_sdr_gps_amd import capi, synth
+n, ms, n_sig = 4096, 400, 8
+lib = capi.load_library()
+steps = sd.StepsLib(lib, False)
+lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+lib.gps_tracking_process_batch.restype = None
+sats = [synth.Sat(i + 1, -2000.0 + 450.0 * i, (2000.0 * i + 37.0) % 16368, 0.25, 0.3 * i) for i in range(n_sig)]
+stream = synth.make_if(ms, sats, noise_amp=1.0, seed=9)
+per_sig = np.stack([sd.preset_channel(steps, s.prn, int(round(s.doppler_hz / 500.0)) * 500, int(s.delay_samples // 8) % 2046) for s in sats])
+table = np.ascontiguousarray(per_sig[np.arange(n) % n_sig])
+crcs = []
+for t in range(ms):
+    steps.set_time(t)
+    lib.gps_tracking_process_batch(table.ctypes.data, n, stream[t].ctypes.data, t & 3)
+    if t % 25 == 24:
+        crcs.append(zlib.crc32(table[:, :664].tobytes()))
+state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+print("RESULT", int((state == sd.TRK_RUN).sum()), *crcs)
+"""
+
+
+def test_batched_step_on_worker_threads_equals_the_single_threaded_step():
+    """gps_tracking_process_batch spreads its per-channel host loops over worker threads from 2048 channels on
+    (gpsx_steps.cpp StepPool).  4096 channels, 400 ms from pre-tracking into tracking and nav-bit synchronisation: the whole
+    channel table (acq, tracking, nav and observation state of every channel, CRC every 25 ms) must be the same with 1, 3
+    and 7 workers -- a channel's state may not depend on which thread served it or on how the ranges were cut.  (Strong
+    signals: the one shared state of the path, rand() in the PLL's false-lock reseed, is never drawn.)  Separate
+    processes: the pool is sized once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for threads in ("1", "3", "7"):
+        env = dict(os.environ, GPSX_STEP_THREADS=threads)
+        r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        outs.append(line[0])
+    assert outs[0] == outs[1] == outs[2], outs
+    assert int(outs[0].split()[1]) >= 4096 * 7 // 8      # and the channels did reach tracking
