@@ -617,6 +617,74 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
   }
 }
 
+// The general form of the above for a workgroup that STARTS at sample offset t0s = 8 half + b (mx_vector_build_direct gave
+// it C0): everything the walk would have accumulated or patched in by then, as start values --
+//   + c1022 A_b(q),  A_b = 2 pop(byte_o & low_b) - b                                                     (quirk Q5)
+//   - half [ pop(W) + chip[1021 - q] b + chip[1022 - q] (16 - b - 2 pop(W))                               (Q3, wrap word)
+//            + T(q) ( pop(P) + c1021 (b - 2 pop(P & low_b)) + c1022 (16 - b - 2 pop(P & high_b)) ) ]      (Q3, tail word)
+// with o = 2 q + half, W = data bytes (2045, 0), P = data bytes (o - 2, o - 1), T = [q > 0] (the formula in front of
+// mx_half_switch; tests/test_formulation.py).  Five multiply-adds per hypothesis, once per workgroup.
+__device__ __forceinline__ void mx_direct_terms(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int t0s,
+                                                int win_start, int win_stop)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const int b = t0s & 7, half = t0s >> 3;
+  const u32 low = (1u << b) - 1u, high = (0xFFFFu << b) & 0xFFFFu;
+  const float fh = (float)half;
+  const u32 f22 = sh.chip_t[1022 + 1] >> (4 * h), f21 = sh.chip_t[1021 + 1] >> (4 * h);
+  float popw[2], beta[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const int pw = (int)__popc(sh.d[s][0] & 0xFFu);   // W = byte 0 << 8: its low byte (data byte 2045) is never mixed
+    popw[s] = (float)pw;
+    beta[s] = (float)(16 - b - 2 * pw);
+  }
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    const bool exists = q < kChips;
+    const int qc = exists ? q : 0;
+    const int o = 2 * qc + half;
+    const float tq = (qc > 0) ? fh : 0.0f;            // half * T(q)
+    float k0[2], k21[2], k22[2], kb[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const int fa = 2 * (int)__popc(lds_byte(sh.d[s], o) & low) - b;
+      int fp = 0, gl = 0, gh = 0;
+      if (qc > 0 || half == 0) {   // (o >= 2 wherever the tail term counts; for half == 0 the values are multiplied by 0)
+        const int o2 = o >= 2 ? o : 2;
+        const u32 prev = lds_byte(sh.d[s], o2 - 2) | (lds_byte(sh.d[s], o2 - 1) << 8);
+        fp = (int)__popc(prev);
+        gl = b - 2 * (int)__popc(prev & low);
+        gh = 16 - b - 2 * (int)__popc(prev & high);
+      }
+      k0[s] = -(fh * popw[s] + tq * (float)fp) * kAccScale;
+      k21[s] = -tq * (float)gl * kAccScale;
+      k22[s] = ((float)fa - tq * (float)gh) * kAccScale;
+      kb[s] = -fh * beta[s] * kAccScale;
+    }
+    const float ka = -fh * (float)b * kAccScale;
+    if (half) {   // the accumulators were started for the even byte offset's window position
+      const bool in0 = exists && 2 * q >= win_start && 2 * q < win_stop;
+      const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
+      if (in0 != in1) {
+        k0[0] += in1 ? -kOutside : kOutside;
+        k0[1] += in1 ? -kOutside : kOutside;
+      }
+    }
+    const u32 w1 = sh.chip_t[(exists ? kChips - 1 - q : 0) + 1] >> (4 * h);   // chip 1022 - q of the lane's PRNs
+    const u32 w0 = sh.chip_t[(exists ? kChips - 2 - q : -1) + 1] >> (4 * h);  // chip 1021 - q (chip -1 = 0)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int pb = (r & 3) + 8 * (r >> 2);
+      const float c22 = (float)((f22 >> pb) & 1u), c21 = (float)((f21 >> pb) & 1u);
+      const float ca = (float)((w0 >> pb) & 1u), cb = (float)((w1 >> pb) & 1u);
+      acc[0][j][r] += k0[0] + ca * ka + cb * kb[0] + c21 * k21[0] + c22 * k22[0];
+      acc[1][j][r] += k0[1] + ca * ka + cb * kb[1] + c21 * k21[1] + c22 * k22[1];
+    }
+  }
+}
+
 // MULTI: the running sums between blocks: the scratch stream is what binds this form (bench.py `roofline` of the
 // multi-block run), so its records are as small as exactness allows.
 //   S16 = true  (kMxWalk16, the form that runs first): four 16-bit sums in two dwords, moved on by SATURATING packed adds
@@ -1024,8 +1092,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   // ---- decode: cluster = (search, Doppler, set of 32 PRN slots); its four 8-PRN groups are sharding units -----------
   const int n_sets = (prm.n_groups + 3) / 4;
   const int ms_store = STORE ? (int)blockIdx.x % prm.n_ms : 0;
-  const int seg = SPLIT ? (int)blockIdx.x & 1 : 0;       // SPLIT: which half of the sample offsets
-  const int cluster = cluster_lo + (STORE ? (int)blockIdx.x / prm.n_ms : SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x);
+  const int n_seg = SPLIT ? prm.split_segs : 1;          // SPLIT: workgroups per cluster (2, 4 or 8) ...
+  const int seg = SPLIT ? (int)blockIdx.x % n_seg : 0;   // ... and which run of 16 / n_seg sample offsets this one has
+  const int cluster = cluster_lo + (STORE ? (int)blockIdx.x / prm.n_ms : SPLIT ? (int)blockIdx.x / n_seg : (int)blockIdx.x);
   const int set = cluster % n_sets;
   const int sd = cluster / n_sets;
   const int dopp = sd % prm.n_dopp;
@@ -1078,8 +1147,10 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid;
   // MODE kMxByte starts each from its own block sums: four passes, two epilogues (round 2 walked ten of the seventeen passes
   // to get from offset 0 to offset 8).
-  constexpr int n_pass = SPLIT ? 9 : kPasses;   // SPLIT: passes 0..8 (offsets 0..7), or two direct passes + seven steps (8..15)
-  const int pbase = seg ? 8 : 0;                // SPLIT, second half: local pass lp >= 2 is pass 8 + lp of the full walk
+  // SPLIT: two direct passes at sample offset t0s, then 16 / n_seg - 1 steps of the walk (local pass lp >= 2 is pass t0s + lp)
+  const int t0s = SPLIT ? seg * (16 / n_seg) : 0;
+  const int n_pass = SPLIT ? 16 / n_seg + 1 : kPasses;
+  const int pbase = t0s;
 #pragma unroll 1
   for (int ms = 0; ms < n_ms; ms++) {
     const bool ms_first = ms == 0, ms_last = ms == n_ms - 1;
@@ -1118,9 +1189,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       }
       continue;
     } else if (SPLIT && seg) {
-      // second half: the first two vectors from the block sums of sample offset 8 (the planes' barrier is the loop's first)
-      mx_vector_build_direct(sh, 0, 8, &sh.e8[0][0][0][0], tid);
-      mx_vector_build_direct(sh, 1, 8, &sh.e8[1][0][0][0], tid);
+      // not the first run: the first two vectors from the block sums of sample offset t0s (the planes' barrier is the loop's first)
+      mx_vector_build_direct(sh, 0, t0s, &sh.e8[0][0][0][0], tid);
+      mx_vector_build_direct(sh, 1, t0s, &sh.e8[1][0][0][0], tid);
       for (int i = tid; i < 2 * 2 * 2 * 128; i += kMxThreads)
         (&sh.corr[0][0][0][0])[i] = 0;
     } else {
@@ -1181,8 +1252,11 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
             __builtin_amdgcn_s_setprio(0);
         }
         if constexpr (SPLIT) {
-          if (p == 1 && seg)
-            mx_half_switch<true>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+          if (p == 1 && seg) {
+            int lane_d = lane;   // (opaque: the terms' per-lane addresses are not worth registers across the step loop)
+            asm volatile("" : "+v"(lane_d));
+            mx_direct_terms(sh, lane_d, q0_tile, acc, t0s, prm.win_start, prm.win_stop);
+          }
         } else {
           if (p == 9)
             mx_half_switch<false>(sh, lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
@@ -1196,7 +1270,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         }
       } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
         if (!MULTI)
-          mx_epilogue_single(sh, lane, kq, SPLIT && seg ? (p == 1 ? 8 : 7 + p) : p - 1, acc);
+          mx_epilogue_single(sh, lane, kq, t0s + p - 1, acc);
         else if (!ms_last)
           mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
         else
@@ -1306,10 +1380,18 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     return "k_acq_mx<4>";
   }
   if (d_planes && 2 * (c_hi - c_lo) <= n_cus) {
-    // fewer clusters than half the chip (a lone cold start is 21): two workgroups per cluster, eight sample offsets each
+    // fewer clusters than half the chip (a lone cold start is 21): two workgroups per cluster with eight sample offsets each,
+    // four with four each from a quarter of the chip down
+    AcqParams sp = prm;
+    const int nc = c_hi - c_lo;
+    sp.split_segs = 8 * nc <= n_cus ? 8 : 4 * nc <= n_cus ? 4 : 2;   // (a lone cold start: 21 clusters -> 168 workgroups)
+    if (const char *e = std::getenv("GPSX_ACQ_SPLIT")) {   // (tests, A/B: 2, 4 or 8 whatever the launch size)
+      const int v = std::atoi(e);
+      sp.split_segs = v == 8 ? 8 : v == 4 ? 4 : 2;
+    }
     (void)hipMemsetAsync(d_planes, 0, 2 * n_peaks * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(2 * (c_hi - c_lo))), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a,
-                       d_mx_t, d_peaks, d_planes, reinterpret_cast<u32 *>((uintptr_t)n_peaks));
+    hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * (c_hi - c_lo))), dim3(kMxThreads), 0, s, sp, c_lo, d_if,
+                       d_mx_a, d_mx_t, d_peaks, d_planes, reinterpret_cast<u32 *>((uintptr_t)n_peaks));
     launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks);
     return "k_acq_mx<5>";
   }

@@ -799,21 +799,25 @@ def capi_peak_dtype():
 
 
 _ALT_KERNELS = {   # what gpsx_last_kernel must report per algorithm for (single-block, multi-block) fine grids
-    "mx": (b"k_acq_mx<5>", b"k_acq_mx<"), "poly": (b"k_acq_poly<", b"k_acq_poly<"), "dot8": (b"k_acq<8,false,dot8>", b"k_acq<8,true,dot8>"),
+    "mx": (b"k_acq_mx<5>", b"k_acq_mx<"), "mx2": (b"k_acq_mx<5>", b"k_acq_mx<"), "mx4": (b"k_acq_mx<5>", b"k_acq_mx<"), "mx8": (b"k_acq_mx<5>", b"k_acq_mx<"), "poly": (b"k_acq_poly<", b"k_acq_poly<"), "dot8": (b"k_acq<8,false,dot8>", b"k_acq<8,true,dot8>"),
     "sad": (b"k_acq<8,false,sad>", b"k_acq<8,true,sad>"), "seg4": (b"k_acq_poly<", b"k_acq_poly<"), "seg8": (b"k_acq_poly<", b"k_acq_poly<"),
     "seg16": (b"k_acq_poly<", b"k_acq_poly<")}
 
 
-@pytest.mark.parametrize("algo", ["mx", "poly", "dot8", "sad", "seg4", "seg8", "seg16"])
+@pytest.mark.parametrize("algo", ["mx", "mx2", "mx4", "mx8", "poly", "dot8", "sad", "seg4", "seg8", "seg16"])
 def test_alternative_grid_kernels_match_the_oracle(oracle, stream, algo, monkeypatch):
     """Every acquisition kernel in the library against the CPU oracle (not against each other: the default IS mx, a
     comparison with it would be vacuous for mx): mx = the matrix-core kernel, poly = the polyphase VALU kernel, dot8 / sad =
     the direct forms, seg* = the polyphase kernel at a forced number of sample offsets per workgroup (GPSX_ACQ_SEG selects
-    the polyphase kernel by itself).  Windows, a PRN count that is not a multiple of the group, odd Doppler counts and
+    the polyphase kernel by itself); mx on launches this small is the split form k_acq_mx<5> (mx2 / mx4 / mx8: two / four /
+    eight workgroups per cluster, i.e. direct starts at sample offsets 8 / 4, 8, 12 / 2, 4 .. 14 -- every quirk term as a
+    start value).  Windows, a PRN count that is not a multiple of the group, odd Doppler counts and
     steps, multi-block searches; gpsx_last_kernel must name the kernel under test."""
     from stm32f4_sdr_gps_amd import capi
-    var, val = ("GPSX_ACQ_SEG", algo[3:]) if algo.startswith("seg") else ("GPSX_ACQ_ALGO", algo)
+    var, val = ("GPSX_ACQ_SEG", algo[3:]) if algo.startswith("seg") else ("GPSX_ACQ_ALGO", algo[:2] if algo.startswith("mx") else algo)
     monkeypatch.setenv(var, val)
+    if algo in ("mx2", "mx4", "mx8"):      # the split form at two / four / eight workgroups per cluster, whatever the launch size
+        monkeypatch.setenv("GPSX_ACQ_SPLIT", algo[2])
     alt = capi.Engine(0)
     monkeypatch.delenv(var)
     try:
