@@ -45,7 +45,7 @@ struct AcqParams {
   int32_t win_start, win_stop;
   int32_t if_format;        // GPSX_IF_1BIT / GPSX_IF_2BIT_SM
   int32_t if_hz;            // gpsx_config_t.if_hz: centre of the Doppler axis
-  int32_t split_segs;       // k_acq_mx<5> only: workgroups per cluster (2, 4 or 8), set by launch_acq_mx
+  int32_t split_segs;       // set by launch_acq_mx: k_acq_mx<5>: workgroups per cluster (2, 4 or 8); k_acq_mx<4>: clusters of the launch
   int32_t experiment;       // ablations of k_acq_mx for timing (results are then wrong); always 0 unless the library was built
                             // with -DGPSX_MX_ABLATIONS, which alone makes gpsx_api.hip read $GPSX_MX_EXPERIMENT
   // explicit job list (job mode)

@@ -427,11 +427,11 @@ __device__ __forceinline__ void mx_build_byte_vectors(MxShared &sh, u32 *e8x, in
 // The sched_group_barriers pin that order -- the DS reads first, (8 MFMAs = 260 cycles ahead of their use) -- which the
 // scheduler, short of registers, would otherwise turn into "requested one MFMA before the wait": the LDS is kept busy by
 // the four waves of the other role, a wave that waits for it at every step loses a third of the matrix pipe's time.
-template <int S>
+template <int S, int NT>
 __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v4i *ca, v4i (&a)[16], v4i &fi, v4i &fq,
-                                             v16f (&acc)[2][kMxTiles], u32 scale_b)
+                                             v16f (&acc)[2][NT], u32 scale_b)
 {
-  constexpr int kSteps = 16 + kMxTiles - 1;
+  constexpr int kSteps = 16 + NT - 1;
   constexpr bool more = S + 1 < kSteps;
   v4i fi_next = fi, fq_next = fq;
   if constexpr (more) {
@@ -440,7 +440,7 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
     if constexpr (S + 1 < 16)
       a[S + 1] = ca[(S + 1) * 64];                         // chips_a[S + 1][h][n]
   }
-  constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < kMxTiles - 1 ? S : kMxTiles - 1;
+  constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < NT - 1 ? S : NT - 1;
 #pragma unroll
   for (int j = j_lo; j <= j_hi; j++) {
     acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
@@ -454,13 +454,14 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
   fi = fi_next;
   fq = fq_next;
   if constexpr (more)
-    mx_pass_step<S + 1>(wi, wq, ca, a, fi, fq, acc, scale_b);
+    mx_pass_step<S + 1, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
 }
 
 // AHEAD = false (the walk form, whose prefetched sums leave no registers for a second set of fragments): every fragment is
 // requested where the compiler sees fit before its use
-template <bool AHEAD>
-__device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][kMxTiles],
+// NT = q-tiles of this call (q0_tile + 2 j, j < NT): four everywhere but in the byte-phase form, which works in tile pairs
+template <bool AHEAD, int NT>
+__device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][NT],
                                         u32 scale_b, v4i a_corr, bool with_corr, const u32 *e8_buf = nullptr)
 {
   const int n = lane & 31, h = lane >> 5;
@@ -473,15 +474,15 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
   if constexpr (AHEAD) {
     v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
     a[0] = ca[0];
-    mx_pass_step<0>(wi, wq, ca, a, fi, fq, acc, scale_b);
+    mx_pass_step<0, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
   } else {
 #pragma unroll
-    for (int s = 0; s < 16 + kMxTiles - 1; s++) {
+    for (int s = 0; s < 16 + NT - 1; s++) {
       if (s < 16)
         a[s] = ca[s * 64];                                   // chips_a[s][h][n]
       const v4i fi = lds_frag(wi, 8 * s), fq = lds_frag(wq, 8 * s);   // fragment Q0 + 2 s
 #pragma unroll
-      for (int j = 0; j < kMxTiles; j++) {
+      for (int j = 0; j < NT; j++) {
         const int kappa = s - j;
         if (kappa < 0 || kappa >= 16)
           continue;
@@ -496,7 +497,7 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
     // (dword q >> 3 = 4 (q0_tile + 2 j) + n / 8 of the term's vector: one address, constant offsets per tile and stream)
     lds_cu32 *cw = lds_opaque(&sh.corr[buf][0][h][4 * q0_tile + (n >> 3)]);
 #pragma unroll
-    for (int j = 0; j < kMxTiles; j++) {
+    for (int j = 0; j < NT; j++) {
       // (nibble q & 7 of dword q >> 3 moved to nibble 0; what is left above it meets zero columns of A)
       const v4i gi = v4i{(int)(cw[8 * j] >> (4 * (n & 7))), 0, 0, 0};
       const v4i gq = v4i{(int)(cw[8 * j + 2 * 128] >> (4 * (n & 7))), 0, 0, 0};
@@ -545,13 +546,14 @@ constexpr float kOutside = -1048576.0f * kAccScale;   // start value (scaled) of
                                                       // below -1, clips to 0
 
 // Start of a block: every accumulator = the part of  cnt - 8184  that does not depend on the code (even byte offsets)
-__device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int win_start,
+template <int NT>
+__device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][NT], int win_start,
                                             int win_stop)
 {
   const int n = lane & 31;
   const float base_i = (float)((int)sh.ones[0] + 8192 - kHalf) * kAccScale, base_q = (float)((int)sh.ones[1] + 8192 - kHalf) * kAccScale;
 #pragma unroll
-  for (int j = 0; j < kMxTiles; j++) {
+  for (int j = 0; j < NT; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
     const int o = 2 * q;
     const bool in_win = q < kChips && o >= win_start && o < win_stop;
@@ -572,8 +574,8 @@ __device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0
 // byte of W (data byte 2045, never mixed) is zero.  At b = 0: A = 0, alpha = 0.
 // DIRECT: the accumulators were started afresh for sample offset 8 (mx_vector_build_direct) -- they never held A_7 of the even
 // offsets, so only the odd offset's own terms are put in.
-template <bool DIRECT>
-__device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][kMxTiles], int win_start,
+template <bool DIRECT, int NT>
+__device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][NT], int win_start,
                                                int win_stop)
 {
   const int n = lane & 31, h = lane >> 5;
@@ -582,7 +584,7 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
   const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
   const u32 f22 = sh.chip_t[1022 + 1] >> (4 * h);
 #pragma unroll
-  for (int j = 0; j < kMxTiles; j++) {
+  for (int j = 0; j < NT; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
     const bool exists = q < kChips;
     const int qc = exists ? q : 0;
@@ -931,8 +933,9 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 //   mx_epilogue), whose f32 pattern is 0x4B000000 + floor(root): shifted left by 11 the exponent bits fall off the key; the
 //   sums carry 0x4B000000 per term, four terms per PRN and sample offset: they start at -4 x 0x4B000000 (mod 2^32).
 constexpr u32 kRootBias = 0x4B000000u;
-__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[kMxTiles], int t0,
-                                                   const v16f (&acc)[2][kMxTiles])
+template <int NT>
+__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0,
+                                                   const v16f (&acc)[2][NT])
 {
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
@@ -941,10 +944,10 @@ __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     best[r] = 0;
-    total[r] = 0u - 4u * kRootBias;
+    total[r] = 0u - (u32)NT * kRootBias;   // (one biased term per tile and PRN)
   }
 #pragma unroll
-  for (int jp = 0; jp < kMxTiles; jp += 2) {
+  for (int jp = 0; jp < NT; jp += 2) {
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += 4) {
       // eight hypotheses: two tiles x four PRNs
@@ -1058,11 +1061,13 @@ void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slo
 // HBM scratch; `flags`[workgroup] tells whether a sum outgrew them), kMxWalk (the same with 24-bit records: launched behind
 // kMxWalk16, a workgroup does its cluster again if its flag is up and leaves otherwise), kMxStore (a workgroup per block,
 // magnitudes out as u16 for k_acq_vals_search: the form for few multi-block searches)
+// One workgroup's work on one launch index `wg` (= blockIdx.x, except in the persistent byte-phase form, which walks them).
+// `tables_set`: the PRN set whose tables are in LDS (-1: none); returns through it the set this call left there.
 template <int MODE>
-__global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,
-                                                          const u32 *__restrict__ mx_a, const u32 *__restrict__ mx_t,
-                                                          gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
-                                                          u32 *__restrict__ flags)
+__device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int wg, int &tables_set, int cluster_lo,
+                                        const uint8_t *__restrict__ if_blocks, const u32 *__restrict__ mx_a,
+                                        const u32 *__restrict__ mx_t, gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
+                                        u32 *__restrict__ flags)
 {
   constexpr bool MULTI = MODE == kMxWalk || MODE == kMxWalk16, STORE = MODE == kMxStore, S16 = MODE == kMxWalk16;
   // SPLIT: the single-block fine grid for launches that leave most of the chip idle -- two workgroups per cluster, sample offsets
@@ -1073,11 +1078,13 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
                                            // accumulator arrays in the fine grid's loop cost that form its registers)
   typedef SumRecT<S16> SumRec;
   if constexpr (MODE == kMxWalk) {
-    if (flags && flags[blockIdx.x] == 0)   // (uniform: the 16-bit run of this cluster was exact)
+    if (flags && flags[wg] == 0)   // (uniform: the 16-bit run of this cluster was exact)
       return;
   }
-  __shared__ MxShared sh;
-  const int tid = threadIdx.x;
+  int tid_raw = threadIdx.x;
+  if constexpr (MODE == kMxByte)
+    asm volatile("" : "+v"(tid_raw));   // (persistent form: per-thread arithmetic is redone per cluster, not kept across the walk)
+  const int tid = tid_raw;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values in SGPRs)
 #ifdef GPSX_MX_ABLATIONS
   const int ex = prm.experiment;
@@ -1091,10 +1098,10 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 
   // ---- decode: cluster = (search, Doppler, set of 32 PRN slots); its four 8-PRN groups are sharding units -----------
   const int n_sets = (prm.n_groups + 3) / 4;
-  const int ms_store = STORE ? (int)blockIdx.x % prm.n_ms : 0;
+  const int ms_store = STORE ? wg % prm.n_ms : 0;
   const int n_seg = SPLIT ? prm.split_segs : 1;          // SPLIT: workgroups per cluster (2, 4 or 8) ...
-  const int seg = SPLIT ? (int)blockIdx.x % n_seg : 0;   // ... and which run of 16 / n_seg sample offsets this one has
-  const int cluster = cluster_lo + (STORE ? (int)blockIdx.x / prm.n_ms : SPLIT ? (int)blockIdx.x / n_seg : (int)blockIdx.x);
+  const int seg = SPLIT ? wg % n_seg : 0;   // ... and which run of 16 / n_seg sample offsets this one has
+  const int cluster = cluster_lo + (STORE ? wg / prm.n_ms : SPLIT ? wg / n_seg : wg);
   const int set = cluster % n_sets;
   const int sd = cluster / n_sets;
   const int dopp = sd % prm.n_dopp;
@@ -1113,8 +1120,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   const float freq_hz = (float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz);   // PM/GPS/acquisition.c:285-289
   const u32 step_word = nco_step_per_word(freq_hz);
 
-  // tables of the cluster
-  {
+  // tables of the cluster (the persistent form keeps them while the set stays the same)
+  if (tables_set != set) {
     const u32 *src_a = mx_a + (size_t)set * (16 * 2 * 32 * 4);
     u32 *dst_a = reinterpret_cast<u32 *>(&sh.chips_a[0][0][0]);
     for (int i = tid; i < 16 * 2 * 32 * 4; i += kMxThreads)
@@ -1122,13 +1129,14 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     const u32 *src_t = mx_t + (size_t)set * 1032;
     for (int i = tid; i < 1032; i += kMxThreads)
       sh.chip_t[i] = src_t[i];
-    for (int i = tid; i < (BYTE ? 1 : 8) * 32 * 2 * 32 / 4; i += kMxThreads)   // (BYTE: bit shift 0 only, the rest holds vectors)
-      reinterpret_cast<uint4 *>(&sh.part[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
     if constexpr (!BYTE)
       mx_fill_tables(sh, tid);
+    tables_set = set;
   }
+  for (int i = tid; i < (BYTE ? 1 : 8) * 32 * 2 * 32 / 4; i += kMxThreads)   // (BYTE: bit shift 0 only, the rest holds vectors)
+    reinterpret_cast<uint4 *>(&sh.part[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
-  const uint8_t *block0 = if_blocks + (size_t)(search * prm.search_stride_blocks + (STORE ? (int)blockIdx.x % prm.n_ms : 0)) * block_bytes;
+  const uint8_t *block0 = if_blocks + (size_t)(search * prm.search_stride_blocks + (STORE ? wg % prm.n_ms : 0)) * block_bytes;
   mx_load_block(sh, block0, prm.if_format, tid);
 
   __syncthreads();
@@ -1141,7 +1149,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
     if constexpr (!MULTI && !STORE)
       asm volatile("" : "+v"(kq[j]));   // (kept in registers, not rebuilt per group; the other forms do not use them)
   }
-  u32 *e_wave = MULTI ? energy + ((size_t)blockIdx.x * 8 + wave) * (16 * kMxTiles * 4 * 64 * (S16 ? 2 : 3)) : nullptr;   // dwords per record
+  u32 *e_wave = MULTI ? energy + ((size_t)wg * 8 + wave) * (16 * kMxTiles * 4 * 64 * (S16 ? 2 : 3)) : nullptr;   // dwords per record
   u32 witness = 0;   // S16: OR of every sum this lane stored
   const int n_ms = MULTI ? prm.n_ms : 1;
   // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid;
@@ -1174,18 +1182,32 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
       static_assert(sizeof(sh.part) - sizeof(sh.part[0]) >= 2 * 2 * 8 * kCopyDwords * sizeof(u32), "room for two vectors");
       mx_build_byte_vectors(sh, e8x, tid);
       __syncthreads();
-      if (role == 1)
-        __builtin_amdgcn_s_sleep(72);   // ~4.6 K cycles: one pass
-      v16f acc[2][kMxTiles];
+      // Stages of (tile pair, sample offset), four per wave: two passes on two q-tiles (128 MFMAs), the odd offset's terms, one
+      // epilogue (32 hypotheses per lane).  The two waves of a SIMD are held in antiphase by one barrier per stage -- waves
+      // 0..3: passes, then epilogue; waves 4..7: the previous stage's epilogue, then passes -- as in the fine grid's loop.
+      // Left to themselves (no barrier, a head start for one role) they fall into lockstep, which is stable: a wave in its
+      // epilogue next to the other's MFMAs issues at 2/3 of its rate until the other catches up, and from then on both want
+      // the matrix pipe together and the vector ALU together -- measured: passes and epilogues simply added up (0.88 ms).
+      v16f acc[2][2];
 #pragma unroll 1
-      for (int o = 0; o < 2; o++) {      // sample offset 8 o (one copy of the stages: two unrolled ones spill)
-        const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + 2 * 8 * kCopyDwords : &sh.e8[1][0][0][0];
-        mx_init_acc(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-        mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
-        mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
-        if (o)
-          mx_half_switch<true>(sh, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-        mx_epilogue_single(sh, lane, kq, 8 * o, acc);
+      for (int hs = 0; hs <= 8; hs++) {
+        if ((hs & 1) == 0)
+          __syncthreads();
+        const int x = hs - role;
+        if (x < 0 || x >= 8)
+          continue;
+        const int item = x >> 1, o = item >> 1, q0t = q0_tile + 4 * (item & 1);   // sample offset 8 o, q-tiles q0t and q0t + 2
+        if ((x & 1) == 0) {
+          const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + 2 * 8 * kCopyDwords : &sh.e8[1][0][0][0];
+          mx_init_acc(sh, lane, q0t, acc, prm.win_start, prm.win_stop);
+          mx_pass<true>(sh, 0, lane, q0t, acc, kScaleOne, a_corr, false, va);
+          mx_pass<true>(sh, 1, lane, q0t, acc, kScaleEight, a_corr, false, vb);
+          if (o)
+            mx_half_switch<true>(sh, lane, q0t, acc, prm.win_start, prm.win_stop);
+        } else {
+          const u32 kq2[2] = {(u32)(2047 - 2 * (32 * q0t + (lane & 31))), (u32)(2047 - 2 * (32 * (q0t + 2) + (lane & 31)))};
+          mx_epilogue_single(sh, lane, kq2, 8 * o, acc);
+        }
       }
       continue;
     } else if (SPLIT && seg) {
@@ -1291,7 +1313,7 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __syncthreads();
   if constexpr (S16) {
     if (tid == 0)
-      flags[blockIdx.x] = sh.ones[0];
+      flags[wg] = sh.ones[0];
     if (sh.ones[0])
       return;   // (uniform) the second kernel does this cluster again and writes its triplets
   }
@@ -1327,6 +1349,27 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
         pk[1] = make_uint2(t, t / (2u * kChips));                          //              sum, avr
       }
     }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,
+                                                          const u32 *__restrict__ mx_a, const u32 *__restrict__ mx_t,
+                                                          gpsx_peak_t *__restrict__ peaks, u32 *__restrict__ energy,
+                                                          u32 *__restrict__ flags)
+{
+  __shared__ MxShared sh;
+  int tables_set = -1;
+  if constexpr (MODE == kMxByte) {
+    // persistent: one workgroup per CU walks the clusters (prm.split_segs carries their number here) -- no dispatch gap between
+    // them, the PRN set's tables loaded once
+#pragma unroll 1
+    for (int wg = (int)blockIdx.x; wg < prm.split_segs; wg += (int)gridDim.x) {
+      mx_unit<MODE>(sh, prm, wg, tables_set, cluster_lo, if_blocks, mx_a, mx_t, peaks, energy, flags);
+      __syncthreads();   // the fold's readers are done before the next cluster's preamble writes
+    }
+  } else {
+    mx_unit<MODE>(sh, prm, (int)blockIdx.x, tables_set, cluster_lo, if_blocks, mx_a, mx_t, peaks, energy, flags);
   }
 }
 
@@ -1375,7 +1418,10 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     return "k_acq_mx<3>";
   }
   if (prm.n_bits == 1) {   // byte-phase grid: sample offsets 0 and 8, each started from its own block sums
-    hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+    AcqParams bp = prm;
+    bp.split_segs = c_hi - c_lo;   // (this form's use of the field: the number of clusters a persistent workgroup walks through)
+    const int grid = c_hi - c_lo < n_cus ? c_hi - c_lo : n_cus;
+    hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t,
                        d_peaks, (u32 *)nullptr, (u32 *)nullptr);
     return "k_acq_mx<4>";
   }

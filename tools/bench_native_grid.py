@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     args = ap.parse_args()
     from stm32f4_sdr_gps_amd import capi, synth
+    if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
+        capi.LIB_PATH = os.environ["GPSX_LIB"]
     eng = capi.Engine(0)
     n_prn, n_dopp, n_phase = 32, 29, 2046
     blocks = synth.cold_start_block(args.searches, seed=11, amp_scale=0.25)
