@@ -56,6 +56,11 @@ struct SlotState {
   uint32_t start_ticks = 0;
   int16_t ip[TRACKING_CH_LENGTH] = {0, 0, 0, 0};
   uint8_t bits[TRACKING_CH_LENGTH] = {0, 0, 0, 0};
+  // the FLL's arctangent of the previous millisecond's prompt pair: this millisecond's "before" is last millisecond's "now"
+  // (same inputs, same function: the value is reused, not recomputed; the inputs are kept to prove it)
+  float fll_now = 0.0f;
+  int16_t fll_now_i = 0, fll_now_q = 0;
+  bool fll_now_valid = false;
 };
 SlotState g_shared_slot;
 
@@ -447,13 +452,13 @@ void dll_update(gps_ch_t &ch, int16_t IE, int16_t QE, int16_t IL, int16_t QL)
 void pll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP)
 {
   gps_tracking_t &t = ch.tracking_data;
+  if (index != 0)    // (the reference evaluates the arctangent first and returns here, tracking.c:178-190: it has no effect then)
+    return;
   float phase_err;   // in units of pi
   if (IP > 0)
     phase_err = (float)((double)atan2f((float)QP, (float)IP) / kPi);
   else  // the reference calls the double-precision atan2 here (tracking.c:184)
     phase_err = (float)(atan2((double)(float)-QP, (double)(float)-IP) / kPi);
-  if (index != 0)
-    return;
   float step = phase_err - t.pll_code_err;
   if ((double)step > kPi / 2)
     step = (float)(kPi - (double)step);
@@ -509,18 +514,30 @@ void false_lock_check(gps_ch_t &ch, uint8_t index, int16_t ip)
   }
 }
 
-void fll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP)
+void fll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP, SlotState *slot)
 {
   gps_tracking_t &t = ch.tracking_data;
   false_lock_check(ch, index, IP);
   if (index == 0) {   // first ms after a channel swap: only remember
     t.fll_old_i = IP;
     t.fll_old_q = QP;
+    if (slot)
+      slot->fll_now_valid = false;
     return;
   }
   const int16_t oldI = t.fll_old_i, oldQ = t.fll_old_q;
   const float now = (IP == 0) ? (float)(kPi / 2) : atanf((float)QP / (float)IP);
-  const float before = (oldI == 0) ? (float)(kPi / 2) : atanf((float)oldQ / (float)oldI);
+  float before;
+  if (slot && slot->fll_now_valid && slot->fll_now_i == oldI && slot->fll_now_q == oldQ)
+    before = slot->fll_now;
+  else
+    before = (oldI == 0) ? (float)(kPi / 2) : atanf((float)oldQ / (float)oldI);
+  if (slot) {
+    slot->fll_now = now;
+    slot->fll_now_i = IP;
+    slot->fll_now_q = QP;
+    slot->fll_now_valid = true;
+  }
   float rot = now - before;
   if ((double)rot > kPi / 2)
     rot = (float)(kPi - (double)rot);
@@ -653,7 +670,7 @@ void tracking_apply(gps_ch_t &ch, uint8_t index, const int16_t iq[6], SlotState 
   const int16_t IE = iq[0], QE = iq[1], IP = iq[2], QP = iq[3], IL = iq[4], QL = iq[5];
   dll_update(ch, IE, QE, IL, QL);
   pll_update(ch, index, IP, QP);
-  fll_update(ch, index, IP, QP);
+  fll_update(ch, index, IP, QP, slot);
   if (slot)
     nav_bit_sync(&ch, index, IP, *slot);
   else
@@ -1304,6 +1321,7 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
   // tracking.c:309-326: with several workers the channels draw from it in no fixed order.)
   StepPool &pool = StepPool::instance();
   const int n_workers = n_ch >= kStepThreadsFrom ? pool.size() : 1;
+  static const int kAhead = [] { const char *e = std::getenv("GPSX_STEP_PREFETCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2; }();
   static std::vector<WorkerLists> lists;
   if ((int)lists.size() < n_workers)
     lists.resize(n_workers);
@@ -1321,8 +1339,8 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
     for (int c = lo; c < hi; c++) {
       gps_ch_t &ch = channel[c];
       gps_tracking_t &t = ch.tracking_data;
-      if (c + 2 < hi)   // (a gps_ch_t is 1688 bytes: every channel's state is a fresh set of cache lines)
-        prefetch_channel(channel[c + 2], false);
+      if (c + kAhead < hi)   // (a gps_ch_t is 1688 bytes: every channel's state is a fresh set of cache lines)
+        prefetch_channel(channel[c + kAhead], false);
       job_of[c] = trk_of[c] = -1;
       enter_pre_track_if_needed(ch);
       if (t.state == GPS_PRE_TRACK_RUN) {
@@ -1405,8 +1423,8 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
     for (int c = lo; c < hi; c++) {
       gps_ch_t &ch = channel[c];
       gps_tracking_t &t = ch.tracking_data;
-      if (c + 2 < hi)
-        prefetch_channel(channel[c + 2], true);
+      if (c + kAhead < hi)
+        prefetch_channel(channel[c + kAhead], true);
       if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
         if (index < TRACKING_CH_LENGTH)
           pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[L.job_base + job_of[c]] : nullptr, slots[c]);
