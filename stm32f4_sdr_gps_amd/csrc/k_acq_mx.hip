@@ -1245,8 +1245,16 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     // into the buffer that both roles read during step p - 1.
 #pragma unroll 1
     for (int hs = 0; hs <= 2 * n_pass; hs++) {
-      if ((hs & 1) == 0) {
+      if ((hs & 1) == 0)
         __syncthreads();
+      // The vector of the next step: built behind the barrier by everybody (single-block forms), or behind this step's epilogue
+      // by the role that just finished one (walk forms: each role's threads own one stream of the vector -- threads 0..255 =
+      // waves 0..3 = I, 256..511 = Q --, the buffer it goes into was last read in the previous step, and the barrier that opens
+      // the next step publishes it).  Same-box A/B: behind the epilogue is 1.5 % faster for the walk form (whose epilogue waits
+      // on HBM anyway) and 1.8 % slower for the single-block form -- the step is bound by the SIMD's issue port, not by the
+      // barrier: moving the work does not shorten it.
+      constexpr bool kBuildBehindEpilogue = MULTI;
+      if (!kBuildBehindEpilogue && (hs & 1) == 0) {
         const int p_vec = (hs >> 1) + 1;
         if (p_vec >= 2 && p_vec < n_pass && !(ex & 8)) {
           int tid_v = tid;
@@ -1297,6 +1305,15 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
           mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
         else
           mx_epilogue<MULTI, true, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
+      }
+      if (kBuildBehindEpilogue && (x & 1) != 0) {
+        const int p_vec = (hs >> 1) + 1;
+        if (p_vec >= 2 && p_vec < n_pass && !(ex & 8)) {
+          int tid_v = tid;
+          if constexpr (MULTI)
+            asm volatile("" : "+v"(tid_v));
+          mx_vector_build(sh, pbase + p_vec, tid_v);
+        }
       }
     }
   }
