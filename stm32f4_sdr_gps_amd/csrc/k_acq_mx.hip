@@ -766,8 +766,8 @@ __device__ __forceinline__ u32 pk_add_sat_u16(u32 a, u32 b)
 }
 
 // MULTI: request the running sums of sample offset t0, records [first, first + count) of this lane's 16; zero for the first
-// block.  The first tile's records are requested before the wave's MFMA pass, the next tile's at the start of each tile
-// of the epilogue: always ~1 us ahead of their use, never more than 8 records in registers.
+// block.  The first two tiles' records are requested before the wave's MFMA pass, the other two's at the start of the
+// epilogue: a pass or two tiles of epilogue ahead of their use, never more than 12 records in registers.
 template <int FIRST, int COUNT, bool S16>
 __device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first,
                                                  SumRecT<S16> (&pre)[16])
@@ -811,12 +811,10 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     const u32 key_lo = (u32)(2047 - (2 * q + half));   // 0 .. 2047 (q = 1023 does not exist: its magnitude is 0)
     if constexpr (MULTI) {
       // (deeper -- two tiles ahead with the 16-bit records -- measured 3 % slower: more registers, nothing gained)
+      // (two tiles ahead: with the spilled registers gone -- round 3 -- the deeper request is 2 % faster; round 2 measured it
+      //  1-3 % slower, next to 46 spilled registers)
       if (j == 0)
-        mx_prefetch_sums<4, 4, S16>(energy, lane, t0, ms_first, pre);
-      if (j == 1)
-        mx_prefetch_sums<8, 4, S16>(energy, lane, t0, ms_first, pre);
-      if (j == 2)
-        mx_prefetch_sums<12, 4, S16>(energy, lane, t0, ms_first, pre);
+        mx_prefetch_sums<8, 8, S16>(energy, lane, t0, ms_first, pre);
     }
     // (all four 8-PRN groups, whether this shard owns them or not: a workgroup that owns only some -- at the ends of a
     //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
@@ -1272,7 +1270,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       if (active && (x & 1) == 0) {
         if constexpr (MULTI) {
           if (p >= 1)
-            mx_prefetch_sums<0, 4, S16>(e_wave, lane_s, p - 1, ms_first, pre);
+            mx_prefetch_sums<0, 8, S16>(e_wave, lane_s, p - 1, ms_first, pre);
         }
         if (!(ex & 2)) {
           if (ex & 16)
