@@ -705,6 +705,11 @@ struct SumRecT {
 template <bool S16>
 __device__ __forceinline__ SumRecT<S16> rec_load(const SumRecT<S16> *p)
 {
+#ifdef WALK_ABL_NO_LOAD   // (timing ablation: results are wrong)
+  SumRecT<S16> z{};
+  asm volatile("" : "+v"(z.w[0]), "+v"(z.w[1]));
+  return z;
+#endif
 #ifdef GPSX_MX_NT
   SumRecT<S16> r;
 #pragma unroll
@@ -718,6 +723,11 @@ __device__ __forceinline__ SumRecT<S16> rec_load(const SumRecT<S16> *p)
 template <bool S16>
 __device__ __forceinline__ void rec_store(SumRecT<S16> *p, const SumRecT<S16> &r)
 {
+#ifdef WALK_ABL_NO_STORE   // (timing ablation: results are wrong)
+  u32 a = r.w[0], b = r.w[1];
+  asm volatile("" : : "v"(a), "v"(b));
+  return;
+#endif
 #ifdef GPSX_MX_NT
 #pragma unroll
   for (int i = 0; i < (S16 ? 2 : 3); i++)
@@ -768,14 +778,30 @@ __device__ __forceinline__ u32 pk_add_sat_u16(u32 a, u32 b)
 // MULTI: request the running sums of sample offset t0, records [first, first + count) of this lane's 16; zero for the first
 // block.  The first two tiles' records are requested before the wave's MFMA pass, the other two's at the start of the
 // epilogue: a pass or two tiles of epilogue ahead of their use, never more than 12 records in registers.
+// Record layout of a wave's slice: [sample offset][tile][lane][8-PRN group] -- a lane's four records of a tile are contiguous
+// (32 bytes with the 16-bit records), so two of them move per instruction: half the loads and stores of the
+// [offset][tile][group][lane] layout of round 2, still 1 KB contiguous per wave instruction.
+template <bool S16>
+struct alignas(8) RecPairT {
+  SumRecT<S16> a, b;
+};
 template <int FIRST, int COUNT, bool S16>
 __device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first,
                                                  SumRecT<S16> (&pre)[16])
 {
-  const SumRecT<S16> *e4 = reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
+  static_assert(FIRST % 2 == 0 && COUNT % 2 == 0, "records move in pairs");
+  const SumRecT<S16> *e4 = reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 64 + lane) * 4;
 #pragma unroll
-  for (int i = FIRST; i < FIRST + COUNT; i++)
-    pre[i] = ms_first ? SumRecT<S16>{} : rec_load<S16>(&e4[(size_t)i * 64]);
+  for (int i = FIRST; i < FIRST + COUNT; i += 2) {
+    if (ms_first) {
+      pre[i] = SumRecT<S16>{};
+      pre[i + 1] = SumRecT<S16>{};
+    } else {
+      const RecPairT<S16> rp = *reinterpret_cast<const RecPairT<S16> *>(&e4[(size_t)(i >> 2) * 256 + (i & 3)]);
+      pre[i] = rp.a;
+      pre[i + 1] = rp.b;
+    }
+  }
 }
 
 // ---- epilogue of one sample offset: magnitude, windowed max / sum -------------------------------------------------------
@@ -804,7 +830,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
   // MULTI: the running sums of a lane's four hypotheses of a group are one 12-byte record ([offset][tile][group][lane]: a
   // wave reads / writes 768 contiguous bytes per instruction); the first records of this offset were requested before
   // the wave's MFMA pass (mx_prefetch_sums) -- the scratch is HBM, the pass hides its latency
-  SumRec *e4 = reinterpret_cast<SumRec *>(energy) + ((size_t)(t0 * kMxTiles) * 4) * 64 + lane;
+  SumRec *e4 = reinterpret_cast<SumRec *>(energy) + ((size_t)(t0 * kMxTiles) * 64 + lane) * 4;   // [tile][lane][group]
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
@@ -823,6 +849,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
     // is in the MFMA pass) to cover the ALU, transcendental and branch latencies, few enough to stay in registers next to
     // the 128 accumulators.
     constexpr int GS = MULTI ? 4 : 8;
+    SumRec held{};   // (16-bit records, not the last block: the even group's new record, until the odd group's is there)
 #pragma unroll
     for (int r0 = 0; r0 < 16; r0 += GS) {
       u32 prev[GS];
@@ -842,7 +869,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
           }
         }
       }
-      SumRec *e_rec = e4 + (size_t)(j * 4 + r0 / 4) * 64;
+      SumRec *e_rec = e4 + (size_t)j * 256 + r0 / 4;
       u32 out[GS];
       // Magnitudes of the group's hypotheses.  When all of them (GS x 64 lanes) lie below radius 1024 -- noise hypotheses
       // sit at a few hundred -- e < 2^20 is an exact integer and trunc(v_sqrt_f32(e + 1/2)) is its integer root with no
@@ -876,7 +903,15 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
         SumRec nr;
         nr.w[0] = pk_add_sat_u16(pr.w[0], __builtin_amdgcn_perm(mag[1], mag[0], 0x05040100u));
         nr.w[1] = pk_add_sat_u16(pr.w[1], __builtin_amdgcn_perm(mag[3], mag[2], 0x05040100u));
-        rec_store<S16>(e_rec, nr);
+        // (a lane's records of a tile are contiguous: the even group's waits for the odd one, both leave in one 16-byte store)
+        if ((r0 / 4) & 1) {
+          RecPairT<S16> both;
+          both.a = held;
+          both.b = nr;
+          *reinterpret_cast<RecPairT<S16> *>(e_rec - 1) = both;
+        } else {
+          held = nr;
+        }
         __builtin_amdgcn_sched_barrier(0);
         continue;
       }
@@ -901,7 +936,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 #pragma unroll
         for (int g = 0; g < GS / 4; g++) {
           const u32 o4[4] = {out[4 * g], out[4 * g + 1], out[4 * g + 2], out[4 * g + 3]};
-          rec_store<S16>(&e_rec[(size_t)g * 64], sums_pack<S16>(o4));
+          rec_store<S16>(&e_rec[g], sums_pack<S16>(o4));
         }
       }
       if (SEARCH && !DIRECT) {   // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
