@@ -92,9 +92,12 @@ inline size_t acq_poly_energy_bytes(long local_units)
 // n_ms > 1 needs d_energy = acq_mx_energy_bytes(clusters) of scratch.
 void launch_build_mx_tables(hipStream_t s, const uint32_t *d_chipbits, int n_slots, uint32_t *d_mx_a, uint32_t *d_mx_t);
 long acq_mx_clusters(const AcqParams &prm);
+constexpr size_t kMxZeroRecBytes = 16384;          // a tile-row's worth of all-zero records in front of the flags: what the walk
+                                                   // forms "read back" in the first block of a search (16 offsets x ... of the
+                                                   // same addresses: 4 tiles x 64 lanes x 4 groups x 12 B = 12 KB, rounded up)
 inline size_t acq_mx_energy_bytes(long clusters)   // per workgroup: 8 waves x 16 offsets x 4 tiles x 4 groups x 64 lanes x 12 B
-{                                                  // (the 24-bit records of the fallback form), + one overflow flag
-  return (size_t)clusters * 8 * (16 * 4 * 4 * 64) * 12 + (size_t)clusters * 4;
+{                                                  // (the 24-bit records of the fallback form), + the zero records + one overflow flag
+  return (size_t)clusters * 8 * (16 * 4 * 4 * 64) * 12 + kMxZeroRecBytes + (size_t)clusters * 4;
 }
 // block_parallel (n_ms > 1): a workgroup per (cluster, block) writes magnitudes into d_energy (acq_poly_vals_bytes of it, u16),
 // k_acq_vals_search sums and searches -- the form for a handful of multi-block searches

@@ -786,21 +786,20 @@ struct alignas(8) RecPairT {
   SumRecT<S16> a, b;
 };
 template <int FIRST, int COUNT, bool S16>
-__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, int lane, int t0, bool ms_first,
-                                                 SumRecT<S16> (&pre)[16])
+__device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy, const u32 *__restrict__ zero_recs, int lane,
+                                                 int t0, bool ms_first, SumRecT<S16> (&pre)[16])
 {
   static_assert(FIRST % 2 == 0 && COUNT % 2 == 0, "records move in pairs");
-  const SumRecT<S16> *e4 = reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 64 + lane) * 4;
+  // (first block of a search: the running sums are zero -- read from a small all-zero region, `zero_recs`, instead of being
+  //  set by the vector ALU: register writes into the prefetch array made the compiler drain every outstanding store first,
+  //  an s_waitcnt vmcnt(0) per step; a load is ordered behind them by the memory system and costs nothing)
+  const SumRecT<S16> *e4 = ms_first ? reinterpret_cast<const SumRecT<S16> *>(zero_recs) + (size_t)lane * 4
+                                    : reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 64 + lane) * 4;
 #pragma unroll
   for (int i = FIRST; i < FIRST + COUNT; i += 2) {
-    if (ms_first) {
-      pre[i] = SumRecT<S16>{};
-      pre[i + 1] = SumRecT<S16>{};
-    } else {
-      const RecPairT<S16> rp = *reinterpret_cast<const RecPairT<S16> *>(&e4[(size_t)(i >> 2) * 256 + (i & 3)]);
-      pre[i] = rp.a;
-      pre[i + 1] = rp.b;
-    }
+    const RecPairT<S16> rp = *reinterpret_cast<const RecPairT<S16> *>(&e4[(size_t)(i >> 2) * 256 + (i & 3)]);
+    pre[i] = rp.a;
+    pre[i + 1] = rp.b;
   }
 }
 
@@ -808,8 +807,8 @@ __device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy,
 // SEARCH = false (MULTI, not the last block): only the running sums move on -- no key, no maximum, no window sum
 template <bool MULTI, bool SEARCH, bool S16>
 __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
-                                            u32 group_mask, u32 *__restrict__ energy, SumRecT<S16> (&pre)[MULTI ? 16 : 1],
-                                            bool ms_first, u32 &witness)
+                                            u32 group_mask, u32 *__restrict__ energy, const u32 *__restrict__ zero_recs,
+                                            SumRecT<S16> (&pre)[MULTI ? 16 : 1], bool ms_first, u32 &witness)
 {
   typedef SumRecT<S16> SumRec;
   constexpr bool ms_last = SEARCH;
@@ -840,7 +839,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       // (two tiles ahead: with the spilled registers gone -- round 3 -- the deeper request is 2 % faster; round 2 measured it
       //  1-3 % slower, next to 46 spilled registers)
       if (j == 0)
-        mx_prefetch_sums<8, 8, S16>(energy, lane, t0, ms_first, pre);
+        mx_prefetch_sums<8, 8, S16>(energy, zero_recs, lane, t0, ms_first, pre);
     }
     // (all four 8-PRN groups, whether this shard owns them or not: a workgroup that owns only some -- at the ends of a
     //  shard's run, or a ragged PRN list -- does a little unused work here instead of branching around register arrays;
@@ -1183,6 +1182,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       asm volatile("" : "+v"(kq[j]));   // (kept in registers, not rebuilt per group; the other forms do not use them)
   }
   u32 *e_wave = MULTI ? energy + ((size_t)wg * 8 + wave) * (16 * kMxTiles * 4 * 64 * (S16 ? 2 : 3)) : nullptr;   // dwords per record
+  const u32 *zero_recs = MULTI ? flags - kMxZeroRecBytes / sizeof(u32) : nullptr;   // (the launcher put them in front of the flags)
   u32 witness = 0;   // S16: OR of every sum this lane stored
   const int n_ms = MULTI ? prm.n_ms : 1;
   // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid;
@@ -1305,7 +1305,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       if (active && (x & 1) == 0) {
         if constexpr (MULTI) {
           if (p >= 1)
-            mx_prefetch_sums<0, 8, S16>(e_wave, lane_s, p - 1, ms_first, pre);
+            mx_prefetch_sums<0, 8, S16>(e_wave, zero_recs, lane_s, p - 1, ms_first, pre);
         }
         if (!(ex & 2)) {
           if (ex & 16)
@@ -1335,9 +1335,9 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         if (!MULTI)
           mx_epilogue_single(sh, lane, kq, t0s + p - 1, acc);
         else if (!ms_last)
-          mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
+          mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, zero_recs, pre, ms_first, witness);
         else
-          mx_epilogue<MULTI, true, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, pre, ms_first, witness);
+          mx_epilogue<MULTI, true, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, zero_recs, pre, ms_first, witness);
       }
       if (kBuildBehindEpilogue && (x & 1) != 0) {
         const int p_vec = (hs >> 1) + 1;
@@ -1460,6 +1460,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     // follows and redoes the clusters whose flag went up.  The flags sit behind the records.
     const unsigned n_wg = (unsigned)(c_hi - c_lo);
     u32 *d_flags = d_energy + acq_mx_energy_bytes(n_wg) / sizeof(u32) - n_wg;
+    (void)hipMemsetAsync(d_flags - kMxZeroRecBytes / sizeof(u32), 0, kMxZeroRecBytes, s);   // the first block's "previous sums"
     hipLaunchKernelGGL(k_acq_mx<kMxWalk16>, dim3(n_wg), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
                        d_energy, d_flags);
     if (prm.n_ms * 11573 > 65535)
