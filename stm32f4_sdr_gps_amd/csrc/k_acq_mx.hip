@@ -38,7 +38,13 @@
 // Lane (n, h) of a wave holds, per tile, column q for the 16 PRNs p = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15 -- the
 // per-offset work (corrections, window test) is shared by 16 hypotheses.  The matrix pipe and the vector ALU of a SIMD
 // are separate: waves 0..3 and 4..7 (one of each per SIMD) run half a step apart, one group's MFMA pass under the
-// other's epilogue, with one barrier per half step.
+// other's epilogue, with one barrier per step.
+//
+// Forms (k_acq_mx<MODE>): 0 single block, one workgroup per cluster (the headline sweep); 3 / 1 a workgroup walks the blocks
+// of its search, running sums as 16- / 24-bit records through HBM scratch; 2 a workgroup per (cluster, block), magnitudes out
+// for k_acq_vals_search; 4 the byte-phase grid (sample offsets 0 and 8, each started directly from its own block sums,
+// persistent workgroups, stages of two q-tiles); 5 small launches: 2 / 4 / 8 workgroups per cluster, each started directly
+// at its own sample offset (mx_direct_terms: every quirk term as a start value), results merged through global planes.
 #include <cstdlib>
 
 #include "gpsx_device.hpp"
@@ -1386,8 +1392,8 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     if (((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn && b < prm.n_bits) {
       const size_t idx = ((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits + b;
       uint2 *pk = reinterpret_cast<uint2 *>(&peaks[idx]);
-      if constexpr (SPLIT) {   // `flags` = the planes' length: keys [0, n), sums [n, 2 n)
-        const size_t n_planes = (size_t)(uintptr_t)flags;
+      if constexpr (SPLIT) {   // the runs of a cluster meet in the planes: keys [0, n), sums [n, 2 n)
+        const size_t n_planes = (size_t)prm.n_planes;
         if (which == 0)
           atomicMax(&energy[idx], k);
         else
@@ -1411,10 +1417,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
   __shared__ MxShared sh;
   int tables_set = -1;
   if constexpr (MODE == kMxByte) {
-    // persistent: one workgroup per CU walks the clusters (prm.split_segs carries their number here) -- no dispatch gap between
-    // them, the PRN set's tables loaded once
+    // persistent: one workgroup per CU walks the clusters -- no dispatch gap between them, the PRN set's tables loaded once
 #pragma unroll 1
-    for (int wg = (int)blockIdx.x; wg < prm.split_segs; wg += (int)gridDim.x) {
+    for (int wg = (int)blockIdx.x; wg < prm.n_clusters; wg += (int)gridDim.x) {
       mx_unit<MODE>(sh, prm, wg, tables_set, cluster_lo, if_blocks, mx_a, mx_t, peaks, energy, flags);
       __syncthreads();   // the fold's readers are done before the next cluster's preamble writes
     }
@@ -1470,7 +1475,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   }
   if (prm.n_bits == 1) {   // byte-phase grid: sample offsets 0 and 8, each started from its own block sums
     AcqParams bp = prm;
-    bp.split_segs = c_hi - c_lo;   // (this form's use of the field: the number of clusters a persistent workgroup walks through)
+    bp.n_clusters = c_hi - c_lo;
     const int grid = c_hi - c_lo < n_cus ? c_hi - c_lo : n_cus;
     hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t,
                        d_peaks, (u32 *)nullptr, (u32 *)nullptr);
@@ -1487,8 +1492,9 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
       sp.split_segs = v == 8 ? 8 : v == 4 ? 4 : 2;
     }
     (void)hipMemsetAsync(d_planes, 0, 2 * n_peaks * sizeof(uint32_t), s);
+    sp.n_planes = n_peaks;
     hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * (c_hi - c_lo))), dim3(kMxThreads), 0, s, sp, c_lo, d_if,
-                       d_mx_a, d_mx_t, d_peaks, d_planes, reinterpret_cast<u32 *>((uintptr_t)n_peaks));
+                       d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);
     launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks);
     return "k_acq_mx<5>";
   }
