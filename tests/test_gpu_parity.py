@@ -294,6 +294,37 @@ def test_acq_grid_reference_native_grid_29_bins_byte_phases(eng, oracle, stream)
                 assert _peak_tuple(peaks[0, p, d, 0]) == (pk["max_val"], pk["phase"], pk["sum"], pk["avr"]), (win, p, d)
 
 
+def test_byte_phase_grid_persistent_workgroups_two_prn_sets_and_two_bit_if(oracle, stream, monkeypatch):
+    """k_acq_mx<4> runs one persistent workgroup per CU that walks the launch's clusters: more clusters than CUs (40 PRNs = two
+    32-slot sets x 29 Doppler bins x 6 captures = 348: every workgroup walks at least one cluster of each set and reloads
+    the set's tables in between), on 2-bit sign/magnitude captures -- against the direct 4-bit-dot-product kernel
+    (GPSX_ACQ_ALGO=dot8: another algorithm, itself checked against the oracle) on every triplet and key, and against the
+    oracle on a sample."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    sats = [synth.Sat(5, 912.5, 1600.0, 0.6, 0.3), synth.Sat(30, 2018.0, 13000.0, 0.6, 4.0), synth.Sat(20, -3011.0, 7000.0, 0.5, 1.0)]
+    two = synth.make_if(6, sats, seed=23, two_bit=True)
+    one = synth.make_if(6, sats, seed=23)
+    prns = np.concatenate([np.arange(1, 33), [33, 40, 61, 100, 120, 150, 200, 210]]).astype(np.uint8)
+    kw = dict(n_search=6, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=capi.PHASES_BYTE)
+    e = capi.Engine(0)
+    monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
+    ref = capi.Engine(0)
+    monkeypatch.delenv("GPSX_ACQ_ALGO")
+    try:
+        e.set_if_format(capi.IF_2BIT_SM)
+        pk, keys = e.acq_grid(two, prns, **kw)
+        assert e.lib.gpsx_last_kernel(e.h) == b"k_acq_mx<4>"
+        want_pk, want_keys = ref.acq_grid(one, prns, **kw)
+        assert ref.lib.gpsx_last_kernel(ref.h).startswith(b"k_acq<8,false,dot8>")
+        assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys)
+        for s_, p, d in ((0, 4, 15), (5, 29, 18), (3, 33, 8), (2, 39, 0), (1, 0, 28)):
+            o, _, _ = oracle.search_job(one[s_:s_ + 1], 1, oracle.ca_code(int(prns[p])), float(IF_HZ - 7000 + 500 * d), 0)
+            assert _peak_tuple(pk[s_, p, d, 0]) == (o["max_val"], o["phase"], o["sum"], o["avr"]), (s_, p, d)
+    finally:
+        e.close()
+        ref.close()
+
+
 def test_acq_grid_non_coherent_10ms_and_per_ms_triplets(eng, oracle, stream):
     """BASELINE.json configs[3] semantics: energy = sum over 10 blocks of the per-block magnitude."""
     prns = np.array([5, 14, 20, 30, 7, 9, 11, 13, 15], np.uint8)   # 9 PRNs: exercises a partial PRN group
