@@ -148,6 +148,8 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     ctx->seg_force = (v == 4 || v == 8 || v == 16) ? v : 0;
   }
   ctx->no_split = std::getenv("GPSX_ACQ_NO_SPLIT") != nullptr;
+  if (const char *w = std::getenv("GPSX_TRACK_WAVE_FROM"))
+    ctx->track_wave_from = std::atoi(w) > 0 ? std::atoi(w) : 1;
   if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
     ctx->ms_mode = std::strcmp(m, "walk") == 0 ? 1 : (std::strcmp(m, "blocks") == 0 ? 2 : 0);
   if (const char *a = std::getenv("GPSX_ACQ_ALGO")) {
@@ -764,7 +766,7 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
   if (!d_if_block || !d_st || !d_iq_out || n_ch < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   launch_track_epl(ctx->stream, static_cast<const uint8_t *>(d_if_block), ctx->if_format, ctx->if_hz, d_st, n_ch,
-                   ctx->d_chips_all, ctx->d_bits_all, ctx->d_trk_rep, d_iq_out, ctx->d_bad_prn + 1);
+                   ctx->d_chips_all, ctx->d_bits_all, ctx->d_trk_rep, d_iq_out, ctx->d_bad_prn + 1, ctx->track_wave_from);
   LAUNCHCHK(ctx, "k_track_epl");
   return GPSX_OK;
 }
@@ -842,7 +844,7 @@ gpsx_ctx::TrackGraph *track_graph_prepare(gpsx_ctx *ctx, int n_ch_asked, size_t 
     if (ok) {
       ok = hipMemcpyAsync(t.d_buf, t.h_in, t.in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
       launch_track_epl(ctx->stream, t.d_buf + t.blk_off, ctx->if_format, ctx->if_hz, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all,
-                       ctx->d_trk_rep, d_iq, ctx->d_bad_prn);
+                       ctx->d_trk_rep, d_iq, ctx->d_bad_prn, ctx->track_wave_from);
       ok = ok && hipGetLastError() == hipSuccess &&
            hipMemcpyAsync(t.h_out, d_st, t.out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
       ok = (hipStreamEndCapture(ctx->stream, &graph) == hipSuccess) && ok && graph;
@@ -977,7 +979,7 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
       CHUNKCHK(hipEventRecord(arrived, ctx->stream));      // (also: the block and everything before it on the stream)
       CHUNKCHK(hipStreamWaitEvent(ctx->aux_stream, arrived, 0));
       launch_track_epl(ctx->aux_stream, d_if, ctx->if_format, ctx->if_hz, d_st + first, n, ctx->d_chips_all, ctx->d_bits_all,
-                       ctx->d_trk_rep, d_iq + (size_t)first * 6, ctx->d_bad_prn);
+                       ctx->d_trk_rep, d_iq + (size_t)first * 6, ctx->d_bad_prn, ctx->track_wave_from);
       CHUNKCHK(hipGetLastError());
       CHUNKCHK(hipEventRecord(done, ctx->aux_stream));
       CHUNKCHK(hipStreamWaitEvent(ctx->out_stream, done, 0));
@@ -994,7 +996,7 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   }
   HIPCHK(ctx, hipMemcpyAsync(d_st, st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyHostToDevice, ctx->stream));
   launch_track_epl(ctx->stream, d_if, ctx->if_format, ctx->if_hz, d_st, n_ch, ctx->d_chips_all, ctx->d_bits_all, ctx->d_trk_rep, d_iq,
-                   ctx->d_bad_prn);
+                   ctx->d_bad_prn, ctx->track_wave_from);
   LAUNCHCHK(ctx, "k_track_epl");
   HIPCHK(ctx, hipMemcpyAsync(st, d_st, n_ch * sizeof(gpsx_trk_state_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(iq_out, d_iq, (size_t)n_ch * 12, hipMemcpyDeviceToHost, ctx->stream));

@@ -55,6 +55,8 @@ struct gpsx_ctx {
   size_t acc_entries = 0;
   int seg_force = 0;                 // $GPSX_ACQ_SEG = 4 | 8 | 16: the polyphase kernel at that many offsets per workgroup (tests, A/B);
                                      // implies $GPSX_ACQ_ALGO=poly unless another algorithm was named
+  int track_wave_from = 1;           // $GPSX_TRACK_WAVE_FROM: channels from which k_track_epl_wave serves the step (default: always;
+                                     // a large value selects the workgroup-per-channel kernel: tests, A/B)
   bool no_split = false;             // $GPSX_ACQ_NO_SPLIT: small single-block fine grids stay one workgroup per cluster (tests, A/B)
   int ms_mode = 0;                   // $GPSX_ACQ_MS_MODE = walk | blocks: force one multi-block form (tests, A/B); 0 = by size
   uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)

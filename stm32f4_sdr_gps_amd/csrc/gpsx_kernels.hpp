@@ -133,7 +133,7 @@ void launch_search_reduce(hipStream_t s, const int16_t *d_corr8, int n, int firs
 // d_trk_rep: the replica bit streams of every PRN slot (launch_build_track_rep), read by the wave-per-channel form
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
                       const uint8_t *d_chips, const uint32_t *d_chipbits, const uint32_t *d_trk_rep, int16_t *d_iq,
-                      uint32_t *d_bad_prn);
+                      uint32_t *d_bad_prn, int wave_from);
 constexpr int kTrackRepStride = 1032;   // words per PRN row of d_trk_rep
 void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n_slots, uint32_t *d_rep);
 constexpr int kTrackPadPrn = -2147483647 - 1;   // gpsx_trk_state_t.prn of a padding channel: the empty code, not an error

@@ -9,6 +9,8 @@
 //   k_track_epl     the correlator half of gps_tracking_data_process            PM/GPS/tracking.c:115-138
 //   k_rewind        gps_rewind_if_phase                                         PM/GPS/gps_misc.c:196-204
 // XOR + v_bcnt_u32_b32 on 16-bit words, wave64 shuffle reductions for the I/Q sums.
+#include <cstdlib>
+
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
 
@@ -536,15 +538,17 @@ __global__ __launch_bounds__(256) void k_track_epl_wave(const uint8_t *__restric
     st[ch_l].if_freq_accum = acc0 + step * (u32)kWords32;
 }
 
-constexpr int kTrackWaveFormFrom = 2048;
-
+// wave_from: channel count from which the wave-per-channel kernel serves the step.  Round 3's k_track_epl_wave is the faster
+// one at every count (4 channels: 3.3 us against 6.2 us; 2047: 4.5 against 9.4), so contexts use it from 1 channel on;
+// k_track_epl -- one workgroup per channel, the reference's 16-bit-word indexing -- stays as the second implementation the
+// tests compare it with ($GPSX_TRACK_WAVE_FROM).
 void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, int if_hz, gpsx_trk_state_t *d_st, int n_ch,
                       const uint8_t *d_chips, const uint32_t *d_chipbits, const uint32_t *d_trk_rep, int16_t *d_iq,
-                      uint32_t *d_bad_prn)
+                      uint32_t *d_bad_prn, int wave_from)
 {
   if (n_ch <= 0)
     return;
-  if (n_ch < kTrackWaveFormFrom) {
+  if (n_ch < wave_from) {
     hipLaunchKernelGGL(k_track_epl, dim3(n_ch), dim3(256), 0, s, d_if_block, if_format, if_hz, d_st, n_ch, d_chips, d_iq,
                        d_bad_prn);
     return;

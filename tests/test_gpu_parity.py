@@ -27,6 +27,25 @@ def stream():
     return synth.default_four_sv(12, seed=7)
 
 
+@pytest.fixture(scope="module")
+def eng_wg():
+    """An engine whose tracking steps run k_track_epl (one workgroup per channel, the reference's 16-bit-word indexing) at every
+    channel count ($GPSX_TRACK_WAVE_FROM): the second implementation the default kernel, k_track_epl_wave, is compared with."""
+    import os
+    from stm32f4_sdr_gps_amd import capi
+    old = os.environ.get("GPSX_TRACK_WAVE_FROM")
+    os.environ["GPSX_TRACK_WAVE_FROM"] = str(1 << 30)
+    try:
+        e = capi.Engine(0)
+    finally:
+        if old is None:
+            del os.environ["GPSX_TRACK_WAVE_FROM"]
+        else:
+            os.environ["GPSX_TRACK_WAVE_FROM"] = old
+    yield e
+    e.close()
+
+
 def _peak_tuple(p):
     return int(p["max_val"]), int(p["phase"]), int(p["sum"]), int(p["avr"])
 
@@ -472,11 +491,12 @@ def test_track_epl_256_channels_vs_oracle(eng, oracle, stream):
         st["code_phase_fine"] = np.mod(st["code_phase_fine"] + rng.uniform(-3, 3, n).astype(np.float32), 16368).astype(np.float32)
 
 
-def test_track_epl_wave_form_for_many_channels(eng, oracle, stream):
-    """From 2048 channels on the step runs k_track_epl_wave (one wave per channel, Early / Prompt / Late out of one shared
-    window per word) instead of the workgroup-per-channel kernel.  2304 channels against the oracle on a sample, and --
-    including code phases the reference itself would mishandle (negative, beyond 16368: both kernels keep every access in
-    range the same way) -- the two kernels against each other on every channel."""
+def test_track_epl_wave_form_for_many_channels(eng, eng_wg, oracle, stream):
+    """The step runs k_track_epl_wave (one wave per channel, Early / Prompt / Late out of one shared replica window per four
+    data words) at every channel count; k_track_epl (one workgroup per channel) is the library's second implementation.
+    2304 channels against the oracle on a sample, and -- including code phases the reference itself would mishandle
+    (negative, beyond 16368: both kernels keep every access in range the same way) -- the two kernels against each other
+    on every channel; and the second implementation against the oracle as well."""
     from stm32f4_sdr_gps_amd.capi import TRK_DTYPE
     rng = np.random.default_rng(10)
     n = 256
@@ -488,7 +508,7 @@ def test_track_epl_wave_form_for_many_channels(eng, oracle, stream):
     st["if_freq_offset_hz"] = (-5000 + 39 * np.arange(n)).astype(np.float32)
     st["if_freq_accum"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
     small = st.copy()
-    iq_small = eng.track_epl(stream[2], small)                 # 256 channels: workgroup-per-channel kernel
+    iq_small = eng_wg.track_epl(stream[2], small)              # 256 channels: workgroup-per-channel kernel
     big = np.tile(st, 9)                                       # 2304 channels: wave-per-channel kernel
     iq_big = eng.track_epl(stream[2], big)
     for rep in range(9):
@@ -498,6 +518,7 @@ def test_track_epl_wave_form_for_many_channels(eng, oracle, stream):
         want, acc = oracle.track_epl(stream[2], oracle.ca_code(int(st["prn"][c])), float(st["code_phase_fine"][c]),
                                      float(st["if_freq_offset_hz"][c]), int(st["if_freq_accum"][c]))
         assert np.array_equal(iq_big[n + c], want) and int(big["if_freq_accum"][n + c]) == acc, c
+        assert np.array_equal(iq_small[c], want) and int(small["if_freq_accum"][c]) == acc, c
 
 
 def test_track_epl_graph_cache_alternating_shapes_and_formats(oracle, stream):
@@ -1424,22 +1445,23 @@ def test_track_epl_chunked_pipeline_every_chunk_boundary_vs_oracle(oracle, strea
         e.close()
 
 
-def test_track_epl_wave_form_channel_counts_and_channels_per_wave(oracle, stream):
-    """k_track_epl_wave serves 1 to 16 channels per wave depending on the launch size (lanes 4 c + k carry channel c's
-    values): counts that give 1, 2, 5 and 16 channels per wave, none a multiple of the workgroup's share -- the last wave
-    is ragged, the last workgroup has idle waves -- against the oracle on a sample and, channel by channel, against the
-    same states in another order (a channel's result must not depend on its position in a wave)."""
+def test_track_epl_wave_form_channel_counts_and_channels_per_wave(oracle, stream, eng_wg):
+    """k_track_epl_wave serves every channel count, 1 to 16 channels per wave depending on the launch size (lanes 4 c + k carry
+    channel c's values): a single channel, counts below one workgroup, and counts that give 1, 2, 5 and 16 channels per
+    wave, none a multiple of the workgroup's share -- the last wave is ragged, the last workgroup has idle waves -- against
+    the oracle on a sample and, channel by channel, against the same states in another order (a channel's result must not
+    depend on its position in a wave)."""
     from stm32f4_sdr_gps_amd import capi
     e = capi.Engine(0)
     try:
         codes = {p: oracle.ca_code(p) for p in range(1, 33)}
-        for n in (2049, 8197, 20491, 70003):
+        for n in (1, 3, 6, 255, 2049, 8197, 20491, 70003):
             rng = np.random.default_rng(n)
             st = np.zeros(n, capi.TRK_DTYPE)
             st["prn"] = rng.integers(1, 33, n)
             st["code_phase_fine"] = rng.uniform(0, 16368, n).astype(np.float32)
-            st["code_phase_fine"][:14] = [0.0, 0.99, 7.5, 8.0, 15.9, 16367.9, 16368.0, 16360.0, 16352.0, 16359.99, -1.0, -9.0,
-                                          -20000.0, 20000.0]
+            edge = [0.0, 0.99, 7.5, 8.0, 15.9, 16367.9, 16368.0, 16360.0, 16352.0, 16359.99, -1.0, -9.0, -20000.0, 20000.0]
+            st["code_phase_fine"][:min(14, n)] = edge[:min(14, n)]
             st["if_freq_offset_hz"] = rng.uniform(-7000, 7000, n).astype(np.float32)
             st["if_freq_accum"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
             before = st.copy()
@@ -1448,14 +1470,14 @@ def test_track_epl_wave_form_channel_counts_and_channels_per_wave(oracle, stream
             st2 = before[perm].copy()
             iq2 = e.track_epl(stream[1], st2)
             assert np.array_equal(iq2, iq[perm]) and np.array_equal(st2, st[perm]), n
-            for c in list(range(10)) + [int(c) for c in rng.integers(14, n, 120)] + [n - 1, n - 2]:
+            for c in [c for c in range(10) if c < n] + ([int(c) for c in rng.integers(14, n, 120)] if n > 14 else []) + [n - 1, max(n - 2, 0)]:
                 want, acc = oracle.track_epl(stream[1], codes[int(before["prn"][c])], float(before["code_phase_fine"][c]),
                                              float(before["if_freq_offset_hz"][c]), int(before["if_freq_accum"][c]))
                 assert np.array_equal(iq[c], want) and int(st["if_freq_accum"][c]) == acc, (n, c)
             # phases outside [0, 16368) (channels 10..13): the workgroup-per-channel kernel is the reference for what "kept in
             # range" means there
             small = before[:256].copy()
-            iq_small = e.track_epl(stream[1], small)
-            assert np.array_equal(iq_small, iq[:256]) and np.array_equal(small, st[:256]), n
+            iq_small = eng_wg.track_epl(stream[1], small)
+            assert np.array_equal(iq_small, iq[:256][:len(small)]) and np.array_equal(small, st[:256]), n
     finally:
         e.close()
