@@ -68,6 +68,12 @@ def main():
                       "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode() + " (byte-phase mode)",
                       "strongest_of_capture_0": {"prn": int(prns[p]), "doppler_hz": int(-7000 + 500 * d),
                                                  "max_val": int(k0[p, d] >> 14)},
+                      "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 10000.0,
+                                   # four FP4 GEMM passes (two per byte offset of a chip offset) x 2 streams x 2*32*1024*1024 flops
+                                   # per (capture, Doppler) pair of 32 PRN x 2046 hypotheses
+                                   "flops_per_hyp": 4 * 2 * 2.0 * 32 * 1024 * 1024 / (32 * 2046),
+                                   "achieved": 4 * 2 * 2.0 * 32 * 1024 * 1024 * args.searches * n_dopp / (ms * 1e-3) / 1e12,
+                                   "frac": 4 * 2 * 2.0 * 32 * 1024 * 1024 * args.searches * n_dopp / (ms * 1e-3) / 1e16},
                       "mcu_equivalent": "one (PRN, Doppler) per ~0.2 s on STM32F407 (SURVEY.md 3.2): 928 pairs = ~186 s "
                                         "per capture"}))
 

@@ -11,6 +11,7 @@ cp gpurun_out/${T}_tracking_latency.json profiles/${T}_tracking_latency.json
 [ -s gpurun_out/${T}_native.json ] && cp gpurun_out/${T}_native.json profiles/${T}_native_grid_32x29x2046.json
 [ -s gpurun_out/${T}_pcie_probe.txt ] && grep contexts gpurun_out/${T}_pcie_probe.txt > profiles/${T}_pcie_probe.txt
 [ -d gpurun_out/prof_${T}_track ] && python tools/summarize_track_profile.py ${T}_track 212992 > /dev/null
+[ -s gpurun_out/prof_${T}_native/trace/trace_kernel_stats.csv ] && cp gpurun_out/prof_${T}_native/trace/trace_kernel_stats.csv profiles/${T}_native_grid_kernel_stats.csv
 [ -s gpurun_out/${T}_gputests.log ] && cp gpurun_out/${T}_gputests.log profiles/${T}_gputests.log
 if [ -f gpurun_out/${T}_sweep.txt ]; then
 python - "$T" <<'PY'

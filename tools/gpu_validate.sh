@@ -18,6 +18,7 @@ python tools/bench_track_kernel.py 2048 16384 65536 212992 688128 > gpurun_out/$
 python tools/bench_tracking.py > gpurun_out/${T}_tracking_latency.json 2>/dev/null
 bash tools/gpu_sweep.sh > gpurun_out/${T}_sweep.txt 2>&1
 python tools/bench_native_grid.py 2>/dev/null | tail -1 > gpurun_out/${T}_native.json
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${T}_native/trace -o trace -- python $GRAFT_REPO_ROOT/tools/bench_native_grid.py > $GRAFT_REPO_ROOT/gpurun_out/${T}_native_prof.log 2>&1 )
 python tools/pcie_probe.py > gpurun_out/${T}_pcie_probe.txt 2>&1
 python - "$T" <<'PY'
 import json, sys
