@@ -136,7 +136,10 @@ def tracking_channels(eng_cls, dev_index, steps=1000, closed_loop=True):
            "criterion": "p99 of ONE 1000-step run < 1000 us (no retries: the worst run is the only run); the ladder stops at "
                         "the first count that misses"}
     if closed_loop:
-        out["closed_loop"] = tracking_closed_loop()
+        try:
+            out["closed_loop"] = tracking_closed_loop()
+        except Exception as exc:   # a secondary leg must not take the headline line with it
+            out["closed_loop"] = {"error": repr(exc)}
     return out
 
 
@@ -374,7 +377,13 @@ def main():
     # captures through the engine does (tools/pcie_probe.py: 1 / 2 / 3 / 4 contexts = 0.98 / 1.02 / 1.13 / 1.18 x 10^12).  `serial` is the one-context, synchronous gpsx_acq_grid() loop of round 1.
     # the secondary metric first: the legs below leave ~100 MB of page-locked host memory and four contexts' worth of
     # state behind, and the tracking step measured after them is 60 us slower
-    tracking = tracking_channels(capi.Engine, dev_index) if (not args.no_tracking and world == 1) else None
+    tracking = None
+    if not args.no_tracking and world == 1:
+        try:
+            tracking = tracking_channels(capi.Engine, dev_index)
+        except Exception as exc:   # a secondary leg must not take the headline line with it
+            tracking = {"error": repr(exc)}
+            print(f"bench.py: tracking leg failed: {exc!r}", file=sys.stderr, flush=True)
 
     pcie = None
     if world == 1 and n_ms == 1 and not args.no_pcie:
@@ -644,7 +653,10 @@ def main():
         if tracking is not None:
             line["tracking"] = tracking
         if not args.no_cpu_baseline and world == 1:
-            line.update(cpu_baseline(blocks, args.cpu_budget_s))
+            try:
+                line.update(cpu_baseline(blocks, args.cpu_budget_s))
+            except Exception as exc:   # (the reported baseline: its failure is reported, the line still goes out)
+                line["cpu_baseline"] = {"error": repr(exc)}
             line["cpu_host"] = {"logical_cpus": os.cpu_count()}
         print(json.dumps(line), flush=True)
 
