@@ -156,7 +156,7 @@ def tracking_closed_loop(ms=1200):
     keep = ("channels", "host_workers", "p50_us", "p99_us", "max_us", "steps_over_1ms", "warmup_max_us", "real_time",
             "tracking_state", "code_and_carrier_lock")
     rows, best = [], None
-    for n in (256, 16384, 65536, 81920, 98304, 114688, 131072):
+    for n in (256, 16384, 65536, 98304, 131072, 147456, 163840, 196608):
         r = mod.closed_loop(n, ms, 0.12, 32)
         rows.append({k: r[k] for k in keep})
         if r["real_time"]:

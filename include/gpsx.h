@@ -252,6 +252,14 @@ typedef struct {
 int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out);
 int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_state_t *d_st, int n_ch,
                              int16_t *d_iq_out);
+/* The same step for a host that has work of its own per channel (the reference's DLL / PLL / FLL after the correlators):
+ * the channels go through in n_chunks (1..16) pieces on the copy / correlate / copy pipeline, and on_chunk(user, first, n) is
+ * called ON THE CALLING THREAD as soon as st[first .. first + n) and iq_out of those channels are in the caller's arrays --
+ * while the GPU works on the next pieces.  Page-locked arrays (gpsx_host_alloc) make the copies asynchronous.  Returns after
+ * the last callback; the PRN verdict is the whole step's. */
+typedef void (*gpsx_track_chunk_fn)(void *user, int first_channel, int n_channels);
+int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out,
+                                 int n_chunks, gpsx_track_chunk_fn on_chunk, void *user);
 
 /* ---- per-call primitives on caller buffers (the device work behind include/gpsx_compat.h) --------------------- */
 

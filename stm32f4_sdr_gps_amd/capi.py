@@ -25,6 +25,7 @@ PHASES_FINE = 16368
 IF_HZ = 4092000
 
 PEAK_DTYPE = np.dtype([("max_val", "<u4"), ("phase", "<u4"), ("sum", "<u4"), ("avr", "<u4")])
+TRACK_CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)   # gpsx_track_chunk_fn
 TRK_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"),
                       ("if_freq_accum", "<u4")])
 JOB_DTYPE = np.dtype([("block", "<i4"), ("n_ms", "<i4"), ("prn", "<i4"), ("freq_hz", "<f4"), ("offset_bits", "<i4"),
@@ -84,6 +85,8 @@ def load_library() -> C.CDLL:
     lib.gpsx_acq_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gpsx_track_epl_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_track_epl_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_track_epl_batch_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                 TRACK_CHUNK_FN, C.c_void_p]
     lib.gpsx_rewind.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gpsx_wipeoff.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
     lib.gpsx_replica.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
@@ -344,6 +347,19 @@ class Engine:
         iq = np.zeros((len(states), 6), np.int16) if iq_out is None else iq_out
         self._chk(self.lib.gpsx_track_epl_batch(self.h, blk.ctypes.data, states.ctypes.data, len(states),
                                                 iq.ctypes.data), "gpsx_track_epl_batch")
+        return iq
+
+    def track_epl_chunked(self, if_block: np.ndarray, states: np.ndarray, n_chunks: int, on_chunk,
+                          iq_out: np.ndarray | None = None) -> np.ndarray:
+        """track_epl in n_chunks pieces; on_chunk(first, n) is called on this thread as each piece's results land in
+        `states` / the returned array while the GPU works on the next pieces (gpsx_track_epl_batch_chunked)."""
+        assert states.dtype == TRK_DTYPE and states.flags.c_contiguous
+        blk = np.ascontiguousarray(if_block, np.uint8)
+        iq = np.zeros((len(states), 6), np.int16) if iq_out is None else iq_out
+        cb = TRACK_CHUNK_FN(lambda user, first, n: on_chunk(first, n))
+        self._chk(self.lib.gpsx_track_epl_batch_chunked(self.h, blk.ctypes.data, states.ctypes.data, len(states),
+                                                        iq.ctypes.data, n_chunks, cb, None),
+                  "gpsx_track_epl_batch_chunked")
         return iq
 
     def rewind(self, states: np.ndarray, steps) -> None:

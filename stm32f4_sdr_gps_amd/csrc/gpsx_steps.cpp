@@ -65,7 +65,8 @@ struct SlotState {
 SlotState g_shared_slot;
 
 // ---- the batched step's host workers (gps_tracking_process_batch) ---------------------------------------------------------
-constexpr int kStepThreadsFrom = 2048;   // channels from which the per-channel host loops are spread over worker threads
+constexpr int kStepThreadsFrom = 2048;    // channels from which the per-channel host loops are spread over worker threads
+constexpr int kStepOverlapFrom = 65536;   // tracked channels from which those loops overlap the correlators, piece by piece
 
 // the cache lines of a channel record the batched step touches: tracking_data (offset 60, 152 bytes) and, after the
 // correlators, the head of nav_data behind it
@@ -87,6 +88,12 @@ struct WorkerLists {   // what one worker's contiguous channel range contributes
   std::vector<uint8_t> skipped;
   int job_base = 0, st_base = 0;
   bool any_skipped = false;
+  // overlapped step: this worker's tracked channels go to the GPU as kRuns runs, run q inside piece q of the launch
+  // (entries [run_start[q], run_start[q + 1]) of `st` at run_base[q] of the step's arrays); `cursor` = the next channel
+  // whose loops have not run yet, `cursor_run` = the run its entry is in
+  static constexpr int kMaxRuns = 16;
+  int run_start[kMaxRuns + 1] = {0}, run_base[kMaxRuns] = {0};
+  int cursor = 0, cursor_run = 0;
 };
 
 // A fixed set of threads that run `fn(worker)` for worker = 0..n-1 (the caller is worker 0) and meet again.  Sized once, from
@@ -101,6 +108,9 @@ class StepPool {
     return pool;
   }
   int size() const { return n_; }
+  // while set, waiting workers keep spinning instead of going to sleep: for a caller whose runs follow each other within a
+  // few tens of microseconds (the pieces of an overlapped step) and who clears it before the long wait for the next millisecond
+  void keep_hot(bool on) { hot_.store(on, std::memory_order_relaxed); }
   template <typename F>
   void run(int n_workers, F &&fn)
   {
@@ -195,7 +205,7 @@ class StepPool {
       // 16-CPU quota: 2000 pauses -> deadline misses at 65536 channels, 200 -> none)
       static const int kSpin = [] { const char *e = std::getenv("GPSX_STEP_SPIN"); return e ? std::atoi(e) : 200; }();
       bool got = false;
-      for (int spin = 0; spin < kSpin; spin++) {
+      for (int spin = 0; spin < kSpin || hot_.load(std::memory_order_relaxed); spin++) {
         if (generation_.load(std::memory_order_acquire) != seen) {
           got = true;
           break;
@@ -228,6 +238,7 @@ class StepPool {
   std::condition_variable cv_;
   std::atomic<unsigned> generation_{0};
   std::atomic<int> pending_{0};
+  std::atomic<bool> hot_{false};
   std::function<void(int)> *job_ = nullptr;
   int active_ = 0;
   bool quit_ = false;
@@ -1388,13 +1399,42 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
   }
   jobs.resize(n_jobs);
   skipped.resize(n_st);
+  // From kStepOverlapFrom tracked channels on (and with workers to spread the loops over) the correlators go through in
+  // pieces (gpsx_track_epl_batch_chunked) and the loops of a piece run while the GPU works on the next ones.  Every worker
+  // keeps ITS channels (their records live in its core's caches from one millisecond to the next): piece q of the launch
+  // is made of the q-th part of every worker's list, so the order of the step's arrays is no longer the channel order.
+  // (Closed loop, 32 signals, one box: 131072 channels 821-870 us per step without, 712 us with 4 pieces, 753 with 2, 892
+  // with 8; 65536 channels 445-546 without, 486 with.  Pieces re-divided over all workers instead: 1175-1421 us -- a
+  // channel's record then moves between cores twice per millisecond.  $GPSX_STEP_CHUNKS = 0 / 1 turns it off.)
+  static const int kStepChunks = [] { const char *e = std::getenv("GPSX_STEP_CHUNKS"); const int v = e ? std::atoi(e) : -1; return v >= 0 && v <= WorkerLists::kMaxRuns ? v : 4; }();
+  const bool overlapped = n_workers > 1 && kStepChunks > 1 && n_st >= (size_t)kStepOverlapFrom;
+  if (overlapped) {
+    int base = 0;
+    for (int q = 0; q < kStepChunks; q++)
+      for (int w = 0; w < n_workers; w++) {
+        WorkerLists &L = lists[w];
+        const long sz = (long)L.st.size();
+        L.run_start[q] = (int)(sz * q / kStepChunks);
+        L.run_start[q + 1] = (int)(sz * (q + 1) / kStepChunks);
+        L.run_base[q] = base;
+        base += L.run_start[q + 1] - L.run_start[q];
+      }
+  }
   auto gather = [&](int w) {
     WorkerLists &L = lists[w];
     if (!L.jobs.empty())
       std::memcpy(&jobs[L.job_base], L.jobs.data(), L.jobs.size() * sizeof(gpsx_acq_job_t));
-    if (!L.st.empty()) {
+    if (L.st.empty())
+      return;
+    if (!overlapped) {
       std::memcpy(st_all + L.st_base, L.st.data(), L.st.size() * sizeof(gpsx_trk_state_t));
       std::memcpy(&skipped[L.st_base], L.skipped.data(), L.skipped.size());
+      return;
+    }
+    for (int q = 0; q < kStepChunks; q++) {
+      const int from = L.run_start[q], cnt = L.run_start[q + 1] - from;
+      std::memcpy(st_all + L.run_base[q], L.st.data() + from, cnt * sizeof(gpsx_trk_state_t));
+      std::memcpy(&skipped[L.run_base[q]], L.skipped.data() + from, cnt);
     }
   };
   pool.run(n_workers, gather);
@@ -1412,32 +1452,79 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
       if (rc != GPSX_OK)
         gpsx_compat_die("gps_tracking_process_batch(rewind)", rc);
     }
-    const int rc = gpsx_track_epl_batch(gx, data, st_all, (int)n_st, iq_all);
-    if (rc != GPSX_OK)
-      gpsx_compat_die("gps_tracking_process_batch", rc);
+    if (!overlapped) {
+      const int rc = gpsx_track_epl_batch(gx, data, st_all, (int)n_st, iq_all);
+      if (rc != GPSX_OK)
+        gpsx_compat_die("gps_tracking_process_batch", rc);
+    }
   }
   // pass 3: per-channel serial logic, in channel order within a worker
-  auto pass3 = [&](int w) {
-    const WorkerLists &L = lists[w];
-    const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
-    for (int c = lo; c < hi; c++) {
-      gps_ch_t &ch = channel[c];
-      gps_tracking_t &t = ch.tracking_data;
-      if (c + kAhead < hi)
-        prefetch_channel(channel[c + kAhead], true);
-      if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
-        if (index < TRACKING_CH_LENGTH)
-          pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[L.job_base + job_of[c]] : nullptr, slots[c]);
-        // a channel whose pre-tracking just settled starts tracking on the NEXT millisecond (its correlators were not
-        // part of this launch); the reference's single-channel call does the same one call later
-      } else if (trk_of[c] >= 0) {
-        const size_t k = (size_t)L.st_base + trk_of[c];
-        t.if_freq_accum = st_all[k].if_freq_accum;
-        tracking_apply(ch, index, &iq_all[k * 6], &slots[c]);
-      }
+  auto loops = [&](const WorkerLists &L, int c, int hi, size_t k) {
+    gps_ch_t &ch = channel[c];
+    gps_tracking_t &t = ch.tracking_data;
+    if (c + kAhead < hi)
+      prefetch_channel(channel[c + kAhead], true);
+    if (t.state == GPS_PRE_TRACK_RUN && trk_of[c] < 0) {
+      if (index < TRACKING_CH_LENGTH)
+        pre_track_apply(ch, index, job_of[c] >= 0 ? &peaks[L.job_base + job_of[c]] : nullptr, slots[c]);
+      // a channel whose pre-tracking just settled starts tracking on the NEXT millisecond (its correlators were not
+      // part of this launch); the reference's single-channel call does the same one call later
+    } else if (trk_of[c] >= 0) {
+      t.if_freq_accum = st_all[k].if_freq_accum;
+      tracking_apply(ch, index, &iq_all[k * 6], &slots[c]);
     }
   };
-  pool.run(n_workers, pass3);
+  if (!overlapped) {
+    auto pass3 = [&](int w) {
+      const WorkerLists &L = lists[w];
+      const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
+      for (int c = lo; c < hi; c++)
+        loops(L, c, hi, (size_t)L.st_base + (trk_of[c] >= 0 ? trk_of[c] : 0));
+    };
+    pool.run(n_workers, pass3);
+    return;
+  }
+  // overlapped: when entries [0, ready) of the step's arrays are back, every worker moves its cursor over the channels whose
+  // entry is among them (and the untracked channels on the way); the last piece takes each worker to the end of its range
+  size_t ready = 0;
+  for (int w = 0; w < n_workers; w++) {
+    lists[w].cursor = (int)((long)n_ch * w / n_workers);
+    lists[w].cursor_run = 0;
+  }
+  auto pass3_piece = [&](int w) {
+    WorkerLists &L = lists[w];
+    const int hi = (int)((long)n_ch * (w + 1) / n_workers);
+    int c = L.cursor, q = L.cursor_run;
+    for (; c < hi; c++) {
+      size_t k = 0;
+      if (trk_of[c] >= 0) {
+        while (trk_of[c] >= L.run_start[q + 1])
+          q++;
+        k = (size_t)L.run_base[q] + (trk_of[c] - L.run_start[q]);
+        if (k >= ready)
+          break;
+      }
+      loops(L, c, hi, k);
+    }
+    L.cursor = c;
+    L.cursor_run = q;
+  };
+  struct Piece {
+    decltype(pass3_piece) *fn;
+    StepPool *pool;
+    size_t *ready;
+    int n_workers;
+  } piece = {&pass3_piece, &pool, &ready, n_workers};
+  auto on_piece = [](void *user, int first, int n) {
+    Piece &p = *static_cast<Piece *>(user);
+    *p.ready = (size_t)first + n;
+    p.pool->run(p.n_workers, *p.fn);
+  };
+  pool.keep_hot(true);   // (workers that slept between the pieces: 827 us per step at 131072 channels instead of 712)
+  const int rc = gpsx_track_epl_batch_chunked(gx, data, st_all, (int)n_st, iq_all, kStepChunks, on_piece, &piece);
+  pool.keep_hot(false);
+  if (rc != GPSX_OK)
+    gpsx_compat_die("gps_tracking_process_batch", rc);
 }
 
 }  // extern "C"

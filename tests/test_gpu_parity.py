@@ -1445,6 +1445,64 @@ def test_track_epl_chunked_pipeline_every_chunk_boundary_vs_oracle(oracle, strea
         e.close()
 
 
+@pytest.mark.parametrize("n,chunks", [(5, 1), (4099, 3), (70001, 4), (150000, 16)])
+def test_track_epl_chunked_entry_delivers_pieces_in_order_vs_oracle(oracle, stream, n, chunks):
+    """gpsx_track_epl_batch_chunked (what the batched host step overlaps its loops with): the callback sees contiguous
+    pieces in channel order that cover every channel once; AT THE TIME OF THE CALLBACK the piece's accumulators and
+    carrier phases are in the caller's arrays (copied out inside the callback) and equal the oracle's on both sides of
+    every piece boundary, the ends and a stride; the channels of later pieces are not required to be there yet.  More
+    pieces than channels / 4 leave empty tail pieces out.  A PRN outside 1..210 fails the whole call after the callbacks."""
+    from stm32f4_sdr_gps_amd import capi
+    e = capi.Engine(0)
+    try:
+        rng = np.random.default_rng(n)
+        st = e.host_array((n,), capi.TRK_DTYPE)
+        st["prn"] = (np.arange(n) % 32) + 1
+        st["code_phase_fine"] = rng.uniform(0, 16368, n).astype(np.float32)
+        st["code_phase_fine"][:5] = [0.0, 7.5, 16367.9, 16368.0, 16359.99]
+        st["if_freq_offset_hz"] = (-5000 + (39 * np.arange(n)) % 10000).astype(np.float32)
+        st["if_freq_accum"] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+        before = np.array(st)
+        iq = e.host_array((n, 6), np.int16)
+        iq[:] = 0x5555
+        pieces, seen_iq, seen_acc = [], np.zeros((n, 6), np.int16), np.zeros(n, np.uint32)
+
+        def on_chunk(first, cnt):
+            pieces.append((first, cnt))
+            seen_iq[first:first + cnt] = iq[first:first + cnt]
+            seen_acc[first:first + cnt] = st["if_freq_accum"][first:first + cnt]
+
+        out = e.track_epl_chunked(stream[3], st, chunks, on_chunk, iq_out=iq)
+        assert out is iq
+        per = ((n + chunks - 1) // chunks + 3) & ~3
+        assert pieces == [(f, min(per, n - f)) for f in range(0, n, per)]
+        assert np.array_equal(seen_iq, iq) and np.array_equal(seen_acc, st["if_freq_accum"])
+        sample = set(range(min(12, n))) | set(range(max(0, n - 4), n)) | set(range(0, n, max(1, n // 61)))
+        for f, _ in pieces[1:]:
+            sample |= {f + d for d in (-2, -1, 0, 1) if 0 <= f + d < n}
+        codes = {p: oracle.ca_code(p) for p in range(1, 33)}
+        for c in sorted(sample):
+            want, acc = oracle.track_epl(stream[3], codes[int(before["prn"][c])], float(before["code_phase_fine"][c]),
+                                         float(before["if_freq_offset_hz"][c]), int(before["if_freq_accum"][c]))
+            assert np.array_equal(seen_iq[c], want), c
+            assert int(seen_acc[c]) == acc, c
+        # argument checks and the PRN verdict
+        for bad_chunks in (0, 17):
+            with pytest.raises(capi.GpsxError, match="n_chunks"):
+                e.track_epl_chunked(stream[3], st, bad_chunks, on_chunk)
+        st2 = e.host_array((n,), capi.TRK_DTYPE)
+        st2[:] = before
+        st2["prn"][n - 1] = 211
+        calls = []
+        with pytest.raises(capi.GpsxError, match="prn must be 1..210"):
+            e.track_epl_chunked(stream[3], st2, chunks, lambda f, c: calls.append(f))
+        assert len(calls) == len(pieces)
+        st2[:] = before
+        assert np.array_equal(e.track_epl(stream[3], st2), np.array(iq))   # ... and the one-call form agrees on every channel
+    finally:
+        e.close()
+
+
 def test_track_epl_wave_form_channel_counts_and_channels_per_wave(oracle, stream, eng_wg):
     """k_track_epl_wave serves every channel count, 1 to 16 channels per wave depending on the launch size (lanes 4 c + k carry
     channel c's values): a single channel, counts below one workgroup, and counts that give 1, 2, 5 and 16 channels per
