@@ -1407,7 +1407,8 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
   // with 8; 65536 channels 445-546 without, 486 with.  Pieces re-divided over all workers instead: 1175-1421 us -- a
   // channel's record then moves between cores twice per millisecond.  $GPSX_STEP_CHUNKS = 0 / 1 turns it off.)
   static const int kStepChunks = [] { const char *e = std::getenv("GPSX_STEP_CHUNKS"); const int v = e ? std::atoi(e) : -1; return v >= 0 && v <= WorkerLists::kMaxRuns ? v : 4; }();
-  const bool overlapped = n_workers > 1 && kStepChunks > 1 && n_st >= (size_t)kStepOverlapFrom;
+  static const int kOverlapFrom = [] { const char *e = std::getenv("GPSX_STEP_OVERLAP_FROM"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : kStepOverlapFrom; }();
+  const bool overlapped = n_workers > 1 && kStepChunks > 1 && n_st >= (size_t)kOverlapFrom;
   if (overlapped) {
     int base = 0;
     for (int q = 0; q < kStepChunks; q++)

@@ -548,6 +548,55 @@ __device__ __forceinline__ u32 root_trunc(float e)
   return (u32)(int)r;
 }
 
+// ---- the rounding mode of an epilogue ---------------------------------------------------------------------------------------
+// The small-radius path wants floor(root) as an integer in the low mantissa bits of an f32: with the f32 rounding mode at
+// "toward zero" that is ONE v_fma_f32 behind the root -- root * 2^13 (1 + 2^-22) + 2^23 -- where round-to-nearest took an add of
+// 1/2 in front of the root (so that the approximate root of a square does not land below it) and an add of 2^23 - 1/2 behind
+// it.  The factor is the guard: v_sqrt_f32 is good to one ulp (2^-23 relative), so root (1 + 2^-23) <= x <= root (1 + 1.5 *
+// 2^-22), never below the true root, and below the next integer as long as 1.5 * 2^-22 < 1 / (2 (m + 1)^2): m + 1 < 1182, the
+// small path ends at 1024.  Everything else on that path is exact in any mode (integers < 2^24 at a power-of-two scale).
+// The exact path -- (float)(I * I), the f32 sum, the correctly rounded root -- is the reference's arithmetic and runs in
+// round-to-nearest: it switches the mode back for its own instructions (its inputs and results go through the switching
+// asm statements, so none of them can be scheduled outside the pair).  MODE.FP_ROUND[1:0]: 0 = nearest even, 3 = toward zero.
+constexpr float kRootGuard = 8192.001953125f;   // 2^13 (1 + 2^-22): scaled root -> root, nudged up past v_sqrt_f32's ulp
+__device__ __forceinline__ void mx_round_toward_zero()
+{
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void mx_round_to_nearest()
+{
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1" ::: "memory");
+}
+// 0x4B000000 + floor(root of e * 2^26), e * 2^26 < 2^20 an integer; needs mx_round_toward_zero()
+__device__ __forceinline__ u32 root_bits_small(float e)
+{
+  return __float_as_uint(__builtin_fmaf(__builtin_amdgcn_sqrtf(e), kRootGuard, 8388608.0f));
+}
+// the exact path of N hypotheses, in round-to-nearest whatever the mode around it
+template <int N>
+__device__ __forceinline__ void mx_roots_exact(float (&ci)[N], float (&cq)[N], u32 (&mag)[N])
+{
+  static_assert(N == 4 || N == 8, "group size");
+  if constexpr (N == 8)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]), "+v"(ci[4]), "+v"(ci[5]), "+v"(ci[6]), "+v"(ci[7]),
+                   "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]), "+v"(cq[4]), "+v"(cq[5]), "+v"(cq[6]), "+v"(cq[7]));
+  else
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]), "+v"(cq[0]), "+v"(cq[1]), "+v"(cq[2]), "+v"(cq[3]));
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    mag[i] = mag8_f32(ci[i], cq[i]);
+  if constexpr (N == 8)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1"
+                 : "+v"(mag[0]), "+v"(mag[1]), "+v"(mag[2]), "+v"(mag[3]), "+v"(mag[4]), "+v"(mag[5]), "+v"(mag[6]), "+v"(mag[7]));
+  else
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1"
+                 : "+v"(mag[0]), "+v"(mag[1]), "+v"(mag[2]), "+v"(mag[3]));
+}
+
 constexpr float kOutside = -1048576.0f * kAccScale;   // start value (scaled) of hypotheses outside the search window: stays
                                                       // below -1, clips to 0
 
@@ -836,6 +885,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
   // wave reads / writes 768 contiguous bytes per instruction); the first records of this offset were requested before
   // the wave's MFMA pass (mx_prefetch_sums) -- the scratch is HBM, the pass hides its latency
   SumRec *e4 = reinterpret_cast<SumRec *>(energy) + ((size_t)(t0 * kMxTiles) * 64 + lane) * 4;   // [tile][lane][group]
+  mx_round_toward_zero();
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
@@ -894,12 +944,15 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       if (small) {
 #pragma unroll
         for (int i = 0; i < GS; i++)
-          mag[i] = PACKED ? __float_as_uint(__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f)) + 8388607.5f)
-                          : (u32)(int)__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f));
+          mag[i] = PACKED ? root_bits_small(ev[i]) : (u32)(int)(__builtin_amdgcn_sqrtf(ev[i]) * kRootGuard);
       } else {
+        float ci[GS], cq[GS];
 #pragma unroll
-        for (int i = 0; i < GS; i++)
-          mag[i] = root_trunc(ev[i] * kUnscaleSq);
+        for (int i = 0; i < GS; i++) {
+          ci[i] = acc[0][j][r0 + i];
+          cq[i] = acc[1][j][r0 + i];
+        }
+        mx_roots_exact<GS>(ci, cq, mag);
       }
       if constexpr (PACKED) {
         // (magnitudes in the low halves of mag[] -- the rounding add's 0x4B000000 sits above them --, two per v_perm_b32,
@@ -952,6 +1005,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  mx_round_to_nearest();
   if (SEARCH && !DIRECT) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -972,56 +1026,99 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 //   sums carry 0x4B000000 per term, four terms per PRN and sample offset: they start at -4 x 0x4B000000 (mod 2^32).
 constexpr u32 kRootBias = 0x4B000000u;
 template <int NT>
-__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0,
-                                                   const v16f (&acc)[2][NT])
+__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0, v16f (&acc)[2][NT],
+                                                   bool half_only = false)
 {
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
   u32 *slot = &sh.part[b][4 * h][0][n];
   u32 best[16], total[16];
+  // The small-radius path is taken on trust and checked afterwards: a hypothesis at radius 1024 or beyond shows in its PRN's
+  // best key, whatever the small path made of its root (at least 1024: the guard only pushes up), and the wave then does
+  // the sample offset again on the exact path -- near a strong satellite only.  One test per 64 hypotheses where a running
+  // maximum of the squares and a test per eight cost 5/8 of an instruction per hypothesis.  The second round is the same code
+  // (a loop, not a copy: a second inlined epilogue costs the MFMA pass its registers), and the accumulators are redefined
+  // at its top so that nothing of the first round is hoisted out of it and kept.
+  constexpr bool kTrust = true;
+  bool exact = false;
+  for (;;) {
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    best[r] = 0;
-    total[r] = 0u - (u32)NT * kRootBias;   // (one biased term per tile and PRN)
-  }
+    for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-  for (int jp = 0; jp < NT; jp += 2) {
+      for (int j = 0; j < NT; j++)
+        asm volatile("" : "+v"(acc[s2][j]));
 #pragma unroll
-    for (int r0 = 0; r0 < 16; r0 += 4) {
-      // eight hypotheses: two tiles x four PRNs
-      float ev[8];
-      u32 e_max = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        ev[i] = clip_square_sum(acc[0][jp + (i >> 2)][r0 + (i & 3)], acc[1][jp + (i >> 2)][r0 + (i & 3)]);
-        e_max = max(e_max, __float_as_uint(ev[i]));
-      }
-      const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
-      u32 bits[8];
-      if (__builtin_expect(small, 1)) {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-          bits[i] = __float_as_uint(__builtin_amdgcn_sqrtf(__builtin_fmaf(ev[i], kUnscaleSq, 0.5f)) + 8388607.5f);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-          bits[i] = root_trunc(ev[i] * kUnscaleSq) + kRootBias;
-      }
-      // key = (magnitude << 11) | (2047 - byte offset), byte offset = 2 q + half: kq = 2047 - 2 q is the lane's own
-      // constant, the wave-uniform half comes off the maximum when it is folded into the LDS slot
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++) {
-        const int r = r0 + rr;
-        const u32 k0 = (bits[rr] << 11) | kq[jp], k1 = (bits[4 + rr] << 11) | kq[jp + 1];
-        best[r] = max(max(best[r], k0), k1);
-        total[r] = total[r] + bits[rr] + bits[4 + rr];
-      }
-      // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
-#pragma unroll
-      for (int rr = 0; rr < 4; rr++)
-        asm volatile("" : "+v"(best[r0 + rr]), "+v"(total[r0 + rr]));
-      __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 16; r++) {
+      best[r] = 0;
+      total[r] = 0u - (u32)NT * kRootBias;   // (one biased term per tile and PRN)
     }
+    mx_round_toward_zero();
+#pragma unroll
+    for (int jp = 0; jp < NT; jp += 2) {
+#ifdef GPSX_MX_ABLATIONS
+      if (jp >= 2 && half_only)   // (timing ablation 128: half an epilogue)
+        break;
+#endif
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 4) {
+        // eight hypotheses: two tiles x four PRNs
+        u32 bits[8];
+        bool small = !exact;
+        float ev[8];
+        if (!kTrust || small) {
+          u32 e_max = 0;
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            ev[i] = clip_square_sum(acc[0][jp + (i >> 2)][r0 + (i & 3)], acc[1][jp + (i >> 2)][r0 + (i & 3)]);
+            if (!kTrust)
+              e_max = max(e_max, __float_as_uint(ev[i]));
+          }
+          if (!kTrust)
+            small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
+        }
+        if (__builtin_expect(small, 1)) {
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            bits[i] = root_bits_small(ev[i]);
+        } else {
+          float ci[8], cq[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            ci[i] = acc[0][jp + (i >> 2)][r0 + (i & 3)];
+            cq[i] = acc[1][jp + (i >> 2)][r0 + (i & 3)];
+          }
+          mx_roots_exact<8>(ci, cq, bits);
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            bits[i] += kRootBias;
+        }
+        // key = (magnitude << 11) | (2047 - byte offset), byte offset = 2 q + half: kq = 2047 - 2 q is the lane's own
+        // constant, the wave-uniform half comes off the maximum when it is folded into the LDS slot
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+          const int r = r0 + rr;
+          const u32 k0 = (bits[rr] << 11) | kq[jp], k1 = (bits[4 + rr] << 11) | kq[jp + 1];
+          best[r] = max(max(best[r], k0), k1);
+          total[r] = total[r] + bits[rr] + bits[4 + rr];
+        }
+        // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+          asm volatile("" : "+v"(best[r0 + rr]), "+v"(total[r0 + rr]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    mx_round_to_nearest();
+    if (!kTrust || exact)
+      break;
+    u32 top = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2)
+      top = max(max(top, best[r]), best[r + 1]);
+    // (the key's magnitude field starts at bit 11; the exponent bits of the root's pattern have fallen off its top)
+    if (__builtin_amdgcn_ballot_w64(top >= (1024u << 11)) == 0)
+      break;
+    exact = true;
   }
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -1130,7 +1227,8 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
   constexpr int ex = 0;            // (production builds carry none of it: its hoisted constants cost the walk form 16 registers)
 #endif
                                    // timing ablations: 1 = no epilogue, 2 = no MFMA (noise-sized counts instead), 4 = both roles in
-                                   // step, 8 = no vector building, 16 = raised priority for the MFMA passes
+                                   // step, 8 = no vector building, 16 = raised priority for the MFMA passes, 32 = no MFMA pass in
+                                   // role 1, 64 = no epilogue in role 0
   const int role = (ex & 4) ? 0 : wave >> 2;             // waves w and w + 4 share a SIMD: half a step apart
   const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
 
@@ -1269,7 +1367,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
 
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane_p, q0_tile, acc, prm.win_start, prm.win_stop);
-    if (ex & 2) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
+    if ((ex & 2) || ((ex & 32) && role)) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
 #pragma unroll
       for (int j = 0; j < kMxTiles; j++)
 #pragma unroll
@@ -1283,7 +1381,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     // but their own pace between the halves: ONE barrier per step, where all eight waves build the vector of pass p + 1
     // into the buffer that both roles read during step p - 1.
 #pragma unroll 1
-    for (int hs = 0; hs <= 2 * n_pass; hs++) {
+    for (int hs = (ex & 256) ? 2 * n_pass + 1 : 0; hs <= 2 * n_pass; hs++) {   // (timing ablation 256: no steps at all)
       if ((hs & 1) == 0)
         __syncthreads();
       // The vector of the next step: built behind the barrier by everybody (single-block forms), or behind this step's epilogue
@@ -1292,7 +1390,11 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       // the next step publishes it).  Same-box A/B: behind the epilogue is 1.5 % faster for the walk form (whose epilogue waits
       // on HBM anyway) and 1.8 % slower for the single-block form -- the step is bound by the SIMD's issue port, not by the
       // barrier: moving the work does not shorten it.
+#ifdef MX_BUILD_BEHIND
+      constexpr bool kBuildBehindEpilogue = true;
+#else
       constexpr bool kBuildBehindEpilogue = MULTI;
+#endif
       if (!kBuildBehindEpilogue && (hs & 1) == 0) {
         const int p_vec = (hs >> 1) + 1;
         if (p_vec >= 2 && p_vec < n_pass && !(ex & 8)) {
@@ -1313,7 +1415,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
           if (p >= 1)
             mx_prefetch_sums<0, 8, S16>(e_wave, zero_recs, lane_s, p - 1, ms_first, pre);
         }
-        if (!(ex & 2)) {
+        if (!(ex & 2) && !((ex & 32) && role)) {
           if (ex & 16)
             __builtin_amdgcn_s_setprio(3);
           mx_pass<!MULTI>(sh, p & 1, lane, q0_tile, acc, p == 1 ? kScaleEight : kScaleOne, a_corr, p >= 2 && (SPLIT || p != 9));
@@ -1337,9 +1439,9 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
                              ((size_t)((search * prm.n_ms + ms_store) * prm.n_prn + 32 * set) * prm.n_dopp + dopp) * (16 * 1024);
           mx_epilogue_store(lane, q0_tile, p - 1, acc, group_mask, plane0, (size_t)prm.n_dopp * (16 * 1024), 32 * set, prm.n_prn);
         }
-      } else if (active && (x & 1) && p >= 1 && !(ex & 1)) {
+      } else if (active && (x & 1) && p >= 1 && !(ex & 1) && !((ex & 64) && !role)) {
         if (!MULTI)
-          mx_epilogue_single(sh, lane, kq, t0s + p - 1, acc);
+          mx_epilogue_single(sh, lane, kq, t0s + p - 1, acc, (ex & 128) != 0);
         else if (!ms_last)
           mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, zero_recs, pre, ms_first, witness);
         else

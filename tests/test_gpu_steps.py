@@ -171,20 +171,26 @@ print("RESULT", int((state == sd.TRK_RUN).sum()), *crcs)
 
 def test_batched_step_on_worker_threads_equals_the_single_threaded_step():
     """gps_tracking_process_batch spreads its per-channel host loops over worker threads from 2048 channels on
-    (gpsx_steps.cpp StepPool).  4096 channels, 400 ms from pre-tracking into tracking and nav-bit synchronisation: the whole
-    channel table (acq, tracking, nav and observation state of every channel, CRC every 25 ms) must be the same with 1, 3
-    and 7 workers -- a channel's state may not depend on which thread served it or on how the ranges were cut.  (Strong
-    signals: the one shared state of the path, rand() in the PLL's false-lock reseed, is never drawn.)  Separate
-    processes: the pool is sized once per process."""
+    (gpsx_steps.cpp StepPool) and, from 65536 tracked channels on, runs them piece by piece while the GPU correlates the
+    next pieces (gpsx_track_epl_batch_chunked; the threshold is lowered here).  4096 channels, 400 ms from pre-tracking into
+    tracking and nav-bit synchronisation: the whole channel table (acq, tracking, nav and observation state of every
+    channel, CRC every 25 ms) must be the same with 1, 3 and 7 workers, and with 5 and 7 workers in the overlapped form
+    (4 pieces once 1024 channels track; 16 pieces from the first tracked channel on, i.e. with pre-tracking and tracking
+    channels mixed and pieces smaller than the worker count) -- a channel's state may not depend on which thread served
+    it, on how the ranges were cut or on the order its correlators went to the GPU in.  (Strong signals: the one shared
+    state of the path, rand() in the PLL's false-lock reseed, is never drawn.)  Separate processes: the pool is sized
+    once per process."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for threads in ("1", "3", "7"):
-        env = dict(os.environ, GPSX_STEP_THREADS=threads)
+    for threads, extra in (("1", {}), ("3", {}), ("7", {}),
+                           ("5", {"GPSX_STEP_OVERLAP_FROM": "1024", "GPSX_STEP_CHUNKS": "4"}),
+                           ("7", {"GPSX_STEP_OVERLAP_FROM": "1", "GPSX_STEP_CHUNKS": "16"})):
+        env = dict(os.environ, GPSX_STEP_THREADS=threads, **extra)
         r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
         assert r.returncode == 0 and line, r.stderr[-2000:]
         outs.append(line[0])
-    assert outs[0] == outs[1] == outs[2], outs
+    assert all(o == outs[0] for o in outs), outs
     assert int(outs[0].split()[1]) >= 4096 * 7 // 8      # and the channels did reach tracking

@@ -83,6 +83,7 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True):
                 "thread_on_gpu_numa_node": bool(bound),
                 "p50_us": float(np.percentile(steady, 50) * 1e6), "p99_us": float(np.percentile(steady, 99) * 1e6),
                 "max_us": float(steady.max() * 1e6), "steps_over_1ms": late,
+                "slowest_steady_steps_ms": [int(i) + ms // 2 for i in np.argsort(steady)[::-1][:4]],
                 "warmup_max_us": float(lat[:ms // 2].max() * 1e6),
                 "real_time": bool(late == 0),
                 "tracking_state": int((state == sd.TRK_RUN).sum()), "code_and_carrier_lock": int(locked.sum()),

@@ -6,6 +6,10 @@ set -e
 cd "$(dirname "$0")/../stm32f4_sdr_gps_amd/csrc"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -fno-fast-math -Wno-unused-function"
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize -DMX_VARIANT_B ${VARIANT_DEFS:--DGPSX_MX_ABLATIONS} -c k_acq_mx.hip -o ../build/k_acq_mx_b.o
-OBJS=$(ls ../build/*.o | grep -v k_acq_mx)
+OBJS=$(ls ../build/*.o | grep -v k_acq_mx | grep -v _b.o)
+case "${VARIANT_DEFS:--DGPSX_MX_ABLATIONS}" in *GPSX_MX_ABLATIONS*)   # $GPSX_MX_EXPERIMENT is read by the launcher's caller
+  /opt/rocm/bin/hipcc $F -DGPSX_MX_ABLATIONS -c gpsx_api.hip -o ../build/gpsx_api_b.o
+  OBJS="$(echo $OBJS | tr ' ' '\n' | grep -v gpsx_api.o) ../build/gpsx_api_b.o";;
+esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libgpsx_b.so $OBJS ../build/k_acq_mx_b.o -Wl,-rpath,/opt/rocm/lib -ldl
 echo built ../lib/libgpsx_b.so
