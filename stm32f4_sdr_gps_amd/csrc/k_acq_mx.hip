@@ -1033,6 +1033,12 @@ __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const
   const int b = t0 & 7, half = t0 >> 3;
   u32 *slot = &sh.part[b][4 * h][0][n];
   u32 best[16], total[16];
+  // key = (magnitude << 11) | (2047 - byte offset), byte offset = 2 q + half: kq = 2047 - 2 q is the lane's own constant
+  // (>= 1), the wave-uniform half comes off it here, once per tile
+  u32 kqh[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++)
+    kqh[j] = kq[j] - (u32)half;
   // The small-radius path is taken on trust and checked afterwards: a hypothesis at radius 1024 or beyond shows in its PRN's
   // best key, whatever the small path made of its root (at least 1024: the guard only pushes up), and the wave then does
   // the sample offset again on the exact path -- near a strong satellite only.  One test per 64 hypotheses where a running
@@ -1092,12 +1098,10 @@ __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const
           for (int i = 0; i < 8; i++)
             bits[i] += kRootBias;
         }
-        // key = (magnitude << 11) | (2047 - byte offset), byte offset = 2 q + half: kq = 2047 - 2 q is the lane's own
-        // constant, the wave-uniform half comes off the maximum when it is folded into the LDS slot
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
           const int r = r0 + rr;
-          const u32 k0 = (bits[rr] << 11) | kq[jp], k1 = (bits[4 + rr] << 11) | kq[jp + 1];
+          const u32 k0 = (bits[rr] << 11) | kqh[jp], k1 = (bits[4 + rr] << 11) | kqh[jp + 1];
           best[r] = max(max(best[r], k0), k1);
           total[r] = total[r] + bits[rr] + bits[4 + rr];
         }
@@ -1123,7 +1127,7 @@ __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;   // PRN (r & 3) + 8 (r >> 2) + 4 h: 2 x 32 words per PRN
-    atomicMax(slot + p_off, best[r] - (u32)half);      // (kq >= 1: the subtraction stays inside the low field)
+    atomicMax(slot + p_off, best[r]);
     atomicAdd(slot + p_off + 32, total[r]);
   }
 }
