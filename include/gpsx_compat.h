@@ -225,6 +225,9 @@ extern uint8_t key_up_presed;
  * channels inside the 1 ms budget; per channel the result is what gps_tracking_process would give a receiver that had
  * only that channel.  Nav-bit synchronisation uses the built-in default (not the overridable hook). */
 void      gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint8_t index);
+/* threads (the caller included) the batched step spreads its per-channel host loops over from 2048 channels on: sized at the
+ * first such call from the calling thread's CPUs and the container's CPU quota ($GPSX_STEP_THREADS overrides) */
+int       gps_tracking_batch_workers(void);
 
 /* Link-time dependencies of the step logic, as in the reference.  libgpsx provides WEAK defaults that a host program
  * overrides simply by defining the symbol:

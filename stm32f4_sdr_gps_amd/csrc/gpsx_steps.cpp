@@ -1307,6 +1307,8 @@ void gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index)
 // receiver (the schedule of project_single_sat/main.c:96-109: every channel is served every millisecond, `index`
 // cycles 0..3 or is 0xFF for an idle slot).  All pre-tracking searches go out as ONE job list and all E/P/L correlators
 // as ONE launch; the per-channel loop logic is the same code gps_tracking_process runs.
+int gps_tracking_batch_workers(void) { return StepPool::instance().size(); }
+
 void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint8_t index)
 {
   static std::vector<SlotState> slots;

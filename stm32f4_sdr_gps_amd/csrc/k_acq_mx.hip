@@ -1018,16 +1018,18 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 
 // The single-block form's epilogue (n_ms == 1: what the headline sweep runs).  A wave that has its SIMD's vector ALU to
 // itself issues an instruction every ~6.5 cycles whatever the instruction (tools/microbench/issue_mix.hip), so what counts
-// here is their number: per hypothesis 2 clip-squares, 1 add, 3/8 of the group's radius test, 1 fma (e + 1/2), the root,
-// 1 add that rounds it down to an integer in the low mantissa bits, the key, and 1/2 + 1/2 for the running maximum and
-// sum of its PRN (two tiles at a time: v_max3_u32 / v_add3_u32).
-//   root + (2^23 - 1/2) rounds to 2^23 + floor(root) for every root of the small path (no root is an integer there, see
-//   mx_epilogue), whose f32 pattern is 0x4B000000 + floor(root): shifted left by 11 the exponent bits fall off the key; the
+// here is their number: per hypothesis 2 clip-squares, 1 add, 5/8 for the group's radius test, the root of the scaled sum,
+// 1 fma that (in round-toward-zero mode, root_bits_small) leaves floor(root) as an integer in the low mantissa bits, the
+// key, and 1/2 + 1/2 for the running maximum and sum of its PRN (two tiles at a time: v_max3_u32 / v_add3_u32).
+//   The f32 pattern of that fma is 0x4B000000 + floor(root): shifted left by 11 the exponent bits fall off the key; the
 //   sums carry 0x4B000000 per term, four terms per PRN and sample offset: they start at -4 x 0x4B000000 (mod 2^32).
+//   (Tried: taking the small path on trust and checking the best keys afterwards -- one test per 64 hypotheses, a second round
+//   on the exact path for the PRN groups that show a radius >= 1024 -- saves the 5/8: 1 % faster on noise, 2.5 % slower
+//   on the strong test signal, same-box A/B; not kept.)
 constexpr u32 kRootBias = 0x4B000000u;
 template <int NT>
-__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0, v16f (&acc)[2][NT],
-                                                   bool half_only = false)
+__device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0,
+                                                   const v16f (&acc)[2][NT], bool half_only = false)
 {
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
@@ -1039,91 +1041,61 @@ __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const
 #pragma unroll
   for (int j = 0; j < NT; j++)
     kqh[j] = kq[j] - (u32)half;
-  // The small-radius path is taken on trust and checked afterwards: a hypothesis at radius 1024 or beyond shows in its PRN's
-  // best key, whatever the small path made of its root (at least 1024: the guard only pushes up), and the wave then does
-  // the sample offset again on the exact path -- near a strong satellite only.  One test per 64 hypotheses where a running
-  // maximum of the squares and a test per eight cost 5/8 of an instruction per hypothesis.  The second round is the same code
-  // (a loop, not a copy: a second inlined epilogue costs the MFMA pass its registers), and the accumulators are redefined
-  // at its top so that nothing of the first round is hoisted out of it and kept.
-  constexpr bool kTrust = true;
-  bool exact = false;
-  for (;;) {
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++)
+  for (int r = 0; r < 16; r++) {
+    best[r] = 0;
+    total[r] = 0u - (u32)NT * kRootBias;   // (one biased term per tile and PRN)
+  }
+  mx_round_toward_zero();
 #pragma unroll
-      for (int j = 0; j < NT; j++)
-        asm volatile("" : "+v"(acc[s2][j]));
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      best[r] = 0;
-      total[r] = 0u - (u32)NT * kRootBias;   // (one biased term per tile and PRN)
-    }
-    mx_round_toward_zero();
-#pragma unroll
-    for (int jp = 0; jp < NT; jp += 2) {
+  for (int jp = 0; jp < NT; jp += 2) {
 #ifdef GPSX_MX_ABLATIONS
-      if (jp >= 2 && half_only)   // (timing ablation 128: half an epilogue)
-        break;
+    if (jp >= 2 && half_only)   // (timing ablation 128: half an epilogue)
+      break;
 #endif
 #pragma unroll
-      for (int r0 = 0; r0 < 16; r0 += 4) {
-        // eight hypotheses: two tiles x four PRNs
-        u32 bits[8];
-        bool small = !exact;
-        float ev[8];
-        if (!kTrust || small) {
-          u32 e_max = 0;
+    for (int r0 = 0; r0 < 16; r0 += 4) {
+      // eight hypotheses: two tiles x four PRNs
+      float ev[8];
+      u32 e_max = 0;
 #pragma unroll
-          for (int i = 0; i < 8; i++) {
-            ev[i] = clip_square_sum(acc[0][jp + (i >> 2)][r0 + (i & 3)], acc[1][jp + (i >> 2)][r0 + (i & 3)]);
-            if (!kTrust)
-              e_max = max(e_max, __float_as_uint(ev[i]));
-          }
-          if (!kTrust)
-            small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
-        }
-        if (__builtin_expect(small, 1)) {
-#pragma unroll
-          for (int i = 0; i < 8; i++)
-            bits[i] = root_bits_small(ev[i]);
-        } else {
-          float ci[8], cq[8];
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            ci[i] = acc[0][jp + (i >> 2)][r0 + (i & 3)];
-            cq[i] = acc[1][jp + (i >> 2)][r0 + (i & 3)];
-          }
-          mx_roots_exact<8>(ci, cq, bits);
-#pragma unroll
-          for (int i = 0; i < 8; i++)
-            bits[i] += kRootBias;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-          const int r = r0 + rr;
-          const u32 k0 = (bits[rr] << 11) | kqh[jp], k1 = (bits[4 + rr] << 11) | kqh[jp + 1];
-          best[r] = max(max(best[r], k0), k1);
-          total[r] = total[r] + bits[rr] + bits[4 + rr];
-        }
-        // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-          asm volatile("" : "+v"(best[r0 + rr]), "+v"(total[r0 + rr]));
-        __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; i++) {
+        ev[i] = clip_square_sum(acc[0][jp + (i >> 2)][r0 + (i & 3)], acc[1][jp + (i >> 2)][r0 + (i & 3)]);
+        e_max = max(e_max, __float_as_uint(ev[i]));
       }
-    }
-    mx_round_to_nearest();
-    if (!kTrust || exact)
-      break;
-    u32 top = 0;
+      const bool small = __builtin_amdgcn_ballot_w64(e_max >= 0x3C800000u /* 2^20 / 2^26 as f32 */) == 0;
+      u32 bits[8];
+      if (__builtin_expect(small, 1)) {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2)
-      top = max(max(top, best[r]), best[r + 1]);
-    // (the key's magnitude field starts at bit 11; the exponent bits of the root's pattern have fallen off its top)
-    if (__builtin_amdgcn_ballot_w64(top >= (1024u << 11)) == 0)
-      break;
-    exact = true;
+        for (int i = 0; i < 8; i++)
+          bits[i] = root_bits_small(ev[i]);
+      } else {
+        float ci[8], cq[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          ci[i] = acc[0][jp + (i >> 2)][r0 + (i & 3)];
+          cq[i] = acc[1][jp + (i >> 2)][r0 + (i & 3)];
+        }
+        mx_roots_exact<8>(ci, cq, bits);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          bits[i] += kRootBias;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        const int r = r0 + rr;
+        const u32 k0 = (bits[rr] << 11) | kqh[jp], k1 = (bits[4 + rr] << 11) | kqh[jp + 1];
+        best[r] = max(max(best[r], k0), k1);
+        total[r] = total[r] + bits[rr] + bits[4 + rr];
+      }
+      // (pinned in program order: left alone, the compiler sinks all 64 chains to the end and spills)
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++)
+        asm volatile("" : "+v"(best[r0 + rr]), "+v"(total[r0 + rr]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
+  mx_round_to_nearest();
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;   // PRN (r & 3) + 8 (r >> 2) + 4 h: 2 x 32 words per PRN

@@ -20,7 +20,7 @@ def main():
     if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
         capi.LIB_PATH = os.environ["GPSX_LIB"]
     eng = capi.Engine(0)
-    blocks = synth.cold_start_block(searches * n_ms, seed=11, amp_scale=0.25, two_bit=True)
+    blocks = synth.cold_start_block(searches * n_ms, seed=11, amp_scale=float(os.environ.get("GPSX_BENCH_AMP", "0.25")), two_bit=True)
     eng.set_if_format(capi.IF_2BIT_SM)
     prns = np.arange(1, 33, dtype=np.uint8)
     g = eng.grid_desc(prns, n_search=searches, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=-5000, dopp_step_hz=500,
