@@ -86,9 +86,6 @@ struct MxShared {
   u32 ones[2];                           // pop(D) per stream
   u32 t_lut[768];                        // [0, 512): 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7;
                                          // [512, 768): 8 bits -> FP4 codes of 2 bit - 1 (mx_fill_tables)
-#ifdef MX_FUSED
-  u32 nowhere[1856];                     // where a stage with no results to publish sends its atomics (fused form)
-#endif
   alignas(16) u32 part[8][32][2][32];              // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
                                          // PRN: every lane folds its own results in with LDS atomics (no return value, no
                                          // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
@@ -1134,198 +1131,6 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
 }
 
 
-#ifdef MX_FUSED
-// ---- fused form of the single-block sweep (experiment) -------------------------------------------------------------------
-// No roles: every wave works in stages of a tile pair -- the MFMAs of pass p on pair X with, between them, the epilogue of pair
-// Y (whose accumulators the pass does not touch): one PRN (two hypotheses) per anti-diagonal step, and the LDS atomics of
-// the stage before, whose results wait in `best` / `total` until the registers are needed for the next ones.  Both waves of a
-// SIMD feed the matrix pipe all the time; the vector ALU work rides in the issue slots between their MFMAs.
-struct MxFusedEpi {
-  u32 best[16], total[16];
-  u32 *slot;    // where best / total of the stage before go (sh.nowhere: nothing to publish)
-};
-
-constexpr int mx_p_off(int r) { return ((r & 3) + 8 * (r >> 2)) * 64; }   // PRN (r & 3) + 8 (r >> 2) + 4 h: 2 x 32 words per PRN
-
-// one PRN of the pair's epilogue: publish what waits in its registers, then its two hypotheses (small-radius path, on trust)
-template <int R>
-__device__ __forceinline__ void mx_fused_unit(MxFusedEpi &st, const v16f (&accY)[2][2], const u32 (&kqh)[2])
-{
-  atomicMax(st.slot + mx_p_off(R), st.best[R]);
-  atomicAdd(st.slot + mx_p_off(R) + 32, st.total[R]);
-  const float e0 = clip_square_sum(accY[0][0][R], accY[1][0][R]), e1 = clip_square_sum(accY[0][1][R], accY[1][1][R]);
-  const u32 b0 = root_bits_small(e0), b1 = root_bits_small(e1);
-  const u32 k0 = (b0 << 11) | kqh[0], k1 = (b1 << 11) | kqh[1];
-  st.best[R] = max(k0, k1);
-  st.total[R] = b0 + b1 + (0u - 2u * kRootBias);
-  asm volatile("" : "+v"(st.best[R]), "+v"(st.total[R]));   // (here, not where the stage's end reads them)
-}
-
-template <int S>
-__device__ __forceinline__ void mx_fused_step(lds_cu32 *wi, lds_cu32 *wq, const v4i *ca, v4i (&a)[16], v4i &fi, v4i &fq,
-                                              v16f (&acc)[2][2], u32 scale_b, MxFusedEpi &st, const v16f (&accY)[2][2],
-                                              const u32 (&kqh)[2])
-{
-  constexpr int NT = 2, kSteps = 16 + NT - 1;
-  constexpr bool more = S + 1 < kSteps;
-  v4i fi_next = fi, fq_next = fq;
-  if constexpr (more) {
-    fi_next = lds_frag(wi, 8 * (S + 1));
-    fq_next = lds_frag(wq, 8 * (S + 1));
-    if constexpr (S + 1 < 16)
-      a[S + 1] = ca[(S + 1) * 64];
-  }
-  constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < NT - 1 ? S : NT - 1;
-#pragma unroll
-  for (int j = j_lo; j <= j_hi; j++) {
-    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
-    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fq), acc[1][j], 4, 4, 0, kScaleA, 0, scale_b);
-  }
-  if constexpr (S < 16)
-    mx_fused_unit<S>(st, accY, kqh);
-  if constexpr (more)
-    __builtin_amdgcn_sched_group_barrier(0x100, S + 1 < 16 ? 5 : 4, 0);   // DS reads of the next anti-diagonal first
-  // then the MFMAs with the unit's vector instructions between them
-  constexpr int n_mfma = 2 * (j_hi - j_lo + 1);
-#pragma unroll
-  for (int m = 0; m < n_mfma; m++) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if constexpr (S < 16)
-      __builtin_amdgcn_sched_group_barrier(0x002, (14 + n_mfma - 1) / n_mfma, 0);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  fi = fi_next;
-  fq = fq_next;
-  if constexpr (more)
-    mx_fused_step<S + 1>(wi, wq, ca, a, fi, fq, acc, scale_b, st, accY, kqh);
-}
-
-// the exact path for a whole pair (a radius >= 1024 showed in the keys the small path produced)
-__device__ __forceinline__ void mx_fused_exact(MxFusedEpi &st, const v16f (&accY)[2][2], const u32 (&kqh)[2])
-{
-#pragma unroll
-  for (int r0 = 0; r0 < 16; r0 += 4) {
-    float ci[8], cq[8];
-    u32 bits[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      ci[i] = accY[0][i >> 2][r0 + (i & 3)];
-      cq[i] = accY[1][i >> 2][r0 + (i & 3)];
-    }
-    mx_roots_exact<8>(ci, cq, bits);
-#pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-      const u32 k0 = (bits[rr] << 11) | kqh[0], k1 = (bits[4 + rr] << 11) | kqh[1];
-      st.best[r0 + rr] = max(k0, k1);
-      st.total[r0 + rr] = bits[rr] + bits[4 + rr];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// after a stage's units: were they all inside the small radius?  If not, the pair again on the exact path.
-__device__ __forceinline__ void mx_fused_check(MxFusedEpi &st, const v16f (&accY)[2][2], const u32 (&kqh)[2])
-{
-  u32 top = 0;
-#pragma unroll
-  for (int r = 0; r < 16; r += 2)
-    top = max(max(top, st.best[r]), st.best[r + 1]);
-  if (__builtin_amdgcn_ballot_w64(top >= (1024u << 11)) != 0)
-    mx_fused_exact(st, accY, kqh);
-}
-
-// one stage: pass on pair X (q-tiles q0x, q0x + 2) || epilogue of pair Y for sample offset t0 (due: is there one yet?)
-__device__ __forceinline__ void mx_fused_stage(MxShared &sh, int buf, int lane, int q0x, v16f (&accX)[2][2], u32 scale_b,
-                                               v4i a_corr, bool with_corr, const v16f (&accY)[2][2], int q0y, int t0, bool due,
-                                               MxFusedEpi &st)
-{
-  const int n = lane & 31, h = lane >> 5;
-  const u32 half = (u32)(t0 >> 3) & 1u;
-  const u32 kqh[2] = {(u32)(2047 - 2 * (32 * q0y + n)) - half, (u32)(2047 - 2 * (32 * (q0y + 2) + n)) - half};
-  const u32 *e8 = &sh.e8[buf][0][0][0];
-  lds_cu32 *wi = lds_opaque(e8 + (n & 7) * kCopyDwords + 4 * (q0x + h) + (n >> 3));
-  lds_cu32 *wq = lds_opaque(e8 + (8 + (n & 7)) * kCopyDwords + 4 * (q0x + h) + (n >> 3));
-  const v4i *ca = &sh.chips_a[0][h][n];
-  v4i a[16];
-  v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
-  a[0] = ca[0];
-  mx_fused_step<0>(wi, wq, ca, a, fi, fq, accX, scale_b, st, accY, kqh);
-  if (with_corr) {   // the extra K step, as in mx_pass
-    lds_cu32 *cw = lds_opaque(&sh.corr[buf][0][h][4 * q0x + (n >> 3)]);
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const v4i gi = v4i{(int)(cw[8 * j] >> (4 * (n & 7))), 0, 0, 0};
-      const v4i gq = v4i{(int)(cw[8 * j + 2 * 128] >> (4 * (n & 7))), 0, 0, 0};
-      accX[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gi), accX[0][j], 4, 4, 0, kScaleA, 0,
-                                                                    kScaleOne);
-      accX[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_corr), widen(gq), accX[1][j], 4, 4, 0, kScaleA, 0,
-                                                                    kScaleOne);
-    }
-  }
-  // what the units left in best / total is this stage's; it goes out during the next stage (or the drain)
-  if (due) {
-    mx_fused_check(st, accY, kqh);
-    st.slot = &sh.part[t0 & 7][4 * h][0][n];
-  } else {
-    st.slot = &sh.nowhere[n];
-  }
-}
-
-template <int R>
-__device__ __forceinline__ void mx_fused_units_only(MxFusedEpi &st, const v16f (&accY)[2][2], const u32 (&kqh)[2])
-{
-  mx_fused_unit<R>(st, accY, kqh);
-  if constexpr (R % 4 == 3)
-    __builtin_amdgcn_sched_barrier(0);
-  if constexpr (R < 15)
-    mx_fused_units_only<R + 1>(st, accY, kqh);
-}
-
-__device__ __forceinline__ void mx_fused_steps(MxShared &sh, const AcqParams &prm, int lane, int tid, int q0_tile, v4i a_corr)
-{
-  const int n = lane & 31, h = lane >> 5;
-  const int qA = q0_tile, qB = q0_tile + 4;
-  v16f accA[2][2], accB[2][2];
-  mx_init_acc(sh, lane, qA, accA, prm.win_start, prm.win_stop);
-  mx_init_acc(sh, lane, qB, accB, prm.win_start, prm.win_stop);
-  MxFusedEpi st;
-#pragma unroll
-  for (int r = 0; r < 16; r++)
-    st.best[r] = st.total[r] = 0;
-  st.slot = &sh.nowhere[n];
-  mx_round_toward_zero();
-#pragma unroll 1
-  for (int p = 0; p < kPasses; p++) {
-    __syncthreads();
-    if (p + 1 >= 2 && p + 1 < kPasses)
-      mx_vector_build(sh, p + 1, tid);
-    const u32 scale_b = p == 1 ? kScaleEight : kScaleOne;
-    const bool corr = p >= 2 && p != 9;
-    // pass p on pair A || epilogue of pair B after pass p - 1 (sample offset p - 2)
-    mx_fused_stage(sh, p & 1, lane, qA, accA, scale_b, a_corr, corr, accB, qB, p - 2, p >= 2, st);
-    if (p == 9)
-      mx_half_switch<false>(sh, lane, qA, accA, prm.win_start, prm.win_stop);
-    // pass p on pair B || epilogue of pair A after pass p (sample offset p - 1)
-    mx_fused_stage(sh, p & 1, lane, qB, accB, scale_b, a_corr, corr, accA, qA, p - 1, p >= 1, st);
-    if (p == 9)
-      mx_half_switch<false>(sh, lane, qB, accB, prm.win_start, prm.win_stop);
-  }
-  // drain: pair B after the last pass (sample offset 15), then what is left in the registers
-  {
-    constexpr int t0 = kPasses - 2;
-    const u32 kqh[2] = {(u32)(2047 - 2 * (32 * qB + n)) - (u32)(t0 >> 3), (u32)(2047 - 2 * (32 * (qB + 2) + n)) - (u32)(t0 >> 3)};
-    mx_fused_units_only<0>(st, accB, kqh);
-    mx_fused_check(st, accB, kqh);
-    u32 *slot = &sh.part[t0 & 7][4 * h][0][n];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      atomicMax(slot + mx_p_off(r), st.best[r]);
-      atomicAdd(slot + mx_p_off(r) + 32, st.total[r]);
-    }
-  }
-  mx_round_to_nearest();
-}
-#endif   // MX_FUSED
 
 constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5;   // k_acq_mx's MODE
 
@@ -1538,12 +1343,6 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       mx_vector_phase2(sh, 1, tid_p, kMxThreads);
     }
 
-#ifdef MX_FUSED
-    if constexpr (MODE == kMxSingle) {
-      mx_fused_steps(sh, prm, lane, tid, q0_tile, a_corr);
-      continue;   // (the block loop runs once)
-    }
-#endif
     v16f acc[2][kMxTiles];
     mx_init_acc(sh, lane_p, q0_tile, acc, prm.win_start, prm.win_stop);
     if ((ex & 2) || ((ex & 32) && role)) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
