@@ -11,11 +11,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
-#include <condition_variable>
 #include <functional>
 #include <initializer_list>
-#include <mutex>
 #include <sched.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <climits>
 #include <thread>
 #include <vector>
 
@@ -99,7 +101,7 @@ struct WorkerLists {   // what one worker's contiguous channel range contributes
 // A fixed set of threads that run `fn(worker)` for worker = 0..n-1 (the caller is worker 0) and meet again.  Sized once, from
 // the CPUs the creating thread may run on ($GPSX_STEP_THREADS overrides; at most 64), so a process that pinned itself next to
 // its GPU (gpsx_bind_thread_to_device) gets workers on those cores.  Between steps the workers spin briefly -- the next
-// millisecond is never far -- then sleep on a condition variable.
+// millisecond is never far -- then sleep on the generation counter (a futex).
 class StepPool {
  public:
   static StepPool &instance()
@@ -120,21 +122,19 @@ class StepPool {
     }
     start_threads();
     std::function<void(int)> f = std::ref(fn);
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      job_ = &f;
-      active_ = n_workers;
-      pending_.store(n_workers - 1, std::memory_order_relaxed);
-      generation_.fetch_add(1, std::memory_order_release);
-    }
-    cv_.notify_all();
+    job_.store(&f, std::memory_order_relaxed);
+    active_.store(n_workers, std::memory_order_relaxed);
+    pending_.store(n_workers - 1, std::memory_order_relaxed);
+    generation_.fetch_add(1);
+    // one system call wakes every sleeper, and none of them takes a lock on its way out (a condition variable hands its mutex
+    // from thread to thread: thirteen wake-ups in a row at the head of every phase of every millisecond)
+    if (sleepers_.load() != 0)   // (sequentially consistent with the sleeper's own "count myself, look again")
+      futex(FUTEX_WAKE_PRIVATE, INT_MAX);
     fn(0);
     for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++)
       if (spin > 64)
         std::this_thread::yield();
-    std::lock_guard<std::mutex> lk(m_);
-    job_ = nullptr;
-    active_ = 0;
+    job_.store(nullptr, std::memory_order_relaxed);
   }
 
  private:
@@ -180,14 +180,16 @@ class StepPool {
   }
   ~StepPool()
   {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      quit_ = true;
-      generation_.fetch_add(1, std::memory_order_release);
-    }
-    cv_.notify_all();
+    quit_.store(true);
+    generation_.fetch_add(1);
+    futex(FUTEX_WAKE_PRIVATE, INT_MAX);
     for (std::thread &t : threads_)
       t.join();
+  }
+  long futex(int op, unsigned val)   // on the generation counter
+  {
+    static_assert(sizeof(std::atomic<unsigned>) == sizeof(unsigned), "futex word");
+    return syscall(SYS_futex, reinterpret_cast<unsigned *>(&generation_), op, val, nullptr, nullptr, 0);
   }
   void start_threads()
   {
@@ -204,28 +206,27 @@ class StepPool {
       // a worker that spins through the GPU's part of the millisecond burns the CPU quota the step needs (measured on a
       // 16-CPU quota: 2000 pauses -> deadline misses at 65536 channels, 200 -> none)
       static const int kSpin = [] { const char *e = std::getenv("GPSX_STEP_SPIN"); return e ? std::atoi(e) : 200; }();
-      bool got = false;
-      for (int spin = 0; spin < kSpin || hot_.load(std::memory_order_relaxed); spin++) {
-        if (generation_.load(std::memory_order_acquire) != seen) {
-          got = true;
-          break;
+      for (int spin = 0; generation_.load(std::memory_order_acquire) == seen; spin++) {
+        if (spin < kSpin || hot_.load(std::memory_order_relaxed)) {
+          __builtin_ia32_pause();
+          continue;
         }
-        __builtin_ia32_pause();
+        sleepers_.fetch_add(1);
+        if (generation_.load() == seen)
+          futex(FUTEX_WAIT_PRIVATE, seen);   // (returns at once if the counter has moved on)
+        sleepers_.fetch_sub(1);
+        spin = 0;
       }
-      if (!got) {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return generation_.load(std::memory_order_acquire) != seen; });
-      }
+      // (job and worker count of THE generation taken: a worker outside a run's count may look late, when the next is posted)
       std::function<void(int)> *job;
       int active;
-      {
-        std::lock_guard<std::mutex> lk(m_);
-        seen = generation_.load(std::memory_order_acquire);
-        if (quit_)
-          return;
-        job = job_;
-        active = active_;
-      }
+      do {
+        seen = generation_.load();
+        job = job_.load(std::memory_order_relaxed);
+        active = active_.load(std::memory_order_relaxed);
+      } while (generation_.load() != seen);
+      if (quit_.load(std::memory_order_relaxed))
+        return;
       if (job && w < active) {
         (*job)(w);
         pending_.fetch_sub(1, std::memory_order_release);
@@ -234,17 +235,12 @@ class StepPool {
   }
   int n_ = 1;
   std::vector<std::thread> threads_;
-  std::mutex m_;
-  std::condition_variable cv_;
   std::atomic<unsigned> generation_{0};
-  std::atomic<int> pending_{0};
-  std::atomic<bool> hot_{false};
-  std::function<void(int)> *job_ = nullptr;
-  int active_ = 0;
-  bool quit_ = false;
+  std::atomic<int> pending_{0}, sleepers_{0}, active_{0};
+  std::atomic<bool> hot_{false}, quit_{false};
+  std::atomic<std::function<void(int)> *> job_{nullptr};
 };
 
-// page-locked staging of the batched step's channel states and accumulators (grow-only; freed with the process)
 struct StepBuffers {
   gpsx_trk_state_t *st = nullptr;
   int16_t *iq = nullptr;
