@@ -154,7 +154,7 @@ def tracking_closed_loop(ms=1200):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     keep = ("channels", "host_workers", "p50_us", "p99_us", "max_us", "steps_over_1ms", "slowest_steady_steps_ms",
-            "warmup_max_us", "real_time", "behind_at_end_ms",
+            "warmup_max_us", "real_time", "behind_at_end_ms", "cpu_quota_throttled_ms_during_run",
             "tracking_state", "code_and_carrier_lock")
     rows, real_time = [], []
     for n in (256, 16384, 65536, 98304, 131072, 147456, 163840, 196608):
@@ -166,13 +166,18 @@ def tracking_closed_loop(ms=1200):
             break     # (far past the last real-time count: the rest of the ladder would only take time)
     best = max(real_time) if real_time else None
     below = [r["channels"] for r in rows if best and r["channels"] < best and not r["real_time"]]
+    by_p99 = [r["channels"] for r in rows if r["p99_us"] < 1000.0]
     return {"metric": "closed-loop real-time tracking channels: largest count whose steady-state steps ALL stay under 1 ms",
-            "value": best, "smaller_counts_that_missed_a_deadline": below, "ms_per_count": ms, "signals_in_stream": 32,
-            "paced_at_1ms": True, "ladder": rows,
+            "value": best, "smaller_counts_that_missed_a_deadline": below,
+            "largest_count_with_p99_under_1ms": max(by_p99) if by_p99 else None,
+            "ms_per_count": ms, "signals_in_stream": 32, "paced_at_1ms": True, "ladder": rows,
             "note": "ONE run per count, every count of the ladder reported; steady state = second half of each run; "
                     "warmup_max_us = worst step of the first half (pre-tracking job lists, graph instantiation, buffer "
-                    "growth) -- reported, not hidden: a receiver takes those on entry; a smaller count that missed a "
-                    "deadline on this box is listed beside the value"}
+                    "growth) -- reported, not hidden: a receiver takes those on entry.  `value` is strict: one step of "
+                    "the steady half at or over 1 ms disqualifies a count.  On a shared host that includes steps in which a "
+                    "thread of this process was preempted for milliseconds by other tenants (max_us of 4-30 ms next to "
+                    "a p99 far below 1 ms; cpu_quota_throttled_ms_during_run says whether the container's own CPU quota "
+                    "was the cause) -- largest_count_with_p99_under_1ms is the same ladder read without those"}
 
 
 def cpu_baseline(blocks, budget_s=20.0):

@@ -98,7 +98,10 @@ struct WorkerLists {   // what one worker's contiguous channel range contributes
   int cursor = 0, cursor_run = 0;
 };
 
-// A fixed set of threads that run `fn(worker)` for worker = 0..n-1 (the caller is worker 0) and meet again.  Sized once, from
+// A fixed set of threads that run `fn(job)` for job = 0..n-1 and meet again.  Every thread takes the job of its own number
+// first (the caller: 0) -- a job is a contiguous channel range, and a range's records then live in one core's caches from
+// millisecond to millisecond -- and then whatever job nobody has started: on a shared host a thread is now and then not
+// scheduled for milliseconds after its wake-up, and its range must not wait for it.  Sized once, from
 // the CPUs the creating thread may run on ($GPSX_STEP_THREADS overrides; at most 64), so a process that pinned itself next to
 // its GPU (gpsx_bind_thread_to_device) gets workers on those cores.  Between steps the workers spin briefly -- the next
 // millisecond is never far -- then sleep on the generation counter (a futex).
@@ -124,13 +127,13 @@ class StepPool {
     std::function<void(int)> f = std::ref(fn);
     job_.store(&f, std::memory_order_relaxed);
     active_.store(n_workers, std::memory_order_relaxed);
-    pending_.store(n_workers - 1, std::memory_order_relaxed);
-    generation_.fetch_add(1);
+    pending_.store(n_workers, std::memory_order_relaxed);
+    const unsigned gen = generation_.fetch_add(1) + 1;
     // one system call wakes every sleeper, and none of them takes a lock on its way out (a condition variable hands its mutex
     // from thread to thread: thirteen wake-ups in a row at the head of every phase of every millisecond)
     if (sleepers_.load() != 0)   // (sequentially consistent with the sleeper's own "count myself, look again")
       futex(FUTEX_WAKE_PRIVATE, INT_MAX);
-    fn(0);
+    take_jobs(f, 0, n_workers, gen);
     for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++)
       if (spin > 64)
         std::this_thread::yield();
@@ -186,6 +189,19 @@ class StepPool {
     for (std::thread &t : threads_)
       t.join();
   }
+  // job `own` if nobody has it yet, then every other job nobody has started (claimed[j] == gen: taken in this generation)
+  void take_jobs(std::function<void(int)> &f, int own, int n_jobs, unsigned gen)
+  {
+    for (int i = 0; i < n_jobs; i++) {
+      const int j = own + i < n_jobs ? own + i : own + i - n_jobs;
+      unsigned c = claimed_[j].load(std::memory_order_relaxed);
+      // (only forward: a thread that was held up with an older generation in hand must find nothing to take)
+      if ((int)(gen - c) <= 0 || !claimed_[j].compare_exchange_strong(c, gen, std::memory_order_acq_rel))
+        continue;
+      f(j);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
   long futex(int op, unsigned val)   // on the generation counter
   {
     static_assert(sizeof(std::atomic<unsigned>) == sizeof(unsigned), "futex word");
@@ -227,10 +243,9 @@ class StepPool {
       } while (generation_.load() != seen);
       if (quit_.load(std::memory_order_relaxed))
         return;
-      if (job && w < active) {
-        (*job)(w);
-        pending_.fetch_sub(1, std::memory_order_release);
-      }
+      // (a job is only entered through a claim of THIS generation, and none is left once the run that owns *job has returned)
+      if (job && w < active)
+        take_jobs(*job, w, active, seen);
     }
   }
   int n_ = 1;
@@ -239,6 +254,7 @@ class StepPool {
   std::atomic<int> pending_{0}, sleepers_{0}, active_{0};
   std::atomic<bool> hot_{false}, quit_{false};
   std::atomic<std::function<void(int)> *> job_{nullptr};
+  std::atomic<unsigned> claimed_[64] = {};
 };
 
 struct StepBuffers {

@@ -29,6 +29,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 _stream_cache = {}
 
 
+def _cpu_throttle():
+    """(periods throttled, microseconds throttled) of this container's CPU quota so far (cgroup v2 cpu.stat), or None"""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except Exception:
+        return None
+
+
 def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=True):
     import steps_driver as sd
     from stm32f4_sdr_gps_amd import capi, synth
@@ -63,6 +72,7 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
         delay = np.array(sig_delay)[np.arange(n) % n_sig]
         lat = np.zeros(ms)
         n_trk = np.zeros(ms, np.int64)
+        thr0 = _cpu_throttle()
         t_start = time.perf_counter()
         for t in range(ms):
             steps.set_time(t)
@@ -75,6 +85,7 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
             lib.gps_tracking_process_batch(table.ctypes.data, n, blk.ctypes.data, t & 3)
             lat[t] = time.perf_counter() - s
         behind = time.perf_counter() - t_start - ms * 1e-3
+        thr1 = _cpu_throttle()
         fine = table[:, 60 + 80:60 + 84].copy().view("<f4")[:, 0]
         freq = table[:, 60 + 4:60 + 8].copy().view("<f4")[:, 0]
         state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
@@ -87,6 +98,8 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
                           "launch, DLL / PLL / FLL + nav-bit logic per channel on the host)",
                 "channels": n, "signals_in_stream": n_sig, "ms": ms, "signal_amp": amp,
                 "paced_at_1ms": bool(paced), "behind_at_end_ms": float(max(0.0, behind) * 1e3),
+                "cpu_quota_throttled_ms_during_run": None if not (thr0 and thr1) else (thr1[1] - thr0[1]) / 1e3,
+                "cpu_quota_throttled_periods_during_run": None if not (thr0 and thr1) else thr1[0] - thr0[0],
                 "host_workers": int(lib.gps_tracking_batch_workers()) if n >= 2048 else 1,
                 "thread_on_gpu_numa_node": bool(bound),
                 "p50_us": float(np.percentile(steady, 50) * 1e6), "p99_us": float(np.percentile(steady, 99) * 1e6),
