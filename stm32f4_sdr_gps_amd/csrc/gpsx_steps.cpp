@@ -125,10 +125,13 @@ class StepPool {
     }
     start_threads();
     std::function<void(int)> f = std::ref(fn);
-    job_.store(&f, std::memory_order_relaxed);
-    active_.store(n_workers, std::memory_order_relaxed);
+    // (what a generation runs sits in the slot of its parity: a thread that looks late, while the NEXT run is being posted,
+    //  still reads its own generation's function and job count, or sees the counter move and looks again)
+    const unsigned gen = generation_.load(std::memory_order_relaxed) + 1;   // (only run() moves the counter)
+    slot_[gen & 1].job.store(&f, std::memory_order_relaxed);
+    slot_[gen & 1].active.store(n_workers, std::memory_order_relaxed);
     pending_.store(n_workers, std::memory_order_relaxed);
-    const unsigned gen = generation_.fetch_add(1) + 1;
+    generation_.fetch_add(1);
     // one system call wakes every sleeper, and none of them takes a lock on its way out (a condition variable hands its mutex
     // from thread to thread: thirteen wake-ups in a row at the head of every phase of every millisecond)
     if (sleepers_.load() != 0)   // (sequentially consistent with the sleeper's own "count myself, look again")
@@ -137,7 +140,7 @@ class StepPool {
     for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++)
       if (spin > 64)
         std::this_thread::yield();
-    job_.store(nullptr, std::memory_order_relaxed);
+    slot_[gen & 1].job.store(nullptr, std::memory_order_relaxed);
   }
 
  private:
@@ -238,8 +241,8 @@ class StepPool {
       int active;
       do {
         seen = generation_.load();
-        job = job_.load(std::memory_order_relaxed);
-        active = active_.load(std::memory_order_relaxed);
+        job = slot_[seen & 1].job.load(std::memory_order_relaxed);
+        active = slot_[seen & 1].active.load(std::memory_order_relaxed);
       } while (generation_.load() != seen);
       if (quit_.load(std::memory_order_relaxed))
         return;
@@ -251,9 +254,12 @@ class StepPool {
   int n_ = 1;
   std::vector<std::thread> threads_;
   std::atomic<unsigned> generation_{0};
-  std::atomic<int> pending_{0}, sleepers_{0}, active_{0};
+  std::atomic<int> pending_{0}, sleepers_{0};
   std::atomic<bool> hot_{false}, quit_{false};
-  std::atomic<std::function<void(int)> *> job_{nullptr};
+  struct Posted {
+    std::atomic<std::function<void(int)> *> job{nullptr};
+    std::atomic<int> active{0};
+  } slot_[2];
   std::atomic<unsigned> claimed_[64] = {};
 };
 
