@@ -265,6 +265,9 @@ def main():
     if args.n_ms is None:
         args.n_ms = 1 if args.gpus == 1 else 10
 
+    # (multi-process GPU work on this driver stack needs dmabuf IPC: RCCL's hipIpcGetMemHandle fails in legacy mode.  The
+    #  image exports it; kept here for an environment that was built without it.)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
