@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 constexpr u32 kRootBias = 0x4B000000u;
 template <int NT>
 __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0,
-                                                   const v16f (&acc)[2][NT], bool half_only = false)
+                                                   const v16f (&acc)[2][NT], bool half_only = false, bool half_atomics = false)
 {
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
@@ -1096,6 +1096,17 @@ __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const
     }
   }
   mx_round_to_nearest();
+#ifdef GPSX_MX_ABLATIONS
+  if (half_atomics) {   // (timing ablation 512: half the LDS atomics)
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;
+      atomicMax(slot + p_off, best[r] | best[r + 8]);
+      atomicAdd(slot + p_off + 32, total[r] + total[r + 8]);
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     const int p_off = ((r & 3) + 8 * (r >> 2)) * 64;   // PRN (r & 3) + 8 (r >> 2) + 4 h: 2 x 32 words per PRN
@@ -1206,7 +1217,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
 #endif
                                    // timing ablations: 1 = no epilogue, 2 = no MFMA (noise-sized counts instead), 4 = both roles in
                                    // step, 8 = no vector building, 16 = raised priority for the MFMA passes, 32 = no MFMA pass in
-                                   // role 1, 64 = no epilogue in role 0
+                                   // role 1, 64 = no epilogue in role 0, 128 = half an epilogue, 256 = no steps, 512 = half the atomics
   const int role = (ex & 4) ? 0 : wave >> 2;             // waves w and w + 4 share a SIMD: half a step apart
   const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
 
@@ -1419,7 +1430,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         }
       } else if (active && (x & 1) && p >= 1 && !(ex & 1) && !((ex & 64) && !role)) {
         if (!MULTI)
-          mx_epilogue_single(sh, lane, kq, t0s + p - 1, acc, (ex & 128) != 0);
+          mx_epilogue_single(sh, lane, kq, t0s + p - 1, acc, (ex & 128) != 0, (ex & 512) != 0);
         else if (!ms_last)
           mx_epilogue<MULTI, false, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, zero_recs, pre, ms_first, witness);
         else
