@@ -460,6 +460,9 @@ def main():
         assert torch.equal(d_keys_all.cpu(), torch.from_numpy(keys)), "sharded sweep + all-reduce != unsharded sweep"
         if rank == 0:
             print("VERIFY sharded == unsharded", flush=True)
+    if use_dist and rank == 0 and os.environ.get("GPSX_BENCH_DUMP_KEYS"):
+        # test hook: the merged key table as rank 0 holds it after the all-reduce, for tests/ to compare with the oracle
+        np.save(os.environ["GPSX_BENCH_DUMP_KEYS"], keys)
 
     # BASELINE.json configs[3] as written: ONE ten-block cold-start search, its 84 (PRN group, Doppler) units dealt to the
     # N ranks, one all-reduce(MAX) of 672 keys; latency per search (outside the headline's timed region)

@@ -14,13 +14,17 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("n_ms, searches, port, ms_mode, algo", [(10, 1, 29571, "blocks", ""), (1, 4, 29572, "", ""),
                                                                 (10, 4, 29573, "walk", "poly"), (10, 5, 29574, "", "")])
-def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode, algo):
+def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode, algo, tmp_path, oracle):
     """n_ms = 10 is what the driver's N > 1 runs execute (BASELINE.json configs[3]; bench.py's default there), in both
     forms: the polyphase kernel with a workgroup per (unit, block) (what a lone search takes), the polyphase kernel walking
     its blocks, and -- what the 256-searches-per-GPU runs take -- the matrix-core kernel walking them (default dispatch,
     5 searches per rank); n_ms = 1 is the coherent grid on the matrix cores.  GPSX_BENCH_VERIFY compares the merged key table with
-    an unsharded sweep of the same captures."""
-    env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1")
+    an unsharded sweep of the same captures; GPSX_BENCH_DUMP_KEYS hands the merged table to this test, which compares
+    searches of it with the CPU oracle (one per rank's half of the searches where the table is the ten-block walk's: the
+    first multi-GPU run is then also a parity run)."""
+    dump = str(tmp_path / "merged_keys.npy")
+    env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1",
+               GPSX_BENCH_DUMP_KEYS=dump)
     if ms_mode:
         env["GPSX_ACQ_MS_MODE"] = ms_mode
     if algo:
@@ -39,3 +43,15 @@ def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode,
     assert line["per_gpu_unsharded"]["value"] > 1e9   # one GPU's share at the same configuration, no sharding
     if n_ms > 1:
         assert line["single_search"]["ms_per_search"] > 0
+    # the merged table against the oracle: bench.py's own input (synth.cold_start_block, seed 11, amplitudes x 0.25), sign plane
+    import numpy as np
+    from stm32f4_sdr_gps_amd import synth
+    keys = np.load(dump)
+    assert keys.shape == (2 * searches, 32, 21)
+    blocks = synth.cold_start_block(2 * searches * n_ms, seed=11, amp_scale=0.25)
+    prns = np.arange(1, 33, dtype=np.uint8)
+    threads = max(4, min(32, len(os.sched_getaffinity(0))))
+    for s_ in ((1, 2 * searches - 2) if (n_ms, algo) == (10, "") else (2 * searches - 1,)):
+        want = oracle.acq_grid(blocks[s_ * n_ms:(s_ + 1) * n_ms], n_ms, prns, -5000, 500, 21, 8, n_threads=threads)
+        fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+        assert np.array_equal(keys[s_], ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)), s_
