@@ -156,25 +156,37 @@ def tracking_closed_loop(ms=1200):
     keep = ("channels", "host_workers", "p50_us", "p99_us", "max_us", "steps_over_1ms", "slowest_steady_steps_ms",
             "warmup_max_us", "real_time", "behind_at_end_ms", "cpu_quota_throttled_ms_during_run",
             "tracking_state", "code_and_carrier_lock")
-    rows, real_time = [], []
+    # configs[4] to the letter first: 256 channels on 256 distinct signals, 10 000 ms, paced
+    literal = mod.closed_loop(256, 10000, 0.12, 0, literal=True)
+    config5 = {k: literal[k] for k in keep + ("signals_in_stream", "ms", "paced_at_1ms",
+                                              "code_and_carrier_lock_in_the_reference_on_this_stream", "not_locked")}
+    rows, best, missed_below = [], None, False
     for n in (256, 16384, 65536, 98304, 131072, 147456, 163840, 196608):
         r = mod.closed_loop(n, ms, 0.12, 32)
         rows.append({k: r[k] for k in keep})
-        if r["real_time"]:
-            real_time.append(n)
-        elif n > 131072 and n > 2 * (max(real_time) if real_time else 0):
-            break     # (far past the last real-time count: the rest of the ladder would only take time)
-    best = max(real_time) if real_time else None
-    below = [r["channels"] for r in rows if best and r["channels"] < best and not r["real_time"]]
+        if r["real_time"] and not missed_below:
+            best = n              # the largest count with no miss AT OR BELOW it
+        if not r["real_time"]:
+            missed_below = True
+            if n > 131072:
+                break             # (past the first miss nothing can raise `value`; two more counts are kept for the p99 reading)
+    isolated = [r["channels"] for r in rows if r["real_time"] and best is not None and r["channels"] > best]
     by_p99 = [r["channels"] for r in rows if r["p99_us"] < 1000.0]
-    return {"metric": "closed-loop real-time tracking channels: largest count whose steady-state steps ALL stay under 1 ms",
-            "value": best, "smaller_counts_that_missed_a_deadline": below,
+    return {"metric": "closed-loop real-time tracking channels: largest count of the ladder with NO steady-state step at or over "
+                      "1 ms at that count or at any smaller one",
+            "value": best, "larger_counts_that_met_every_deadline_after_a_smaller_one_missed": isolated,
             "largest_count_with_p99_under_1ms": max(by_p99) if by_p99 else None,
+            "config5": config5,
+            "one_signal_in_32_never_locks": "PRN 1 at delay 0 is handed over with found_code_phase 0; the reference's pre-tracking "
+                                            "accepts a settled phase only if it is non-zero (tracking.c gps_pre_track_process, "
+                                            "`if (max_phase_value)`), so that channel stays in GPS_PRE_TRACK_RUN for ever -- in the "
+                                            "reference too (tests/golden/f7_steps_config5_64ch.npz channels 0 and 32): "
+                                            "tracking_state = 31/32 of every count of the ladder below",
             "ms_per_count": ms, "signals_in_stream": 32, "paced_at_1ms": True, "ladder": rows,
             "note": "ONE run per count, every count of the ladder reported; steady state = second half of each run; "
                     "warmup_max_us = worst step of the first half (pre-tracking job lists, graph instantiation, buffer "
-                    "growth) -- reported, not hidden: a receiver takes those on entry.  `value` is strict: one step of "
-                    "the steady half at or over 1 ms disqualifies a count.  On a shared host that includes steps in which a "
+                    "growth) -- reported, not hidden: a receiver takes those on entry.  `value` is strict and monotone: one "
+                    "step of the steady half at or over 1 ms disqualifies that count AND every larger one.  On a shared host that includes steps in which a "
                     "thread of this process was preempted for milliseconds by other tenants (max_us of 4-30 ms next to "
                     "a p99 far below 1 ms; cpu_quota_throttled_ms_during_run says whether the container's own CPU quota "
                     "was the cause) -- largest_count_with_p99_under_1ms is the same ladder read without those"}

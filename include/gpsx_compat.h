@@ -33,6 +33,7 @@ extern "C" {
 #define ACQ_PHASE1_HIST_SIZE       32
 #define PRE_TRACK_POINTS_MAX_CNT   30
 #define TRACKING_CH_LENGTH         4
+#define PRN_SPEED_HZ               1000   /* code periods per second (PM/config.h:25) */
 #define GPS_SAT_CNT                4
 #define GPS_DATA_WORDS_CNT         (PRN_SPI_WORDS_CNT + 1)   /* PM/GPS/common_ram.h:10 */
 #define IF_NCO_STEP_HZ             (0.003810972f)            /* PM/config.h:50 */
@@ -209,15 +210,33 @@ void      gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index);
 /* --- channel sequencing (PM/GPS/gps_master.h:7-14; gps_master.c:68-129,458-510) ------------------------------------- */
 /* Starts acquisition channel by channel, opens the code-phase searches together, hands finished channels to tracking
  * (GPS_NEED_PRE_TRACK).  Call it after every acquisition_process / gps_tracking_process, as PM/main.c:157,167 does.
- * The reference's navigation / pseudorange / PVT / UI duties are not reproduced: gps_master_nav_handling is a weak
- * no-op hook (called in the idle slot, index 0xFF), key_up_presed a weak variable a host may set. */
+ * In the idle slot (index 0xFF) it calls gps_master_nav_handling, the pseudorange step below (weak: a host may bring its
+ * own); the reference's UI duties are not reproduced, key_up_presed is a weak variable a host may set. */
 void    gps_master_handling(gps_ch_t *channels /* [GPS_SAT_CNT] */, uint8_t index);
 uint8_t gps_master_need_acq(void);
 uint8_t gps_master_need_freq_search(gps_ch_t *channels);
 uint8_t gps_master_is_code_search3(gps_ch_t *channels);
 void    gps_master_reset_to_aqc_start(gps_ch_t *channels);
-void    gps_master_nav_handling(gps_ch_t *channels);
 extern uint8_t key_up_presed;
+
+/* --- the pseudorange step (PM/GPS/gps_master.c:159-430; csrc/gpsx_nav_master.cpp) -- PARITY UNPINNED -------------------
+ * gps_master.c cannot be compiled in place (its include chain ends at CMSIS' core_cm4.h, which the reference tree does
+ * not ship), so these follow the source text and are tested end to end on physics (tests/test_gpu_pvt_chain.py), not
+ * against the reference's object code.
+ * gps_master_nav_handling: subframe epochs of the four channels -> reference satellite (earliest stamp, declared
+ * 68.802 ms away) -> obs_data.pseudorange_m / obs_data.tow_s of every channel from the stamps' differences and the
+ * code phases averaged over the filter window (code_phase_fine_filt, accumulated by the DLL), code-phase wraps
+ * compensated; then gps_master_calculate_pos: twice a second, once every channel holds subframes 1-3,
+ * sdrobs2obsd + gps_pos_solve (call gps_pos_solve_init(channels) once before). */
+void     gps_master_nav_handling(gps_ch_t *channels /* [GPS_SAT_CNT] */);
+void     gps_master_final_pseudorange_calc(gps_ch_t *channels, uint32_t curr_tick_time, uint32_t ref_time_diff_ms,
+                                           uint32_t ref_time_ms, uint8_t ref_idx);
+uint16_t gps_master_filter_code_phase(gps_ch_t *channels, uint32_t curr_tick_time);
+void     gps_master_code_phase_filter_reset(gps_ch_t *channels, uint32_t curr_tick_time);
+void     gps_master_calculate_pos(gps_ch_t *channels);
+/* not in the reference: the same step (without the position call) for a table of n_ch channels.  1 = pseudoranges and
+ * reception times renewed, 0 = filter window not ready, -1 = subframe epochs not there yet. */
+int      gpsx_nav_pseudoranges(gps_ch_t *channels, int n_ch, uint32_t now_ms);
 
 /* NOT in the reference: one tracking step of n_ch channels on the same millisecond, each channel served every
  * millisecond as in the single-satellite firmware's schedule (project_single_sat/main.c:96-109; index cycles 0..3).
@@ -305,6 +324,7 @@ uint8_t solving_is_busy(void);
 void    sdrobs2obsd(gps_ch_t *channels, int ns, obsd_t *out);
 extern sol_t  gps_sol;
 extern double final_pos[3];
+extern obsd_t obsd[GPS_SAT_CNT];         /* the observation records gps_master_calculate_pos hands to the solver (gps_master.c:42) */
 /* azimuth / elevation (deg) of the four satellites of the last solution (the reference's global `azel`) */
 const double *gpsx_pvt_azel(void);
 

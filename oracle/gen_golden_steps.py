@@ -139,3 +139,101 @@ def gen_ephemeris():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ephemeris":
     gen_ephemeris()
+
+
+
+def gen_config5():
+    """Golden for the batched step beyond four channels: 64 channels (tests/steps_driver.py config5_64ch_scenario), the
+    reference's gps_tracking_process on one private library instance per channel (file-static slot buffers), all of them
+    called millisecond by millisecond in channel order, so that the one thing they share -- libc's rand(), drawn by the
+    false-lock reseed -- is drawn in the order a single-threaded loop over the channels draws it.  1500 ms; kept: a CRC of
+    every channel's 226 state bytes per millisecond, full snapshots every 100 ms and at the end, and which channels
+    reseeded when (a jump of if_freq_offset_hz by more than 150 Hz between two milliseconds)."""
+    import shutil
+    import tempfile
+    pyoracle.build_ref()
+    n_ms = sd.CONFIG5_MS
+    sats, chans, seed = sd.config5_64ch_scenario()
+    stream = synth.make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+    n = len(chans)
+    crcs = np.zeros((n_ms, n), np.uint32)
+    checkpoints = np.zeros((n_ms // 100, n, sd.SNAP), np.uint8)
+    reseed_ms = []
+    src = os.path.join(ROOT, "oracle", "_ref", "libref_steps.so")
+    with tempfile.TemporaryDirectory() as td:
+        insts = []
+        table = np.zeros((n, sd.CH_SIZE), np.uint8)
+        for c in range(n):
+            path = os.path.join(td, f"ref_copy_{c}.so")
+            shutil.copy(src, path)
+            insts.append(sd.StepsLib(C.CDLL(path), True))
+            table[c] = sd.preset_channel(insts[c], *chans[c])
+        C.CDLL("libc.so.6").srand(1)
+        prev = np.zeros(n, np.float32)
+        for t in range(n_ms):
+            blk = np.ascontiguousarray(stream[t])
+            for c in range(n):
+                insts[c].set_time(t)
+                insts[c].lib.gps_tracking_process(table[c].ctypes.data, blk.ctypes.data, t & 3)
+            freq = table[:, 64:68].copy().view("<f4")[:, 0]
+            for c in np.flatnonzero((np.abs(freq - prev) > 150) & (t > 0)):
+                reseed_ms.append((t, int(c)))
+            prev = freq
+            crcs[t] = sd.snapshot_crcs(table)
+            if (t + 1) % 100 == 0:
+                checkpoints[(t + 1) // 100 - 1] = sd.snapshot(table)
+        final = sd.snapshot(table)
+    path = os.path.join(ROOT, "tests", "golden", "f7_steps_config5_64ch.npz")
+    np.savez_compressed(path, crcs=crcs, checkpoints=checkpoints, final=final, chans=np.array(chans, np.int32),
+                        reseeds=np.array(reseed_ms, np.int32), n_ms=np.int32(n_ms),
+                        stream_fnv=np.uint32(fnv1a32(stream[::97])))
+    state = final[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+    print("config5", os.path.getsize(path), "bytes;", len(reseed_ms), "reseeds on", len({c for _, c in reseed_ms}),
+          "channels; tracking:", int((state == sd.TRK_RUN).sum()), "of", n, "; not tracking:", np.flatnonzero(state != sd.TRK_RUN))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "config5":
+    gen_config5()
+
+
+
+def gen_config5_literal():
+    """SURVEY.md 8(d) config 5 to the letter through the reference: 256 channels on 256 signals, 10 000 ms, one private
+    instance of the reference's step sources per channel, channel order within each millisecond (rand() as in
+    gen_config5).  Kept: a CRC of every channel's state every 100 ms, the final snapshots, the reference's lock mask."""
+    import shutil
+    import tempfile
+    pyoracle.build_ref()
+    n_ms = sd.CONFIG5_LITERAL_MS
+    stream, chans, dopp, delay = sd.config5_literal_scenario(n_ms)
+    n = len(chans)
+    crcs = np.zeros((n_ms // 100, n), np.uint32)
+    src = os.path.join(ROOT, "oracle", "_ref", "libref_steps.so")
+    with tempfile.TemporaryDirectory() as td:
+        insts = []
+        table = np.zeros((n, sd.CH_SIZE), np.uint8)
+        for c in range(n):
+            path = os.path.join(td, f"ref_copy_{c}.so")
+            shutil.copy(src, path)
+            insts.append(sd.StepsLib(C.CDLL(path), True))
+            table[c] = sd.preset_channel(insts[c], *chans[c])
+        C.CDLL("libc.so.6").srand(1)
+        for t in range(n_ms):
+            blk = stream[t]
+            for c in range(n):
+                insts[c].set_time(t)
+                insts[c].lib.gps_tracking_process(table[c].ctypes.data, blk.ctypes.data, t & 3)
+            if (t + 1) % 100 == 0:
+                crcs[(t + 1) // 100 - 1] = sd.snapshot_crcs(table)
+        final = sd.snapshot(table)
+        locked = sd.lock_mask(table, dopp, delay)
+    path = os.path.join(ROOT, "tests", "golden", "f7_steps_config5_256ch.npz")
+    np.savez_compressed(path, crcs=crcs, final=final, locked=locked, chans=np.array(chans, np.int32), n_ms=np.int32(n_ms),
+                        stream_fnv=np.uint32(fnv1a32(stream[::97])))
+    state = final[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+    print("config5 literal", os.path.getsize(path), "bytes; tracking", int((state == sd.TRK_RUN).sum()), "locked", int(locked.sum()),
+          "of", n, "; not locked:", np.flatnonzero(~locked).tolist())
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "config5_literal":
+    gen_config5_literal()

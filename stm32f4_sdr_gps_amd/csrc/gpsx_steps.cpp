@@ -18,6 +18,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <climits>
+#include <dlfcn.h>
 #include <thread>
 #include <vector>
 
@@ -66,8 +67,39 @@ struct SlotState {
 };
 SlotState g_shared_slot;
 
+// The millisecond tick as the tracking-side logic reads it.  Inside gps_tracking_process_batch the host's time source
+// (signal_capture_get_packet_cnt, a weak hook the host may override with anything -- a ctypes callback, a non-atomic
+// counter) is read ONCE, on the calling thread, and every channel of the step sees that value: worker threads never call
+// into the host.  Outside a batched step it is the hook itself, call by call, as the reference reads it.
+std::atomic<bool> g_batch_tick_valid{false};
+uint32_t g_batch_tick = 0;
+inline uint32_t tick()
+{
+  return g_batch_tick_valid.load(std::memory_order_acquire) ? g_batch_tick : signal_capture_get_packet_cnt();
+}
+struct BatchTick {
+  explicit BatchTick(uint32_t now)
+  {
+    g_batch_tick = now;
+    g_batch_tick_valid.store(true, std::memory_order_release);
+  }
+  ~BatchTick() { g_batch_tick_valid.store(false, std::memory_order_release); }
+};
+
+// true when `fn` (the address of one of this library's weak hooks, taken through the GOT) resolves outside this library:
+// the host overrode it
+bool resolves_outside_this_library(const void *fn)
+{
+  static const int anchor = 0;
+  Dl_info theirs, ours;
+  if (!dladdr(fn, &theirs) || !dladdr(&anchor, &ours))
+    return false;
+  return theirs.dli_fbase != ours.dli_fbase;
+}
+
 // ---- the batched step's host workers (gps_tracking_process_batch) ---------------------------------------------------------
 constexpr int kStepThreadsFrom = 2048;    // channels from which the per-channel host loops are spread over worker threads
+                                          // ($GPSX_STEP_THREADS_FROM lowers it: tests put the 64-channel reference trace on workers)
 constexpr int kStepOverlapFrom = 65536;   // tracked channels from which those loops overlap the correlators, piece by piece
 
 // the cache lines of a channel record the batched step touches: tracking_data (offset 60, 152 bytes) and, after the
@@ -96,6 +128,8 @@ struct WorkerLists {   // what one worker's contiguous channel range contributes
   static constexpr int kMaxRuns = 16;
   int run_start[kMaxRuns + 1] = {0}, run_base[kMaxRuns] = {0};
   int cursor = 0, cursor_run = 0;
+  // channels of this worker's range that stopped in front of a false-lock reseed (channel, entry of the step's arrays)
+  std::vector<std::pair<int, size_t>> deferred;
 };
 
 // A fixed set of threads that run `fn(job)` for job = 0..n-1 and meet again.  Every thread takes the job of its own number
@@ -128,8 +162,8 @@ class StepPool {
     // (what a generation runs sits in the slot of its parity: a thread that looks late, while the NEXT run is being posted,
     //  still reads its own generation's function and job count, or sees the counter move and looks again)
     const unsigned gen = generation_.load(std::memory_order_relaxed) + 1;   // (only run() moves the counter)
-    slot_[gen & 1].job.store(&f, std::memory_order_relaxed);
-    slot_[gen & 1].active.store(n_workers, std::memory_order_relaxed);
+    slot_[gen & 1].job.store(&f, std::memory_order_release);
+    slot_[gen & 1].active.store(n_workers, std::memory_order_release);
     pending_.store(n_workers, std::memory_order_relaxed);
     generation_.fetch_add(1);
     // one system call wakes every sleeper, and none of them takes a lock on its way out (a condition variable hands its mutex
@@ -227,7 +261,7 @@ class StepPool {
       static const int kSpin = [] { const char *e = std::getenv("GPSX_STEP_SPIN"); return e ? std::atoi(e) : 200; }();
       for (int spin = 0; generation_.load(std::memory_order_acquire) == seen; spin++) {
         if (spin < kSpin || hot_.load(std::memory_order_relaxed)) {
-          __builtin_ia32_pause();
+          __builtin_ia32_pause();   // (the pool is x86-64 host code: the GPU boxes are EPYC)
           continue;
         }
         sleepers_.fetch_add(1);
@@ -241,8 +275,10 @@ class StepPool {
       int active;
       do {
         seen = generation_.load();
-        job = slot_[seen & 1].job.load(std::memory_order_relaxed);
-        active = slot_[seen & 1].active.load(std::memory_order_relaxed);
+        // (acquire loads between two sequentially consistent loads of the counter: the re-check below cannot be satisfied
+        //  by a counter value older than the slot contents just read -- the C++ memory model's guarantee, not only x86's)
+        job = slot_[seen & 1].job.load(std::memory_order_acquire);
+        active = slot_[seen & 1].active.load(std::memory_order_acquire);
       } while (generation_.load() != seen);
       if (quit_.load(std::memory_order_relaxed))
         return;
@@ -501,14 +537,20 @@ void pll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP)
   t.pll_code_err = phase_err;
 }
 
-void false_lock_check(gps_ch_t &ch, uint8_t index, int16_t ip)
+// The PLL's stability check in two parts (tracking.c:261-327).  false_lock_detect is the bookkeeping: it returns true when
+// the channel has been flipping signs for long enough that its carrier must jump to a random offset (counters already
+// cleared, as the reference clears them before it draws); false_lock_reseed is that jump -- the ONE place of the tracking
+// path that touches process-global state (libc's rand()).  The batched step's worker threads only detect; the jumps, and
+// the rest of such a channel's millisecond, are done afterwards on the calling thread in channel order, so the draws come
+// out of rand() in the order the single-threaded step (and the reference's own loop over its channels) makes them.
+bool false_lock_detect(gps_ch_t &ch, uint8_t index, int16_t ip)
 {
   gps_tracking_t &t = ch.tracking_data;
   if (index >= TRACKING_CH_LENGTH)
-    return;
+    return false;
   t.pll_check_buf[index] = ip;
   if (index < TRACKING_CH_LENGTH - 1)
-    return;
+    return false;
   uint8_t flips = 0;
   uint8_t prev = t.pll_check_buf[0] > 0 ? 1 : 0;
   for (uint8_t i = 1; i < TRACKING_CH_LENGTH; i++) {
@@ -529,24 +571,30 @@ void false_lock_check(gps_ch_t &ch, uint8_t index, int16_t ip)
   else if (t.pll_bad_state_cnt == 0)
     t.pll_bad_state_master_cnt = 0;
 
-  if (t.pll_bad_state_master_cnt > kPllBadThreshold) {
-    // false lock: jump to a random carrier offset around the acquired one (tracking.c:309-326)
-    t.pll_bad_state_master_cnt = 0;
-    t.pll_bad_state_cnt = 0;
-    int16_t delta = 0, candidate;
-    do {
-      const uint16_t r = (uint16_t)(std::rand() % ACQ_SEARCH_STEP_HZ);
-      candidate = (int16_t)(ch.acq_data.found_freq_offset_hz - r + (ACQ_SEARCH_STEP_HZ / 2));
-      delta = (int16_t)((int16_t)t.if_freq_offset_hz - candidate);
-    } while (std::abs((int)delta) < 200);
-    t.if_freq_offset_hz = (float)candidate;
-  }
+  if (t.pll_bad_state_master_cnt <= kPllBadThreshold)
+    return false;
+  t.pll_bad_state_master_cnt = 0;
+  t.pll_bad_state_cnt = 0;
+  return true;
 }
 
+void false_lock_reseed(gps_ch_t &ch)
+{
+  // false lock: jump to a random carrier offset around the acquired one (tracking.c:309-326)
+  gps_tracking_t &t = ch.tracking_data;
+  int16_t delta = 0, candidate;
+  do {
+    const uint16_t r = (uint16_t)(std::rand() % ACQ_SEARCH_STEP_HZ);
+    candidate = (int16_t)(ch.acq_data.found_freq_offset_hz - r + (ACQ_SEARCH_STEP_HZ / 2));
+    delta = (int16_t)((int16_t)t.if_freq_offset_hz - candidate);
+  } while (std::abs((int)delta) < 200);
+  t.if_freq_offset_hz = (float)candidate;
+}
+
+// the frequency-locked loop proper: what gps_tracking_fll does after its call of gps_tracking_pll_check (tracking.c:208-256)
 void fll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP, SlotState *slot)
 {
   gps_tracking_t &t = ch.tracking_data;
-  false_lock_check(ch, index, IP);
   if (index == 0) {   // first ms after a channel swap: only remember
     t.fll_old_i = IP;
     t.fll_old_q = QP;
@@ -683,7 +731,7 @@ void nav_bit_sync(gps_ch_t *channel, uint8_t index, int16_t new_i, SlotState &sl
 uint8_t tracking_skipped_ms(gps_ch_t &ch)
 {
   gps_tracking_t &t = ch.tracking_data;
-  const uint32_t now = signal_capture_get_packet_cnt();
+  const uint32_t now = tick();
   uint32_t elapsed = now - t.prev_track_timestamp;
   t.prev_track_timestamp = now;
   if (elapsed > 50)
@@ -693,12 +741,11 @@ uint8_t tracking_skipped_ms(gps_ch_t &ch)
 
 // Everything after the correlators: DLL / PLL / FLL, nav-bit hook, SNR.  slot == nullptr: call the overridable
 // gps_nav_data_analyse_new_code (reference linkage); otherwise the built-in bit synchroniser on the given slot state.
-void tracking_apply(gps_ch_t &ch, uint8_t index, const int16_t iq[6], SlotState *slot)
+// tracking_tail is the part behind the false-lock check.
+void tracking_tail(gps_ch_t &ch, uint8_t index, const int16_t iq[6], SlotState *slot)
 {
   gps_tracking_t &t = ch.tracking_data;
-  const int16_t IE = iq[0], QE = iq[1], IP = iq[2], QP = iq[3], IL = iq[4], QL = iq[5];
-  dll_update(ch, IE, QE, IL, QL);
-  pll_update(ch, index, IP, QP);
+  const int16_t IP = iq[2], QP = iq[3];
   fll_update(ch, index, IP, QP, slot);
   if (slot)
     nav_bit_sync(&ch, index, IP, *slot);
@@ -719,6 +766,22 @@ void tracking_apply(gps_ch_t &ch, uint8_t index, const int16_t iq[6], SlotState 
     t.i_part_summ = 0;
     t.q_part_summ = 0;
   }
+}
+
+// Returns true when the channel stopped in front of a false-lock reseed it may not draw itself (defer_reseed: a worker
+// thread of the batched step): the caller owes it false_lock_reseed + tracking_tail, in channel order.
+bool tracking_apply(gps_ch_t &ch, uint8_t index, const int16_t iq[6], SlotState *slot, bool defer_reseed = false)
+{
+  const int16_t IE = iq[0], QE = iq[1], IP = iq[2], QP = iq[3], IL = iq[4], QL = iq[5];
+  dll_update(ch, IE, QE, IL, QL);
+  pll_update(ch, index, IP, QP);
+  if (false_lock_detect(ch, index, IP)) {
+    if (defer_reseed)
+      return true;
+    false_lock_reseed(ch);
+  }
+  tracking_tail(ch, index, iq, slot);
+  return false;
 }
 
 // ---- tracking step (tracking.c:92-170) ------------------------------------------------------------------------------
@@ -922,7 +985,7 @@ void stamp_subframe(gps_nav_data_t &n)
 {
   if (n.accurate_swap_ok == 0)
     return;
-  const uint32_t now = signal_capture_get_packet_cnt();
+  const uint32_t now = tick();
   uint32_t edge = now / 20 * 20 + n.accurate_swap_time;
   if ((int32_t)(now - edge) < 0)
     edge -= 20;
@@ -952,8 +1015,8 @@ __attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *channel, uint8
         n.inv_polarity_flag = 1;
     }
     if (n.polarity_found) {
-      if (signal_capture_get_packet_cnt() - n.word_detection_timestamp > kBadPolarityTimeoutMs) {
-        n.word_detection_timestamp = signal_capture_get_packet_cnt();
+      if (tick() - n.word_detection_timestamp > kBadPolarityTimeoutMs) {
+        n.word_detection_timestamp = tick();
         n.polarity_found = 0;
         n.inv_polarity_flag = 0;
       }
@@ -973,7 +1036,7 @@ __attribute__((weak)) void gps_nav_data_words_detection(gps_ch_t *channel, uint8
   store_word(n);
   n.word_cnt++;
   n.word_bit_cnt = 0;
-  n.word_detection_timestamp = signal_capture_get_packet_cnt();
+  n.word_detection_timestamp = tick();
   n.polarity_found = 1;
   if (n.word_cnt == 10) {
     (void)gps_nav_data_decode_subframe(channel);
@@ -1061,7 +1124,7 @@ void nav_bit_sync(gps_ch_t *channel, uint8_t index, int16_t new_i, SlotState &sl
     bit ^= 1;
   slot.bits[index] = bit;
   slot.ip[index] = new_i;
-  const uint32_t now = signal_capture_get_packet_cnt();
+  const uint32_t now = tick();
   if (index == 0)
     slot.start_ticks = now;
   if (n.period_sync_ok_flag == 1)
@@ -1215,15 +1278,14 @@ void acquisition_process(gps_ch_t *channel, uint8_t *data)
 
 // ---- gps_master.h: channel sequencing (PM/GPS/gps_master.c:68-129, 458-510) -------------------------------------------------
 // The part of the reference's "GPS master" that drives the step calls above: start acquisition channel by channel,
-// open the code-phase searches together, hand finished channels to tracking.  Its navigation / pseudorange / PVT /
-// UI duties are out of scope: gps_master_nav_handling is a weak no-op hook, key_up_presed a weak variable.
+// open the code-phase searches together, hand finished channels to tracking.  Its pseudorange / PVT duty
+// (gps_master_nav_handling) is gpsx_nav_master.cpp; the UI is out of scope, key_up_presed a weak variable.
 namespace {
 uint8_t g_need_acq = 1;     // gps_common_need_acq
 uint8_t g_start_flag = 1;   // gps_start_flag
 }  // namespace
 
 __attribute__((weak)) uint8_t key_up_presed = 0;
-__attribute__((weak)) void gps_master_nav_handling(gps_ch_t *) {}
 
 uint8_t gps_master_need_acq(void) { return g_need_acq; }
 
@@ -1348,16 +1410,24 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
   // independent per channel (each owns its gps_ch_t and its slot state): from kStepThreadsFrom channels on it is spread over
   // the calling thread's CPUs (after gpsx_bind_thread_to_device: the cores next to the GPU), contiguous channel ranges per
   // worker.  Below that -- the reference's four channels, the golden traces -- everything runs on the calling thread in
-  // channel order, as before.  (The one shared state on this path is rand() in the PLL's false-lock reseed,
-  // tracking.c:309-326: with several workers the channels draw from it in no fixed order.)
+  // channel order, as before.  Shared state this path can reach: rand() in the PLL's false-lock reseed (tracking.c:309-326)
+  // -- never drawn on a worker: false_lock_detect / finish_deferred below -- and the host's weak hooks (kForeignHooks).
   StepPool &pool = StepPool::instance();
-  const int n_workers = n_ch >= kStepThreadsFrom ? pool.size() : 1;
+  static const int kThreadsFrom = [] { const char *e = std::getenv("GPSX_STEP_THREADS_FROM"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : kStepThreadsFrom; }();
+  // A host that overrides one of the weak hooks this path reaches (its own tick source, the reference's nav_data.c with its
+  // function-static scratch, a ctypes callback) gets every call from the thread that called the step, as the
+  // reference's single-threaded loop makes them: no workers then.
+  static const bool kForeignHooks = resolves_outside_this_library((const void *)&signal_capture_get_packet_cnt) ||
+                                    resolves_outside_this_library((const void *)&gps_nav_data_words_detection) ||
+                                    resolves_outside_this_library((const void *)&gps_nav_data_decode_subframe);
+  const int n_workers = (n_ch >= kThreadsFrom && !kForeignHooks) ? pool.size() : 1;
   static const int kAhead = [] { const char *e = std::getenv("GPSX_STEP_PREFETCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2; }();
   static std::vector<WorkerLists> lists;
   if ((int)lists.size() < n_workers)
     lists.resize(n_workers);
-  const uint32_t now = signal_capture_get_packet_cnt();   // (one read for all workers: the hook is the caller's)
-  (void)now;
+  const BatchTick one_tick(signal_capture_get_packet_cnt());   // ONE read, here, for every channel and worker of the step: tick()
+  for (int w = 0; w < n_workers; w++)
+    lists[w].deferred.clear();
 
   // pass 1: state transitions that precede the correlators, and the work lists (per worker, in channel order)
   auto pass1 = [&](int w) {
@@ -1480,7 +1550,7 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
     }
   }
   // pass 3: per-channel serial logic, in channel order within a worker
-  auto loops = [&](const WorkerLists &L, int c, int hi, size_t k) {
+  auto loops = [&](WorkerLists &L, int c, int hi, size_t k) {
     gps_ch_t &ch = channel[c];
     gps_tracking_t &t = ch.tracking_data;
     if (c + kAhead < hi)
@@ -1492,17 +1562,30 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
       // part of this launch); the reference's single-channel call does the same one call later
     } else if (trk_of[c] >= 0) {
       t.if_freq_accum = st_all[k].if_freq_accum;
-      tracking_apply(ch, index, &iq_all[k * 6], &slots[c]);
+      if (tracking_apply(ch, index, &iq_all[k * 6], &slots[c], n_workers > 1))
+        L.deferred.emplace_back(c, k);
     }
+  };
+  // The reseeds the workers left undone, in channel order (a worker's range is contiguous, it walks it upwards, and the
+  // ranges follow each other), each followed by the rest of that channel's millisecond: rand() is drawn exactly as the
+  // single-threaded step draws it.
+  auto finish_deferred = [&]() {
+    for (int w = 0; w < n_workers; w++)
+      for (const auto &d : lists[w].deferred) {
+        gps_ch_t &ch = channel[d.first];
+        false_lock_reseed(ch);
+        tracking_tail(ch, index, &iq_all[d.second * 6], &slots[d.first]);
+      }
   };
   if (!overlapped) {
     auto pass3 = [&](int w) {
-      const WorkerLists &L = lists[w];
+      WorkerLists &L = lists[w];
       const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
       for (int c = lo; c < hi; c++)
         loops(L, c, hi, (size_t)L.st_base + (trk_of[c] >= 0 ? trk_of[c] : 0));
     };
     pool.run(n_workers, pass3);
+    finish_deferred();
     return;
   }
   // overlapped: when entries [0, ready) of the step's arrays are back, every worker moves its cursor over the channels whose
@@ -1546,6 +1629,7 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
   pool.keep_hot(false);
   if (rc != GPSX_OK)
     gpsx_compat_die("gps_tracking_process_batch", rc);
+  finish_deferred();
 }
 
 }  // extern "C"

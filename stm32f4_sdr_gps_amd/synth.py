@@ -100,6 +100,43 @@ def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, s
     return out
 
 
+def make_if_static(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, batch_ms: int = 250) -> np.ndarray:
+    """make_if for MANY satellites over MANY milliseconds (BASELINE.json configs[4] as SURVEY.md 8(d) words it: 256 signals,
+    10 000 ms), for satellites without navigation data.  One millisecond is exactly 1023 chips and 4092 IF cycles, so a
+    satellite's samples of millisecond m are those of millisecond 0 with the carrier turned by alpha = 2 pi fd m / 1000:
+
+        c(n) cos(theta(n) + alpha) = [c(n) cos theta(n)] cos alpha - [c(n) sin theta(n)] sin alpha
+
+    and the whole stream is one matrix product [n_ms, 2 S] x [2 S, 16368] plus noise.  Both factors and the noise are rounded
+    to integers (2^-15, 2^-15 and 2^-30 units) first: every product and partial sum is then an integer below 2^53, the float64
+    product is exact in ANY summation order, and the sign bits do not depend on the BLAS, its threading or the machine.
+    (Not sample-identical to make_if, which accumulates unrounded doubles: a different, equally valid stream.)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = np.arange(SAMPLES_PER_MS, dtype=np.float64)
+    basis = np.zeros((2 * len(sats), SAMPLES_PER_MS))
+    for k, s in enumerate(sats):
+        if s.nav_bits is not None:
+            raise ValueError("make_if_static: satellites without navigation data only")
+        code = 1.0 - 2.0 * ca_code(s.prn).astype(np.float64)
+        chip = np.floor((n - s.delay_samples) / 16.0).astype(np.int64) % CHIPS
+        theta = 2.0 * np.pi * ((IF_HZ + s.doppler_hz) / FS_HZ) * n + s.phase_rad
+        basis[2 * k] = np.rint(s.amp * code[chip] * np.cos(theta) * 32768.0)
+        basis[2 * k + 1] = np.rint(s.amp * code[chip] * np.sin(theta) * 32768.0)
+    fd = np.array([s.doppler_hz for s in sats])
+    out = np.zeros((n_ms, BYTES_PER_MS), np.uint8)
+    for m0 in range(0, n_ms, batch_ms):
+        m = np.arange(m0, min(n_ms, m0 + batch_ms), dtype=np.float64)
+        alpha = 2.0 * np.pi * np.outer(m, fd) / 1000.0
+        turn = np.empty((len(m), 2 * len(sats)))
+        turn[:, 0::2] = np.rint(np.cos(alpha) * 32768.0)
+        turn[:, 1::2] = -np.rint(np.sin(alpha) * 32768.0)
+        x = turn @ basis
+        if noise_amp > 0:
+            x += np.rint(rng.uniform(-noise_amp, noise_amp, x.shape) * float(1 << 30))
+        out[m0:m0 + len(m)] = np.packbits(x >= 0, axis=1, bitorder="little")
+    return out
+
+
 def default_four_sv(n_ms: int, seed: int = 7) -> np.ndarray:
     """The reference's default 4-satellite table (PM/main.c:59-73): PRN 5/14/20/30, hints 900/4000/-1000/2000 Hz."""
     # true Dopplers sit a few tens of Hz off the hints so the carrier phase walks through all four quadrants (the
@@ -145,14 +182,15 @@ def lnav_word(d: list[int], d29_prev: int, d30_prev: int, solve_tail: bool = Fal
     raise AssertionError("no tail bits give D29 = D30 = 0")
 
 
-def lnav_subframe(sub_id: int, tow_count: int, rng: np.random.Generator) -> list[int]:
+def lnav_subframe(sub_id: int, tow_count: int, rng: np.random.Generator, payload: list[list[int]] | None = None) -> list[int]:
     """300 transmitted bits of one subframe: TLM (preamble), HOW (time of week of the next subframe, subframe ID), eight
-    words of random payload.  Starts from D29* = D30* = 0, which every subframe's last word guarantees."""
+    words of payload -- random, or the 8 x 24 source bits given (words 3..10; the last two bits of word 10 are solved for
+    parity either way).  Starts from D29* = D30* = 0, which every subframe's last word guarantees."""
     def rand(n):
         return [int(b) for b in rng.integers(0, 2, n)]
     words = [list(_PREAMBLE) + rand(16),
              [(tow_count >> (16 - i)) & 1 for i in range(17)] + [0, 0] + [(sub_id >> (2 - i)) & 1 for i in range(3)] + [0, 0]]
-    words += [rand(24) for _ in range(8)]
+    words += [list(w) for w in payload] if payload is not None else [rand(24) for _ in range(8)]
     out, d29, d30 = [], 0, 0
     for i, d in enumerate(words):
         w = lnav_word(d, d29, d30, solve_tail=i in (1, 9))

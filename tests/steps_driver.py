@@ -217,3 +217,63 @@ def run_ephemeris(lib: C.CDLL, imgs: np.ndarray, prn: int = 7):
         ids[i] = lib.gps_nav_data_decode_subframe(ch.ctypes.data)
         snaps[i] = ch[344:664]
     return ids, snaps
+
+
+# ---- the 64-channel reference trace (tests/golden/f7_steps_config5_64ch.npz) -------------------------------------------------
+CONFIG5_MS = 1500
+
+
+def config5_64ch_scenario():
+    """BASELINE.json configs[4]'s signal table (PRN (i mod 32) + 1, Doppler -5000 + 39 i (+ 7) Hz,
+    delay 61 i samples -- the closed-loop bench's own stream) cut to 32 signals -- 24 at the bench's amplitude 0.12, 8 weak
+    ones at 0.05 -- and 64 channels on it: channels 0..31 preset as a cold start would hand them over (Doppler to the
+    500 Hz bin, code phase to the byte), channels 32..63 on the same signals with a wrong hand-over -- the next Doppler bin
+    (even) or a code phase three bytes off (odd).  Channel 0 (PRN 1, delay 0 -> found_code_phase 0) can never leave
+    pre-tracking: gps_pre_track_process accepts a phase only `if (max_phase_value)`, and its value is 0; the wrong-bin
+    channels are what the PLL's false-lock detector reseeds from rand() (tracking.c:309-326).
+    Returns (sats for synth.make_if, [(prn, found_freq_hz, found_code_phase)] * 64, stream seed)."""
+    from stm32f4_sdr_gps_amd import synth
+    sig = [(i + 1, -5000.0 + 39.0 * i + 7.0, (61.0 * i) % 16368, 0.12 if i < 24 else 0.05, 0.37 * i) for i in range(32)]
+    chans = []
+    for c in range(64):
+        prn, dopp, delay, _, _ = sig[c % 32]
+        freq, phase = int(round(dopp / 500.0)) * 500, int(delay // 8) % 2046
+        if c >= 32:
+            if c % 2 == 0:
+                freq += 500
+            else:
+                phase = (phase + 3) % 2046
+        chans.append((prn, freq, phase))
+    return [synth.Sat(*s) for s in sig], chans, 5
+
+
+def snapshot_crcs(table):
+    """CRC of each channel's 226 snapshot bytes"""
+    import zlib
+    snap = snapshot(table)
+    return np.array([zlib.crc32(snap[c].tobytes()) & 0xFFFFFFFF for c in range(len(table))], np.uint32)
+
+
+CONFIG5_LITERAL_MS = 10000
+
+
+def config5_literal_scenario(n_ms=CONFIG5_LITERAL_MS):
+    """SURVEY.md 8(d) config 5 to the letter: 256 channels on 256 distinct signals of one shared stream -- PRN (i mod 32) + 1,
+    Doppler -5000 + 39 i Hz, delay 61 i samples (amplitude 0.12 against U(-1, 1) noise, carrier phase 0.37 i) -- 10 000 ms;
+    every channel preset as a cold start hands it over (Doppler to the 500 Hz bin, code phase to the byte).
+    Returns (stream [n_ms, 2046], [(prn, found_freq_hz, found_code_phase)] * 256, true Doppler [256], true delay [256])."""
+    from stm32f4_sdr_gps_amd import synth
+    sats = [synth.Sat((i % 32) + 1, -5000.0 + 39.0 * i, (61.0 * i) % 16368, 0.12, 0.37 * i) for i in range(256)]
+    chans = [(s.prn, int(round(s.doppler_hz / 500.0)) * 500, int(s.delay_samples // 8) % 2046) for s in sats]
+    stream = synth.make_if_static(n_ms, sats, noise_amp=1.0, seed=5)
+    return stream, chans, np.array([s.doppler_hz for s in sats]), np.array([s.delay_samples for s in sats])
+
+
+def lock_mask(table, dopp, delay):
+    """code and carrier lock as the closed-loop bench counts it: tracking state, code phase within 4 samples of the truth,
+    carrier within 60 Hz"""
+    fine = table[:, 60 + 80:60 + 84].copy().view("<f4")[:, 0]
+    freq = table[:, 60 + 4:60 + 8].copy().view("<f4")[:, 0]
+    state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+    err = np.abs(((fine - delay + 8184) % 16368) - 8184)
+    return (state == TRK_RUN) & (err < 4.0) & (np.abs(freq - dopp) < 60.0)

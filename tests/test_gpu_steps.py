@@ -194,3 +194,120 @@ def test_batched_step_on_worker_threads_equals_the_single_threaded_step():
         outs.append(line[0])
     assert all(o == outs[0] for o in outs), outs
     assert int(outs[0].split()[1]) >= 4096 * 7 // 8      # and the channels did reach tracking
+
+
+_CONFIG5_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import steps_driver as sd
+from golden_util import fnv1a32, load
+from stm32f4_sdr_gps_amd import capi, synth
+g = load("f7_steps_config5_64ch.npz")
+n_ms = int(g["n_ms"])
+sats, chans, seed = sd.config5_64ch_scenario()
+assert np.array_equal(np.array(chans, np.int32), g["chans"])
+stream = synth.make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+assert fnv1a32(stream[::97]) == int(g["stream_fnv"]), "synthetic stream differs from the one the trace was recorded on"
+lib = capi.load_library()
+steps = sd.StepsLib(lib, False)
+lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+lib.gps_tracking_process_batch.restype = None
+# libc's rand() is process-global and the ROCm runtime draws from it too (libamd_comgr, hundreds of draws whenever a code
+# object is loaded: tools/experiments/randshim.c shows them).  A host that wants the reference's reseed sequence seeds AFTER
+# the kernels of the path have been loaded: here every kernel the step launches runs once on another context first.
+warm = capi.Engine(0)
+jobs = np.zeros(1, capi.JOB_DTYPE); jobs[0] = (0, 1, 5, capi.IF_HZ + 900.0, 0, 0, 2046)
+warm.acq_jobs(stream[:1], jobs)
+st = np.zeros(64, capi.TRK_DTYPE); st["prn"] = 1 + np.arange(64) % 32
+warm.track_epl(stream[0], st); warm.rewind(st, np.full(64, 3, np.uint8))
+warm.close()
+lib.gps_fill_summ_table()
+C.CDLL("libc.so.6").srand(1)
+table = np.stack([sd.preset_channel(steps, *c) for c in chans])
+for t in range(n_ms):
+    steps.set_time(t)
+    lib.gps_tracking_process_batch(table.ctypes.data, len(chans), stream[t].ctypes.data, t & 3)
+    crc = sd.snapshot_crcs(table)
+    bad = np.flatnonzero(crc != g["crcs"][t])
+    if len(bad):
+        print("MISMATCH ms", t, "channels", bad[:8].tolist(), "reseeds so far", [tuple(r) for r in g["reseeds"] if r[0] <= t][-3:])
+        sys.exit(1)
+    if (t + 1) % 100 == 0:
+        assert np.array_equal(sd.snapshot(table), g["checkpoints"][(t + 1) // 100 - 1])
+assert np.array_equal(sd.snapshot(table), g["final"])
+state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+print("RESULT", int((state == sd.TRK_RUN).sum()), np.flatnonzero(state != sd.TRK_RUN).tolist(), len(g["reseeds"]), len(set(g["reseeds"][:, 1].tolist())), lib.gps_tracking_batch_workers())
+"""
+
+
+@pytest.mark.parametrize("threads, extra", [("1", {}), ("3", {"GPSX_STEP_THREADS_FROM": "16"}),
+                                             ("7", {"GPSX_STEP_THREADS_FROM": "16", "GPSX_STEP_OVERLAP_FROM": "8", "GPSX_STEP_CHUNKS": "4"})])
+def test_batched_step_64_channels_follows_the_reference_incl_false_lock_reseeds(threads, extra):
+    """The batched step beyond the reference's four channels, against the reference itself: 64 channels on the closed-loop
+    bench's signal table (tests/steps_driver.py config5_64ch_scenario; golden: one private instance of the reference's
+    tracking.c / nav_data.c per channel, called in channel order every millisecond, oracle/gen_golden_steps.py config5),
+    1500 ms, every channel's 226 state bytes after every millisecond.  14 of the channels were handed over on the wrong
+    Doppler bin or on weak signals and go through the PLL's false-lock reseed -- 21 draws from libc's rand()
+    (tracking.c:309-326) -- and channels 0 and 32 (PRN 1 at code phase 0) never leave pre-tracking, in the reference
+    and here alike (tracking.c: a settled phase of 0 reads as "none": the 1 signal in 32 of bench.py's closed-loop
+    ladder that never locks).  On ONE thread, and on 3 and 7 worker threads (threshold lowered; 7: overlapped with the
+    correlators in 4 pieces): workers only detect a false lock, the draws are made afterwards in channel order
+    (gpsx_steps.cpp false_lock_detect / finish_deferred), so the trace is the reference's whichever thread served a
+    channel."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPSX_STEP_THREADS=threads, **extra)
+    r = subprocess.run([sys.executable, "-c", _CONFIG5_SCRIPT, root], env=env, capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert r.returncode == 0 and line, (r.stdout[-1500:], r.stderr[-1500:])
+    f = line[0].split()
+    assert int(f[1]) == 62 and "[0, 32]" in line[0]
+    assert line[0].split("]")[1].split() == ["21", "14", threads]
+
+
+def _load_the_paths_kernels_then_seed_rand(stream):
+    """libc's rand() is process-global and the ROCm runtime draws from it too (libamd_comgr, whenever a code object is
+    loaded): run every kernel the batched step launches once on another context, THEN srand(1) -- from there on the only
+    draws are the false-lock reseeds, in the reference's order."""
+    from stm32f4_sdr_gps_amd import capi
+    warm = capi.Engine(0)
+    jobs = np.zeros(1, capi.JOB_DTYPE)
+    jobs[0] = (0, 1, 5, capi.IF_HZ + 900.0, 0, 0, 2046)
+    warm.acq_jobs(stream[:1], jobs)
+    st = np.zeros(256, capi.TRK_DTYPE)
+    st["prn"] = 1 + np.arange(256) % 32
+    warm.track_epl(stream[0], st)
+    warm.rewind(st, np.full(256, 3, np.uint8))
+    warm.close()
+    capi.load_library().gps_fill_summ_table()
+    C.CDLL("libc.so.6").srand(1)
+
+
+def test_config5_to_the_letter_256_channels_10_seconds_follow_the_reference(gpsx_lib):
+    """BASELINE.json configs[4] as SURVEY.md 8(d) words it -- 256 channels on 256 distinct signals (PRN (i mod 32) + 1,
+    -5000 + 39 i Hz, 61 i samples), 10 000 ms -- through gps_tracking_process_batch, against the reference run on the same
+    stream (tests/golden/f7_steps_config5_256ch.npz: one private instance of its step sources per channel,
+    oracle/gen_golden_steps.py config5_literal): every channel's 226 state bytes every 100 ms and at the end, and the
+    reference's own lock count -- 229 of the 256 (eight signals share each PRN and the hand-over is only good to the
+    byte: 27 channels settle on a wrong phase or carrier in the reference, and the same 27 here)."""
+    g = load("f7_steps_config5_256ch.npz")
+    n_ms = int(g["n_ms"])
+    stream, chans, dopp, delay = sd.config5_literal_scenario(n_ms)
+    assert fnv1a32(stream[::97]) == int(g["stream_fnv"]), "synthetic stream differs from the one the trace was recorded on"
+    assert np.array_equal(np.array(chans, np.int32), g["chans"])
+    steps = sd.StepsLib(gpsx_lib, False)
+    gpsx_lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+    gpsx_lib.gps_tracking_process_batch.restype = None
+    _load_the_paths_kernels_then_seed_rand(stream)
+    table = np.stack([sd.preset_channel(steps, *c) for c in chans])
+    for t in range(n_ms):
+        steps.set_time(t)
+        gpsx_lib.gps_tracking_process_batch(table.ctypes.data, 256, stream[t].ctypes.data, t & 3)
+        if (t + 1) % 100 == 0:
+            bad = np.flatnonzero(sd.snapshot_crcs(table) != g["crcs"][(t + 1) // 100 - 1])
+            assert len(bad) == 0, (t, bad[:8].tolist())
+    assert np.array_equal(sd.snapshot(table), g["final"])
+    locked = sd.lock_mask(table, dopp, delay)
+    assert np.array_equal(locked, g["locked"]) and int(locked.sum()) == 229

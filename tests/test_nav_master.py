@@ -1,0 +1,191 @@
+"""The pseudorange step (csrc/gpsx_nav_master.cpp = PM/GPS/gps_master.c:159-430) on its own, without a GPU: host code.
+PARITY UNPINNED -- the reference's gps_master.c cannot be compiled in place (its include chain ends at CMSIS' core_cm4.h,
+which the reference tree does not ship), so nothing here compares with the reference's object code.  What is checked
+instead is physics: channel records as a perfect tracker would leave them -- subframe stamps, code phases, hand-over words
+and ephemerides derived from satellites on broadcast orbits and a chosen receiver position (tests/pvt_chain.py) -- must come
+out of the step as pseudoranges that (a) differ from the true travel times by ONE common constant, and (b) put the pinned
+solver (tests/test_pvt.py: 1e-6 m against the reference's pntpos) back on the chosen position."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import pvt_chain as pc
+from pvt_types import CLIGHT, Nav, Obsd, Sol, geodetic_to_ecef
+
+RX = geodetic_to_ecef(48.1374, 11.5755, 520.0)
+TOW0 = 388800 + 30 * 37          # a frame boundary (subframe 1 starts) at the satellites
+
+
+@pytest.fixture(scope="module")
+def lib(lib_path):
+    lib = C.CDLL(lib_path)
+    lib.gpsx_nav_pseudoranges.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    lib.gps_nav_data_decode_subframe.argtypes = [C.c_void_p]
+    lib.gps_nav_data_decode_subframe.restype = C.c_uint8
+    lib.sdrobs2obsd.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.pntpos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gpsx_compat_set_packet_cnt.argtypes = [C.c_uint32]
+    return lib
+
+
+def test_lnav_ephemeris_encoding_round_trips_through_the_decoder(lib):
+    """tests/pvt_chain.py's LNAV encoder against the library's decoder (itself pinned to the reference's, f8_ephemeris.npz):
+    every element comes back as the quantized value the signal model uses."""
+    for raw, row in pc.pick_satellites(RX, TOW0, 6, seed=5):
+        ch = pc.GpsCh()
+        ch.prn = row["sat"]
+        for sub_id in (1, 2, 3):
+            img = pc.subframe_image(raw, sub_id, 64800 + sub_id)
+            C.memmove(C.addressof(ch.nav_data.subframe_data), img.ctypes.data, 38)
+            assert lib.gps_nav_data_decode_subframe(C.byref(ch)) == sub_id
+        e = ch.eph_data.eph
+        assert (ch.eph_data.received_mask_proc & 7) == 7 and e.week == pc.WEEK and ch.eph_data.tow_gpst == (64800 + 3) * 6.0
+        for k in ("A", "e", "i0", "OMG0", "omg", "M0", "deln", "OMGd", "idot", "crc", "crs", "cuc", "cus", "cic", "cis", "toes",
+                  "f0", "f1", "f2"):
+            assert getattr(e, k) == row[k], (k, getattr(e, k), row[k])
+        assert (e.iode, e.iodc, e.sat, e.svh) == (row["iode"], row["iodc"], row["sat"], 0)
+
+
+def _perfect_channels(lib, sats, now_ms, window_ms=300, points=120):
+    """Channel records at receiver tick now_ms (ms since TOW0; the receiver's clock is GPS time and its blocks start on whole
+    milliseconds) as a perfect tracker leaves them.  Channel i's code phase is the one it has 4 i ms after the middle of the
+    filter window -- the 17 ms multiplex serves the channels one after the other, which is what the step's `+ 4 i` on the
+    reception time stands for.  Returns (table, true lag of every channel at its own measurement time)."""
+    n = len(sats)
+    table = (pc.GpsCh * n)()
+    lags = []
+    for i, (raw, row) in enumerate(sats):
+        ch = table[i]
+        ch.prn = row["sat"]
+        for sub_id in (1, 2, 3):
+            img = pc.subframe_image(raw, sub_id, 1)
+            C.memmove(C.addressof(ch.nav_data.subframe_data), img.ctypes.data, 38)
+            lib.gps_nav_data_decode_subframe(C.byref(ch))
+
+        def lag(t_ms):      # reception time minus the satellite clock's reading of what is being received, seconds
+            tau, dts, _ = pc.travel_time(row, RX, np.array([TOW0 + t_ms * 1e-3]))
+            return float(tau[0] - dts[0])
+        # the last subframe boundary (satellite time 6 k) received before now: solve t - lag(t) = 6 k
+        k = int((now_ms * 1e-3 - 0.1) // 6)
+        t = 6000.0 * k + 70.0
+        for _ in range(6):
+            t = 6000.0 * k + lag(t) * 1e3
+        ch.nav_data.last_subframe_time = int(math.floor(t))      # the block the boundary falls into
+        ch.nav_data.subframe_cnt = 1
+        ch.eph_data.tow_gpst = TOW0 + 6.0 * k                     # the hand-over word of the subframe that just ended
+        t_meas = now_ms - window_ms / 2 + 4 * i
+        lg = lag(t_meas)
+        lags.append(lg)
+        phase = np.float32((lg * 1e3 % 1.0) * 16368.0)
+        ch.tracking_data.code_phase_fine = phase
+        ch.tracking_data.old_code_phase_fine = phase
+        ch.tracking_data.code_phase_fine_filt = np.float32(float(phase) * points)
+        ch.tracking_data.code_filt_cnt = points
+        ch.tracking_data.filt_start_time_ms = now_ms - window_ms
+        ch.tracking_data.if_freq_offset_hz = 1000.0
+        ch.tracking_data.snr_value = 10.0
+    return table, np.array(lags)
+
+
+def test_pseudoranges_of_six_perfect_channels_differ_from_the_truth_by_one_constant(lib):
+    sats = pc.pick_satellites(RX, TOW0, 6, seed=5)
+    # first call: the zero moment is locked (and its own ranges use the count from before the zeroing, as the source does)
+    table, _ = _perfect_channels(lib, sats, now_ms=6500)
+    assert lib.gpsx_nav_pseudoranges(table, 6, 6500) == 1
+    first = [ch.nav_data.first_subframe_time for ch in table]
+    assert all(f == ch.nav_data.last_subframe_time for f, ch in zip(first, table))
+    # second call, one subframe later: every channel has counted one subframe since the zero moment
+    table2, lags = _perfect_channels(lib, sats, now_ms=12500)
+    for ch, f in zip(table2, first):
+        ch.nav_data.first_subframe_time = f
+    assert lib.gpsx_nav_pseudoranges(table2, 6, 12500) == 1
+    pr = np.array([ch.obs_data.pseudorange_m for ch in table2])
+    common = pr - lags * CLIGHT
+    assert np.ptp(common) < 0.05, common - common.mean()       # float32 code phases: 0.001 sample = 2 cm
+    assert 55e-3 * CLIGHT < pr.min() and pr.max() < 100e-3 * CLIGHT
+    ref = int(np.argmin([ch.nav_data.last_subframe_time for ch in table2]))
+    assert abs(pr[ref] - (68.802 + float(table2[ref].tracking_data.code_phase_fine) / 16368.0) * CLIGHT / 1e3) < 1e-6
+    # reception times: hand-over word of the reference satellite + ticks since its stamp - half the window + 4 ms per channel
+    since = 12500 - table2[ref].nav_data.last_subframe_time - 150
+    for i, ch in enumerate(table2):
+        assert abs(ch.obs_data.tow_s - (TOW0 + 12.0 + (since + 4 * i) / 1e3)) < 1e-6
+        assert ch.tracking_data.code_filt_cnt == 0 and ch.tracking_data.filt_start_time_ms == 12500   # window reopened
+    # not ready: one channel short of points
+    table2[3].tracking_data.code_filt_cnt = 50
+    assert lib.gpsx_nav_pseudoranges(table2, 6, 12600) == 0
+    # a wrap inside the window restarts it
+    for ch in table2:
+        ch.tracking_data.code_filt_cnt = 120
+    table2[2].tracking_data.code_phase_fine_filt = -1.0
+    assert lib.gpsx_nav_pseudoranges(table2, 6, 12700) == 0 and table2[0].tracking_data.filt_start_time_ms == 12700
+
+
+def test_code_phase_wrap_since_the_stamp_moves_the_range_by_one_code_period(lib):
+    sats = pc.pick_satellites(RX, TOW0, 4, seed=29)
+    table, lags = _perfect_channels(lib, sats, now_ms=12500)
+    for ch in table:
+        ch.nav_data.first_subframe_time = ch.nav_data.last_subframe_time - 6000
+    base = (pc.GpsCh * 4)()
+    C.memmove(base, table, C.sizeof(table))
+    assert lib.gpsx_nav_pseudoranges(base, 4, 12500) == 1
+    # channel 1's code phase has wrapped upwards through 16368 since its stamp (negative Doppler: the delay grows)
+    t = table[1].tracking_data
+    t.old_code_phase_fine = 16300.0
+    t.code_phase_fine = 12.0
+    t.code_phase_fine_filt = 12.0 * 120
+    t.if_freq_offset_hz = -1500.0
+    assert lib.gpsx_nav_pseudoranges(table, 4, 12500) == 1
+    assert table[1].tracking_data.code_phase_swap_flag == 1
+    want = base[1].obs_data.pseudorange_m + ((12.0 - float(base[1].tracking_data.code_phase_fine)) / 16368.0 + 1.0) * CLIGHT / 1e3
+    assert abs(table[1].obs_data.pseudorange_m - want) < 1e-3
+    assert table[0].obs_data.pseudorange_m == base[0].obs_data.pseudorange_m
+
+
+def test_perfect_channels_through_the_step_and_the_solver_return_the_receiver_position(lib):
+    """The reference-named flow for its four channels: gps_master_nav_handling (pseudoranges, then gps_master_calculate_pos
+    -> sdrobs2obsd -> gps_pos_solve, twice: solve, then geodetic).
+    The reference's reception time is the reference satellite's hand-over word plus the ticks since its subframe arrived --
+    the time the signal now being received LEFT that satellite -- while its pseudoranges declare that satellite 68.802 ms
+    away: the solver therefore places every satellite where it was ~69 ms before the transmission and the earth
+    accordingly, a range error of (range rate x 69 ms) per satellite, up to ~55 m, which the four-satellite solution turns
+    into some tens of metres of position ("This is just a demo!", gps_master.c:4-5).  Restated as written.  Checked here:
+    (1) the flow's own answer is within 150 m of the truth, and (2) the SAME observation records with nothing but
+    their time tags moved by the declared 68.802 ms put the solver within half a metre of it -- i.e. the pseudoranges and the
+    epoch arithmetic are right, and what remains is exactly that convention."""
+    sats = pc.pick_satellites(RX, TOW0, 4, seed=29)
+    table, _ = _perfect_channels(lib, sats, now_ms=12500)
+    for ch in table:
+        ch.nav_data.first_subframe_time = ch.nav_data.last_subframe_time - 6000
+    lib.gps_pos_solve_init(table)
+    lib.gpsx_compat_set_packet_cnt(12500)
+    lib.gps_master_nav_handling(table)             # pseudoranges + first solver call
+    assert lib.solving_is_busy() == 1
+    lib.gpsx_compat_set_packet_cnt(12517)
+    lib.gps_master_nav_handling(table)             # filter window not ready again; the solver's second call converts
+    assert lib.solving_is_busy() == 0
+    sol = Sol.in_dll(lib, "gps_sol")
+    pos = np.array(list(sol.rr)[:3])
+    assert sol.stat == 5 and sol.ns == 4
+    assert np.linalg.norm(pos - RX) < 150.0, pos - RX
+    final = (C.c_double * 3).in_dll(lib, "final_pos")
+    assert abs(final[0] - 48.1374) < 2e-3 and abs(final[1] - 11.5755) < 2e-3 and abs(final[2] - 520.0) < 150.0
+    # (2) the same records, time tags + 68.802 ms
+    obs = (Obsd * 4).in_dll(lib, "obsd")
+    moved = (Obsd * 4)()
+    C.memmove(moved, obs, C.sizeof(obs))
+    for o in moved:
+        o.time.sec += 68.802e-3
+    nav = Nav()
+    nav.n = 4
+    for i in range(4):
+        nav.eph[i] = C.pointer(table[i].eph_data.eph)
+    sol2 = Sol()
+    assert lib.pntpos(moved, 4, C.byref(nav), C.byref(sol2)) == 1
+    pos2 = np.array(list(sol2.rr)[:3])
+    assert np.linalg.norm(pos2 - RX) < 0.5, pos2 - RX
+    # the receiver clock term then holds what the declared 68.802 ms is off by for the reference satellite
+    ref = int(np.argmin([ch.nav_data.last_subframe_time for ch in table]))
+    assert abs(sol2.dtr[0]) < 2e-3
+    assert table[ref].obs_data.pseudorange_m <= min(ch.obs_data.pseudorange_m for ch in table) + 1e-3 * CLIGHT

@@ -38,11 +38,14 @@ def _cpu_throttle():
         return None
 
 
-def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=True):
+def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=True, literal=False):
+    """literal: SURVEY.md 8(d) config 5 to the letter -- one signal per channel at -5000 + 39 i Hz exactly (no 7 Hz offset),
+    synthesised by synth.make_if_static (the stream tests/golden/f7_steps_config5_256ch.npz was recorded on when channels =
+    256 and ms = 10000: the reference's own lock count on it is reported beside the engine's)."""
     import steps_driver as sd
     from stm32f4_sdr_gps_amd import capi, synth
     n = channels
-    n_sig = signals if 0 < signals < n else n
+    n_sig = signals if 0 < signals < n and not literal else n
     lib = capi.load_library()
     affinity = os.sched_getaffinity(0)
     bound = False
@@ -55,14 +58,14 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
         lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
         lib.gps_tracking_process_batch.restype = None
         sig_prn = [(i % 32) + 1 for i in range(n_sig)]
-        sig_dopp = [-5000.0 + 39.0 * i + 7.0 for i in range(n_sig)]
+        sig_dopp = [-5000.0 + 39.0 * i + (0.0 if literal else 7.0) for i in range(n_sig)]
         sig_delay = [(61.0 * i) % 16368 for i in range(n_sig)]
-        key = (n_sig, ms, amp)
+        key = (n_sig, ms, amp, literal)
         t0 = time.time()
         if key not in _stream_cache:
             _stream_cache.clear()
             sats = [synth.Sat(sig_prn[i], sig_dopp[i], sig_delay[i], amp, 0.37 * i) for i in range(n_sig)]
-            _stream_cache[key] = synth.make_if(ms, sats, noise_amp=1.0, seed=5)
+            _stream_cache[key] = (synth.make_if_static if literal else synth.make_if)(ms, sats, noise_amp=1.0, seed=5)
         stream = _stream_cache[key]
         gen_s = time.time() - t0
         per_sig = np.stack([sd.preset_channel(steps, sig_prn[i], int(round(sig_dopp[i] / 500.0)) * 500,
@@ -94,6 +97,13 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
         steady = lat[ms // 2:]
         late = int((steady >= 1e-3).sum())
         del n_trk
+        ref_locked = None
+        if literal and (n, ms) == (256, sd.CONFIG5_LITERAL_MS):
+            try:
+                from golden_util import load
+                ref_locked = int(load("f7_steps_config5_256ch.npz")["locked"].sum())
+            except Exception:
+                ref_locked = None
         return {"metric": "closed-loop real-time tracking channels (gps_tracking_process_batch per ms: work lists, one E/P/L "
                           "launch, DLL / PLL / FLL + nav-bit logic per channel on the host)",
                 "channels": n, "signals_in_stream": n_sig, "ms": ms, "signal_amp": amp,
@@ -108,6 +118,8 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
                 "warmup_max_us": float(lat[:ms // 2].max() * 1e6),
                 "real_time": bool(late == 0),
                 "tracking_state": int((state == sd.TRK_RUN).sum()), "code_and_carrier_lock": int(locked.sum()),
+                "code_and_carrier_lock_in_the_reference_on_this_stream": ref_locked,
+                "not_locked": np.flatnonzero(~locked)[:64].tolist(),
                 "median_code_error_samples": float(np.median(err)), "synth_seconds": gen_s,
                 "note": "latencies of the second half of the run (steady state: every channel past pre-tracking); "
                         "warmup_max_us = the worst step of the first half (graph instantiation, buffer growth, the "
@@ -129,9 +141,10 @@ def main():
                          "i mod signals -- a cheap way to load thousands of channels without synthesising thousands of signals")
     ap.add_argument("--no-bind", action="store_true")
     ap.add_argument("--unpaced", action="store_true", help="steps back to back instead of one per millisecond")
+    ap.add_argument("--literal", action="store_true", help="SURVEY.md 8(d) config 5 to the letter (see closed_loop)")
     args = ap.parse_args()
     for n in args.channels:
-        print(json.dumps(closed_loop(n, args.ms, args.amp, args.signals, not args.no_bind, not args.unpaced)), flush=True)
+        print(json.dumps(closed_loop(n, args.ms, args.amp, args.signals, not args.no_bind, not args.unpaced, args.literal)), flush=True)
 
 
 if __name__ == "__main__":
