@@ -261,6 +261,69 @@ typedef void (*gpsx_track_chunk_fn)(void *user, int first_channel, int n_channel
 int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out,
                                  int n_chunks, gpsx_track_chunk_fn on_chunk, void *user);
 
+/* ---- the tracking LOOPS on the device: correlators + DLL / PLL / FLL + false-lock check + SNR + 20 ms bit synchroniser,
+ *      K milliseconds per launch, channel state resident in HBM  (gps_tracking_data_process, PM/GPS/tracking.c:92-170,
+ *      with gps_tracking_dll / _pll / _fll / _pll_check :175-393 and gps_nav_data_analyse_new_code, PM/GPS/nav_data.c:46-253)
+ *
+ * The bit-exact mode of this library runs those float loops on the host behind every correlator launch
+ * (gps_tracking_process / gps_tracking_process_batch, include/gpsx_compat.h).  This is the other mode: a receiver that tracks
+ * tens of thousands of channels keeps each channel's loop state in a gpsx_loop_state_t in device memory and hands the
+ * engine K consecutive 1 ms blocks; one kernel runs, per channel and millisecond, the E/P/L correlators (bit-exact, as
+ * above) and then the reference's loop arithmetic in its own order of float operations.  Nothing crosses the link per
+ * millisecond but the IF block in and ONE byte per channel out:
+ *     bit 0  prompt in-phase accumulator > 0          bit 1  a navigation bit was completed this millisecond ...
+ *     bit 2  ... and this is its value                bit 3  20 ms bit period synchronised (after this millisecond)
+ *     bit 4  the false-lock detector moved the carrier (tracking.c:309-326)
+ * -- what the word layer (gps_nav_data_words_detection, one call per completed bit) needs.  Serving schedule: every channel
+ * every millisecond, index = tick & 3 (project_single_sat/main.c:96-109, as gps_tracking_process_batch).
+ * Differences from the host mode, all stated: the arctangents are the device's (results agree with glibc's to the last
+ * bit or the one before it: the stated tolerance of the closed loop is |d code_phase_fine| <= 0.01 sample,
+ * |d if_freq_offset_hz| <= 0.5 Hz against the reference's traces, tests/test_gpu_track_loop.py); the false-lock jump
+ * draws from a per-channel xorshift32 (`rng`, never 0) instead of libc's process-global rand(). */
+typedef struct {
+  int32_t  prn;                                /* 1 .. 210 */
+  float    code_phase_fine;                    /* gps_tracking_t, same names, same meaning (include/gpsx_compat.h) */
+  float    if_freq_offset_hz;
+  uint32_t if_freq_accum;
+  float    dll_code_err, pll_code_err, fll_err;
+  int16_t  fll_old_i, fll_old_q;
+  int16_t  pll_check_buf[4];
+  uint16_t pll_bad_state_master_cnt;
+  uint8_t  pll_bad_state_cnt;
+  uint8_t  period_sync_ok_flag;                /* gps_nav_data_t: 20 ms bit period found (selects the PLL's gain set) */
+  int16_t  found_freq_offset_hz;               /* gps_acq_t: centre of the false-lock jump */
+  uint16_t reseed_count;                       /* false-lock jumps so far */
+  uint32_t rng;                                /* xorshift32 state of those jumps; must not be 0 */
+  uint32_t i_part_summ, q_part_summ;           /* SNR estimator */
+  float    snr_value;
+  uint16_t snr_summ_cnt;
+  uint16_t code_filt_cnt;                      /* code-phase averaging window of the pseudorange step */
+  float    code_phase_fine_filt;
+  uint32_t old_swap_time;                      /* gps_nav_data_t: bit synchroniser */
+  uint32_t slot_start_ticks;                   /* tick of index 0 of the current 4 ms group */
+  int16_t  slot_ip[4];                         /* prompt I of the group so far */
+  uint8_t  slot_bits;                          /* bit i = sign bit of index i of the group */
+  uint8_t  right_period_cnt, old_reminder, accurate_swap_time, accurate_swap_ok;
+  uint8_t  last_bit_pos_cnt, last_bit_neg_cnt;
+  uint8_t  inv_polarity_flag;                  /* written by the HOST's word layer when it finds inverted preambles */
+} gpsx_loop_state_t;                           /* 96 bytes */
+
+typedef struct {                               /* optional per-millisecond record, for tests and inspection */
+  int16_t  iq[6];                              /* IE, QE, IP, QP, IL, QL of this millisecond */
+  float    code_phase_fine, if_freq_offset_hz; /* AFTER this millisecond's loop updates */
+  uint32_t if_freq_accum;
+} gpsx_loop_trace_t;                           /* 24 bytes */
+
+/* d_if_blocks: n_blocks consecutive 1 ms blocks in device memory (the context's IF format); d_state: n_ch states in device
+ * memory, read, advanced by n_blocks milliseconds, written; first_tick_ms: the millisecond tick of the first block;
+ * d_flags: [n_blocks][n_ch] bytes (above); d_trace_opt: NULL or [n_blocks][n_ch] records.  Enqueues and returns. */
+int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
+                        uint32_t first_tick_ms, uint8_t *d_flags, gpsx_loop_trace_t *d_trace_opt);
+/* The same with the blocks and the flag bytes in host memory (page-locked: gpsx_host_alloc): copies the blocks in,
+ * runs, copies the flags (and trace records, if asked for) out, waits.  The states stay on the device. */
+int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
+                    uint32_t first_tick_ms, uint8_t *flags, gpsx_loop_trace_t *trace_opt);
+
 /* ---- per-call primitives on caller buffers (the device work behind include/gpsx_compat.h) --------------------- */
 
 /* gps_shift_to_zero_freq(_track): *accum is the NCO accumulator in/out (0 for the stateless call).  Writes bytes

@@ -328,6 +328,13 @@ extern obsd_t obsd[GPS_SAT_CNT];         /* the observation records gps_master_c
 /* azimuth / elevation (deg) of the four satellites of the last solution (the reference's global `azel`) */
 const double *gpsx_pvt_azel(void);
 
+/* not in the reference: a tracking channel's loop state to / from the device-resident form of include/gpsx.h
+ * (gpsx_track_loop: DLL / PLL / FLL and the bit synchroniser on the GPU).  Hand a channel over on a tick with
+ * tick & 3 == 0 (the 4 ms group state of the bit synchroniser is not part of gps_ch_t). */
+#include "gpsx.h"
+void gpsx_loop_state_from_channel(const gps_ch_t *ch, uint32_t rng_seed, gpsx_loop_state_t *out);
+void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch);
+
 /* not in the reference: release the default context (optional, for leak checkers) */
 void gpsx_compat_shutdown(void);
 

@@ -24,6 +24,18 @@ PHASES_BYTE = 2046
 PHASES_FINE = 16368
 IF_HZ = 4092000
 
+LOOP_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"), ("if_freq_accum", "<u4"),
+                       ("dll_code_err", "<f4"), ("pll_code_err", "<f4"), ("fll_err", "<f4"), ("fll_old_i", "<i2"),
+                       ("fll_old_q", "<i2"), ("pll_check_buf", "<i2", 4), ("pll_bad_state_master_cnt", "<u2"),
+                       ("pll_bad_state_cnt", "u1"), ("period_sync_ok_flag", "u1"), ("found_freq_offset_hz", "<i2"),
+                       ("reseed_count", "<u2"), ("rng", "<u4"), ("i_part_summ", "<u4"), ("q_part_summ", "<u4"),
+                       ("snr_value", "<f4"), ("snr_summ_cnt", "<u2"), ("code_filt_cnt", "<u2"), ("code_phase_fine_filt", "<f4"),
+                       ("old_swap_time", "<u4"), ("slot_start_ticks", "<u4"), ("slot_ip", "<i2", 4), ("slot_bits", "u1"),
+                       ("right_period_cnt", "u1"), ("old_reminder", "u1"), ("accurate_swap_time", "u1"),
+                       ("accurate_swap_ok", "u1"), ("last_bit_pos_cnt", "u1"), ("last_bit_neg_cnt", "u1"),
+                       ("inv_polarity_flag", "u1")])          # gpsx_loop_state_t, 96 bytes
+LOOP_TRACE_DTYPE = np.dtype([("iq", "<i2", 6), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"), ("if_freq_accum", "<u4")])
+assert LOOP_DTYPE.itemsize == 96 and LOOP_TRACE_DTYPE.itemsize == 24
 PEAK_DTYPE = np.dtype([("max_val", "<u4"), ("phase", "<u4"), ("sum", "<u4"), ("avr", "<u4")])
 TRACK_CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)   # gpsx_track_chunk_fn
 TRK_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"),
@@ -88,6 +100,12 @@ def load_library() -> C.CDLL:
     lib.gpsx_track_epl_batch_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                  TRACK_CHUNK_FN, C.c_void_p]
     lib.gpsx_rewind.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_track_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.gpsx_track_loop_dev.argtypes = lib.gpsx_track_loop.argtypes
+    lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.gpsx_loop_state_from_channel.restype = None
+    lib.gpsx_loop_state_to_channel.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_loop_state_to_channel.restype = None
     lib.gpsx_wipeoff.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
     lib.gpsx_replica.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
     lib.gpsx_corr_offsets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -361,6 +379,16 @@ class Engine:
                                                         iq.ctypes.data, n_chunks, cb, None),
                   "gpsx_track_epl_batch_chunked")
         return iq
+
+    def track_loop(self, if_blocks: np.ndarray, d_state: int, n_ch: int, first_tick: int, want_trace=False):
+        """K = len(if_blocks) milliseconds of the device tracking loops on the n_ch states at device address d_state.
+        Returns (flags uint8 [K, n_ch], trace LOOP_TRACE_DTYPE [K, n_ch] or None)."""
+        blocks = np.ascontiguousarray(if_blocks, np.uint8).reshape(-1, self.block_bytes)
+        flags = np.zeros((len(blocks), n_ch), np.uint8)
+        trace = np.zeros((len(blocks), n_ch), LOOP_TRACE_DTYPE) if want_trace else None
+        self._chk(self.lib.gpsx_track_loop(self.h, blocks.ctypes.data, len(blocks), d_state, n_ch, first_tick,
+                                           flags.ctypes.data, _ptr(trace)), "gpsx_track_loop")
+        return flags, trace
 
     def rewind(self, states: np.ndarray, steps) -> None:
         steps = np.ascontiguousarray(steps, np.uint8)

@@ -1050,6 +1050,54 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   return track_prn_verdict(ctx);
 }
 
+/* ---- the tracking loops on the device ---------------------------------------------------------------------------------- */
+
+int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
+                        uint32_t first_tick_ms, uint8_t *d_flags, gpsx_loop_trace_t *d_trace_opt)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!d_if_blocks || !d_state || !d_flags || n_ch < 1 || n_blocks < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
+  launch_track_loop(ctx->stream, static_cast<const uint8_t *>(d_if_blocks), (uint32_t)blk_bytes, n_blocks, ctx->if_format,
+                    ctx->if_hz, d_state, n_ch, first_tick_ms, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace_opt,
+                    ctx->d_bad_prn + 1);
+  LAUNCHCHK(ctx, "k_track_loop");
+  ctx->last_kernel = "k_track_loop";
+  return GPSX_OK;
+}
+
+int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
+                    uint32_t first_tick_ms, uint8_t *flags, gpsx_loop_trace_t *trace_opt)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!if_blocks || !d_state || !flags || n_ch < 1 || n_blocks < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
+  const size_t n_rec = (size_t)n_blocks * n_ch;
+  if (int rc = arena_reset(ctx, arena_size(blk_bytes * n_blocks + 2) + arena_size(n_rec) +
+                                    (trace_opt ? arena_size(n_rec * sizeof(gpsx_loop_trace_t)) : 0)))
+    return rc;
+  const uint8_t *d_if = capture_mirror(ctx, if_blocks, blk_bytes * n_blocks);
+  uint8_t *d_if_copy = arena_take<uint8_t>(ctx, blk_bytes * n_blocks + 2);
+  uint8_t *d_flags = arena_take<uint8_t>(ctx, n_rec);
+  gpsx_loop_trace_t *d_trace = trace_opt ? arena_take<gpsx_loop_trace_t>(ctx, n_rec) : nullptr;
+  if (!d_if) {
+    HIPCHK(ctx, hipMemcpyAsync(d_if_copy, if_blocks, blk_bytes * n_blocks, hipMemcpyHostToDevice, ctx->stream));
+    d_if = d_if_copy;
+  }
+  ctx->h_bad_prn[0] = 0;   // (flag 0: this entry point waits for its kernel, as gpsx_track_epl_batch does)
+  launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick_ms,
+                    ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, ctx->d_bad_prn);
+  LAUNCHCHK(ctx, "k_track_loop");
+  ctx->last_kernel = "k_track_loop";
+  HIPCHK(ctx, hipMemcpyAsync(flags, d_flags, n_rec, hipMemcpyDeviceToHost, ctx->stream));
+  if (trace_opt)
+    HIPCHK(ctx, hipMemcpyAsync(trace_opt, d_trace, n_rec * sizeof(gpsx_loop_trace_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return track_prn_verdict(ctx);
+}
+
 int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *steps)
 {
   if (int rc = use_device(ctx)) return rc;

@@ -171,3 +171,88 @@ void gps_rewind_if_phase(gps_tracking_t *trk_channel, uint8_t steps)
 }
 
 }  // extern "C"
+
+
+// ---- channel record <-> device loop state (include/gpsx.h gpsx_loop_state_t) ------------------------------------------------
+static_assert(sizeof(gpsx_loop_state_t) == 96 && offsetof(gpsx_loop_state_t, pll_check_buf) == 32 &&
+                  offsetof(gpsx_loop_state_t, slot_ip) == 80 && sizeof(gpsx_loop_trace_t) == 24,
+              "gpsx_loop_state_t layout");
+
+extern "C" {
+
+// A tracking channel (state GPS_TRACKING_RUN) handed to the device loop.  The 4 ms group state of the bit synchroniser is
+// not part of gps_ch_t (the reference keeps it in file statics): hand channels over on a millisecond whose tick & 3 == 0,
+// where a group starts.  rng_seed: any non-zero value, e.g. the channel number + 1.
+void gpsx_loop_state_from_channel(const gps_ch_t *ch, uint32_t rng_seed, gpsx_loop_state_t *out)
+{
+  const gps_tracking_t &t = ch->tracking_data;
+  const gps_nav_data_t &n = ch->nav_data;
+  gpsx_loop_state_t s;
+  std::memset(&s, 0, sizeof s);
+  s.prn = ch->prn;
+  s.code_phase_fine = t.code_phase_fine;
+  s.if_freq_offset_hz = t.if_freq_offset_hz;
+  s.if_freq_accum = t.if_freq_accum;
+  s.dll_code_err = t.dll_code_err;
+  s.pll_code_err = t.pll_code_err;
+  s.fll_err = t.fll_err;
+  s.fll_old_i = t.fll_old_i;
+  s.fll_old_q = t.fll_old_q;
+  std::memcpy(s.pll_check_buf, t.pll_check_buf, sizeof s.pll_check_buf);
+  s.pll_bad_state_master_cnt = t.pll_bad_state_master_cnt;
+  s.pll_bad_state_cnt = t.pll_bad_state_cnt;
+  s.period_sync_ok_flag = n.period_sync_ok_flag;
+  s.found_freq_offset_hz = ch->acq_data.found_freq_offset_hz;
+  s.rng = rng_seed ? rng_seed : 1u;
+  s.i_part_summ = t.i_part_summ;
+  s.q_part_summ = t.q_part_summ;
+  s.snr_value = t.snr_value;
+  s.snr_summ_cnt = t.snr_summ_cnt;
+  s.code_filt_cnt = t.code_filt_cnt;
+  s.code_phase_fine_filt = t.code_phase_fine_filt;
+  s.old_swap_time = n.old_swap_time;
+  s.right_period_cnt = n.right_period_cnt;
+  s.old_reminder = n.old_reminder;
+  s.accurate_swap_time = n.accurate_swap_time;
+  s.accurate_swap_ok = n.accurate_swap_ok;
+  s.last_bit_pos_cnt = n.last_bit_pos_cnt;
+  s.last_bit_neg_cnt = n.last_bit_neg_cnt;
+  s.inv_polarity_flag = n.inv_polarity_flag;
+  *out = s;
+}
+
+// ... and back: everything the loops own is written into the record, the rest of it (acquisition result, word layer,
+// observations, ephemeris) is left alone.
+void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch)
+{
+  gps_tracking_t &t = ch->tracking_data;
+  gps_nav_data_t &n = ch->nav_data;
+  const gpsx_loop_state_t &s = *in;
+  t.code_phase_fine = s.code_phase_fine;
+  t.if_freq_offset_hz = s.if_freq_offset_hz;
+  t.if_freq_accum = s.if_freq_accum;
+  t.dll_code_err = s.dll_code_err;
+  t.pll_code_err = s.pll_code_err;
+  t.fll_err = s.fll_err;
+  t.fll_old_i = s.fll_old_i;
+  t.fll_old_q = s.fll_old_q;
+  std::memcpy(t.pll_check_buf, s.pll_check_buf, sizeof s.pll_check_buf);
+  t.pll_bad_state_master_cnt = s.pll_bad_state_master_cnt;
+  t.pll_bad_state_cnt = s.pll_bad_state_cnt;
+  t.i_part_summ = s.i_part_summ;
+  t.q_part_summ = s.q_part_summ;
+  t.snr_value = s.snr_value;
+  t.snr_summ_cnt = s.snr_summ_cnt;
+  t.code_filt_cnt = s.code_filt_cnt;
+  t.code_phase_fine_filt = s.code_phase_fine_filt;
+  n.period_sync_ok_flag = s.period_sync_ok_flag;
+  n.old_swap_time = s.old_swap_time;
+  n.right_period_cnt = s.right_period_cnt;
+  n.old_reminder = s.old_reminder;
+  n.accurate_swap_time = s.accurate_swap_time;
+  n.accurate_swap_ok = s.accurate_swap_ok;
+  n.last_bit_pos_cnt = s.last_bit_pos_cnt;
+  n.last_bit_neg_cnt = s.last_bit_neg_cnt;
+}
+
+}  // extern "C"

@@ -38,7 +38,7 @@ struct gpsx_ctx {
   uint32_t *h_bad_prn = nullptr;      // page-locked flag the tracking kernels raise on a PRN outside 1..210
   uint32_t *d_bad_prn = nullptr;      // its device address
   std::string err;
-  const char *last_kernel = "";      // dominant kernel of the last acquisition launch (gpsx_last_kernel)
+  const char *last_kernel = "";      // dominant kernel of the last acquisition / device-loop launch (gpsx_last_kernel)
   hipDeviceProp_t prop;
 
   // tables for every PRN, slot == prn (slot 0 is the empty code): K1 output

@@ -1,0 +1,390 @@
+// k_track_loop.hip -- the tracking loops on the device (include/gpsx.h "the tracking LOOPS on the device").
+//
+// One launch advances every channel by K milliseconds: per millisecond the wave-per-channel E/P/L correlators of
+// gpsx_track_wave.hpp (bit-exact: the same device function k_track_epl_wave launches), then, for the up to sixteen channels of
+// a wave at once, what gps_tracking_data_process does with the six accumulators (PM/GPS/tracking.c:132-170):
+//   gps_tracking_dll :338-393   gps_tracking_pll :175-205   gps_tracking_fll :208-256 with gps_tracking_pll_check :261-327
+//   gps_nav_data_analyse_new_code, PM/GPS/nav_data.c:46-253 (20 ms bit period, bit edge, bit votes)   SNR :141-169
+// restated from csrc/gpsx_steps.cpp's host versions expression by expression: the same float32 operations in the same order
+// (this file is built with -ffp-contract=off and correctly rounded division like the rest), so that everything but the
+// three arctangents and the SNR's logarithm is bit-identical to the host mode.
+//
+// Lanes: lane 4 c + k of a wave holds channel c of the wave (k = 0 / 1 / 2 = Early / Prompt / Late in the correlators).
+// All four lanes of a quad carry the channel's whole loop state and run the loops redundantly -- they all need the new
+// code phase and carrier for the next millisecond's correlators, and a broadcast would cost what the arithmetic does.
+// HBM traffic per launch: K x 2 KB of samples per workgroup (L2 hits after the first), 96 B of state in and out and K flag
+// bytes per channel: the kernel is bound by the correlators' vector instructions exactly as k_track_epl_wave is.
+#include <hip/hip_runtime.h>
+
+#include "gpsx_device.hpp"
+#include "gpsx_kernels.hpp"
+#include "gpsx_track_wave.hpp"
+
+namespace gpsx {
+
+namespace {
+
+constexpr double kPiD = 3.14159265358979323846;
+constexpr float kDll1C1 = 1.0f, kDll1C2 = 300.0f;          // TRACKING_DLL1_C1 / _C2 (PM/config.h)
+constexpr float kPll1C1 = 4.0f, kPll1C2 = 3000.0f, kPll2C1 = 8.0f, kPll2C2 = 5000.0f;
+constexpr float kFll1C1 = 200.0f, kFll1C2 = 2000.0f;
+constexpr int kPllBadThreshold = 80;                        // tracking.c:14
+constexpr int kSnrLength = 200;                             // tracking.c:26
+constexpr int kSearchStepHz = 500;                          // ACQ_SEARCH_STEP_HZ
+
+template <int K>
+__device__ __forceinline__ u32 quad_get(u32 v)   // lane k of this lane's quad
+{
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+// The two four-entry int16 arrays of the state (pll_check_buf, slot_ip) live in one 64-bit register pair each while the loops
+// run: indexing a register array with the millisecond's index would send the whole state to scratch memory.
+struct Quad16 {
+  unsigned long long v;
+  __device__ __forceinline__ int get(int i) const { return (int16_t)(uint16_t)(v >> (16 * i)); }
+  __device__ __forceinline__ void set(int i, int x) { v = (v & ~(0xFFFFull << (16 * i))) | ((unsigned long long)(uint16_t)x << (16 * i)); }
+};
+__device__ __forceinline__ Quad16 quad16_load(const int16_t (&a)[4])
+{
+  return Quad16{(unsigned long long)(uint16_t)a[0] | ((unsigned long long)(uint16_t)a[1] << 16) |
+                ((unsigned long long)(uint16_t)a[2] << 32) | ((unsigned long long)(uint16_t)a[3] << 48)};
+}
+__device__ __forceinline__ void quad16_store(const Quad16 &q, int16_t (&a)[4])
+{
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    a[i] = (int16_t)q.get(i);
+}
+
+// gps_tracking_dll
+__device__ __forceinline__ void loop_dll(gpsx_loop_state_t &s, int IE, int QE, int IL, int QL)
+{
+  const int32_t e2 = IE * IE + QE * QE, l2 = IL * IL + QL * QL;
+  float err = (float)(e2 - l2) / (float)(e2 + l2);
+  err = -err;
+  const float dt = 0.001f;
+  s.code_phase_fine += (kDll1C1 * (err - s.dll_code_err) + kDll1C2 * dt * err);
+  const float span = (float)(2 * kChips * 8);
+  bool wrapped = false;
+  if (s.code_phase_fine < 0.0f) {
+    s.code_phase_fine = span - s.code_phase_fine;   // sic (tracking.c:356-361)
+    wrapped = true;
+  } else if (s.code_phase_fine > span) {
+    s.code_phase_fine = s.code_phase_fine - span;
+    wrapped = true;
+  }
+  if (wrapped) {
+    s.code_phase_fine_filt = -1.0f;
+  } else if (s.code_phase_fine_filt >= 0.0f) {
+    s.code_phase_fine_filt += s.code_phase_fine;
+    s.code_filt_cnt++;
+  }
+  s.dll_code_err = err;
+}
+
+// gps_tracking_pll (index 0 only has an effect).  The reference's atan2f / atan2 -> the device's double-precision atan2,
+// rounded once: the correctly rounded float in all but ~1 case in 2^29, where glibc's own atan2f is good to an ulp.
+__device__ __forceinline__ void loop_pll(gpsx_loop_state_t &s, int IP, int QP)
+{
+  float phase_err;   // in units of pi
+  if (IP > 0)
+    phase_err = (float)((double)(float)atan2((double)QP, (double)IP) / kPiD);
+  else
+    phase_err = (float)(atan2((double)(float)-QP, (double)(float)-IP) / kPiD);
+  float step = phase_err - s.pll_code_err;
+  if ((double)step > kPiD / 2)
+    step = (float)(kPiD - (double)step);
+  if ((double)step < -kPiD / 2)
+    step = (float)(-kPiD - (double)step);
+  const float dt = 0.001f;
+  if (s.period_sync_ok_flag)
+    s.if_freq_offset_hz -= kPll2C1 * step + (kPll2C2 * dt * phase_err);
+  else
+    s.if_freq_offset_hz -= kPll1C1 * step + (kPll1C2 * dt * phase_err);
+  s.pll_code_err = phase_err;
+}
+
+// gps_tracking_pll_check; true = the carrier was moved
+__device__ __forceinline__ bool loop_false_lock(gpsx_loop_state_t &s, Quad16 &chk, int index, int IP)
+{
+  chk.set(index, IP);
+  if (index < 3)
+    return false;
+  int flips = 0;
+  int prev = chk.get(0) > 0;
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    const int cur = chk.get(i) > 0;
+    flips += cur != prev;
+    prev = cur;
+  }
+  if (flips > 1) {
+    if (s.pll_bad_state_cnt < 10)
+      s.pll_bad_state_cnt++;
+  } else if (s.pll_bad_state_cnt > 0) {
+    s.pll_bad_state_cnt--;
+  }
+  if (s.pll_bad_state_cnt > 9)
+    s.pll_bad_state_master_cnt++;
+  else if (s.pll_bad_state_cnt == 0)
+    s.pll_bad_state_master_cnt = 0;
+  if (s.pll_bad_state_master_cnt <= kPllBadThreshold)
+    return false;
+  s.pll_bad_state_master_cnt = 0;
+  s.pll_bad_state_cnt = 0;
+  // a random carrier offset around the acquired one, at least 200 Hz from where the loop stands (tracking.c:309-326);
+  // the draws come from the channel's own xorshift32 -- libc's rand() is one sequence per PROCESS
+  int16_t candidate;
+  int delta;
+  u32 x = s.rng ? s.rng : 0x9E3779B9u;
+  do {
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    const int r = (int)(x % (u32)kSearchStepHz);
+    candidate = (int16_t)(s.found_freq_offset_hz - r + kSearchStepHz / 2);
+    delta = (int16_t)((int16_t)s.if_freq_offset_hz - candidate);
+  } while (iabs(delta) < 200);
+  s.rng = x;
+  s.reseed_count++;
+  s.if_freq_offset_hz = (float)candidate;
+  return true;
+}
+
+__device__ __forceinline__ float atan_ratio(int q, int i)   // the reference's (i == 0) ? pi / 2 : atanf((float)q / (float)i)
+{
+  if (i == 0)
+    return (float)(kPiD / 2);
+  return (float)atan((double)((float)q / (float)i));
+}
+
+// gps_tracking_fll behind its call of the check
+__device__ __forceinline__ void loop_fll(gpsx_loop_state_t &s, int index, int IP, int QP)
+{
+  if (index == 0) {
+    s.fll_old_i = (int16_t)IP;
+    s.fll_old_q = (int16_t)QP;
+    return;
+  }
+  const float now = atan_ratio(QP, IP), before = atan_ratio(s.fll_old_q, s.fll_old_i);
+  float rot = now - before;
+  if ((double)rot > kPiD / 2)
+    rot = (float)(kPiD - (double)rot);
+  if ((double)rot < -kPiD / 2)
+    rot = (float)(-kPiD - (double)rot);
+  float change = rot - s.fll_err;
+  if ((double)change > kPiD / 2)
+    change = (float)(kPiD - (double)change);
+  if ((double)change < -kPiD / 2)
+    change = (float)(-kPiD - (double)change);
+  const float dt = 0.001f;
+  const float hz = kFll1C1 * dt * change + (kFll1C2 * dt * rot);
+  s.if_freq_offset_hz -= hz;
+  s.fll_old_i = (int16_t)IP;
+  s.fll_old_q = (int16_t)QP;
+  s.fll_err = rot;
+}
+
+// nav_data.c:145-218: which millisecond of the 4 ms group holds the bit edge
+__device__ __forceinline__ void nav_refine_edge(gpsx_loop_state_t &s, const Quad16 &sip)
+{
+  const int ip[4] = {sip.get(0), sip.get(1), sip.get(2), sip.get(3)};
+  if (iabs(ip[1]) > iabs(ip[0]))
+    return;
+  if (ip[3] == 0)
+    return;
+  const float whole = (float)iabs(ip[0]) / (float)iabs(ip[3]);
+  if (whole > 1.5f || whole < 0.7f)
+    return;
+  const int chip = (int16_t)((int16_t)s.code_phase_fine / 16);
+  if (chip < 0 || chip > kChips)
+    return;
+  int edge = 0;
+  if (chip < kChips / 4 || chip > kChips * 3 / 4) {
+    if (ip[1] == 0)
+      return;
+    const float jump = (float)iabs(ip[0]) / (float)iabs(ip[1]);
+    if (jump > 1.5f || jump < 0.7f)
+      return;
+    edge = chip < kChips / 4 ? 2 : 1;
+  } else {
+    const int d1 = (uint16_t)iabs(ip[0] - ip[1]), d2 = (uint16_t)iabs(ip[2] - ip[3]);
+    if (d1 > d2) {
+      if (d2 == 0)
+        return;
+      if ((float)d1 / (float)d2 < 2.5f)
+        return;
+      edge = 1;
+    } else {
+      if (d1 == 0)
+        return;
+      if ((float)d2 / (float)d1 < 2.5f)
+        return;
+      edge = 2;
+    }
+  }
+  s.accurate_swap_time = (uint8_t)((s.slot_start_ticks + (u32)edge) % 20u);
+  s.accurate_swap_ok = 1;
+}
+
+// gps_nav_data_analyse_new_code on the channel's own slot state; returns flag bits 1 / 2 (a bit was completed / its value)
+__device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, int index, int IP, u32 now)
+{
+  u32 out = 0;
+  u32 bit = IP > 0 ? 1u : 0u;
+  if (s.inv_polarity_flag)
+    bit ^= 1u;
+  s.slot_bits = (uint8_t)((s.slot_bits & ~(1u << index)) | (bit << index));
+  sip.set(index, IP);
+  if (index == 0)
+    s.slot_start_ticks = now;
+  if (s.period_sync_ok_flag == 1) {   // nav_data.c:223-253
+    const u32 rem = (now - s.old_swap_time) % 20u;
+    if (rem < s.old_reminder) {
+      out = 2u | (s.last_bit_pos_cnt > s.last_bit_neg_cnt ? 4u : 0u);
+      s.last_bit_pos_cnt = 0;
+      s.last_bit_neg_cnt = 0;
+    }
+    if (bit)
+      s.last_bit_pos_cnt++;
+    else
+      s.last_bit_neg_cnt++;
+    s.old_reminder = (uint8_t)rem;
+  }
+  if (index < 3)
+    return out;
+  int flips = 0, flip_at = 0;
+  u32 prev = s.slot_bits & 1u;
+#pragma unroll
+  for (int i = 1; i < 4; i++) {
+    const u32 cur = (s.slot_bits >> i) & 1u;
+    if (cur != prev) {
+      flips++;
+      flip_at = i;
+    }
+    prev = cur;
+  }
+  if (flips != 1)
+    return out;
+  const u32 edge_time = s.slot_start_ticks + (u32)flip_at;
+  const u32 rem = (edge_time - s.old_swap_time) % 20u;
+  if (rem < 2 || rem == 19) {
+    if (s.right_period_cnt < 10)
+      s.right_period_cnt++;
+    if (s.right_period_cnt > 8)
+      s.period_sync_ok_flag = 1;
+  } else {
+    if (s.right_period_cnt > 0)
+      s.right_period_cnt--;
+    if (s.right_period_cnt < 3)
+      s.period_sync_ok_flag = 0;
+  }
+  s.old_swap_time = edge_time;
+  if (s.period_sync_ok_flag && flip_at == 2)
+    nav_refine_edge(s, sip);
+  return out;
+}
+
+__device__ __forceinline__ void loop_snr(gpsx_loop_state_t &s, int IP, int QP)
+{
+  s.i_part_summ += (u32)iabs(IP);
+  s.q_part_summ += (u32)iabs(QP);
+  s.snr_summ_cnt++;
+  if (s.snr_summ_cnt > kSnrLength) {
+    if (s.q_part_summ == 0) {
+      s.snr_value = 1.0f;
+      return;   // sic: the sums are not cleared on this path (tracking.c:152-156)
+    }
+    const float ratio = (float)s.i_part_summ / (float)s.q_part_summ;
+    s.snr_value = 10.0f * log10f(ratio);
+    s.snr_summ_cnt = 0;
+    s.i_part_summ = 0;
+    s.q_part_summ = 0;
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ if_blocks, u32 block_stride, int n_blocks,
+                                                    int if_format, int if_hz, gpsx_loop_state_t *__restrict__ st, int n_ch, int cpw,
+                                                    u32 first_tick, const u32 *__restrict__ chipbits_all,
+                                                    const u32 *__restrict__ rep_all, uint8_t *__restrict__ flags,
+                                                    gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn)
+{
+  __shared__ u32 s_x[2][512];        // this and the next millisecond's sign plane: one barrier per millisecond
+  __shared__ uint2 s_carrier[4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int ch0 = ((int)blockIdx.x * 4 + wave) * cpw;
+  const int n_here = ch0 < n_ch ? min(cpw, n_ch - ch0) : 0;   // (0: an idle wave of the last workgroup still stages blocks)
+  const int c_l = lane >> 2, k_l = lane & 3;
+  const bool in_wave = c_l < n_here;
+  const bool mine = in_wave && k_l < 3;
+  const int ch_l = ch0 + (in_wave ? c_l : 0);
+  gpsx_loop_state_t s = {};
+  int prn = 0;
+  if (n_here) {
+    s = st[ch_l < n_ch ? ch_l : 0];
+    prn = track_prn(s.prn, bad_prn, mine && k_l == 0);
+  }
+  Quad16 chk = quad16_load(s.pll_check_buf), sip = quad16_load(s.slot_ip);
+
+#pragma unroll 1
+  for (int ms = 0; ms < n_blocks; ms++) {
+    u32 *sx = s_x[ms & 1];
+    trkwave::stage_block(if_blocks + (size_t)ms * block_stride, if_format, sx, s_carrier);
+    __syncthreads();
+    if (!n_here)
+      continue;
+    const u32 now = first_tick + (u32)ms;
+    const int index = (int)(now & 3u);
+    const int fine = (int)(int16_t)(int)s.code_phase_fine;
+    const u32 step = nco_step_per_word((float)if_hz + s.if_freq_offset_hz);
+    const u32 iq = trkwave::wave_epl(sx, s_carrier, lane, n_here, mine, prn, fine, step, s.if_freq_accum, chipbits_all, rep_all);
+    const u32 e = quad_get<0>(iq), p = quad_get<1>(iq), l = quad_get<2>(iq);
+    const int IE = (int16_t)(e & 0xFFFFu), QE = (int16_t)(e >> 16), IP = (int16_t)(p & 0xFFFFu), QP = (int16_t)(p >> 16);
+    const int IL = (int16_t)(l & 0xFFFFu), QL = (int16_t)(l >> 16);
+    s.if_freq_accum += step * (u32)kWords32;
+    // tracking.c:132-170, in the reference's order
+    loop_dll(s, IE, QE, IL, QL);
+    if (index == 0)
+      loop_pll(s, IP, QP);
+    const bool moved = loop_false_lock(s, chk, index, IP);
+    loop_fll(s, index, IP, QP);
+    u32 flag = nav_bit_sync(s, sip, index, IP, now);
+    loop_snr(s, IP, QP);
+    flag |= (IP > 0 ? 1u : 0u) | (s.period_sync_ok_flag ? 8u : 0u) | (moved ? 16u : 0u);
+    if (in_wave && k_l == 0) {
+      flags[(size_t)ms * n_ch + ch_l] = (uint8_t)flag;
+      if (trace) {
+        gpsx_loop_trace_t t;
+        t.iq[0] = (int16_t)IE; t.iq[1] = (int16_t)QE; t.iq[2] = (int16_t)IP; t.iq[3] = (int16_t)QP; t.iq[4] = (int16_t)IL; t.iq[5] = (int16_t)QL;
+        t.code_phase_fine = s.code_phase_fine;
+        t.if_freq_offset_hz = s.if_freq_offset_hz;
+        t.if_freq_accum = s.if_freq_accum;
+        trace[(size_t)ms * n_ch + ch_l] = t;
+      }
+    }
+  }
+  if (in_wave && k_l == 0) {
+    quad16_store(chk, s.pll_check_buf);
+    quad16_store(sip, s.slot_ip);
+    st[ch_l] = s;
+  }
+}
+
+void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
+                       gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, const uint32_t *d_chipbits, const uint32_t *d_trk_rep,
+                       uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
+{
+  if (n_ch <= 0 || n_blocks <= 0)
+    return;
+  int cpw = n_ch / (4 * 256 * 4);   // as launch_track_epl: ~4 workgroups per CU, 16 channels per wave at most
+  cpw = cpw < 1 ? 1 : (cpw > 16 ? 16 : cpw);
+  hipLaunchKernelGGL(k_track_loop, dim3((n_ch + 4 * cpw - 1) / (4 * cpw)), dim3(256), 0, s, d_if_blocks, block_stride, n_blocks,
+                     if_format, if_hz, d_st, n_ch, cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn);
+}
+
+}  // namespace gpsx

@@ -81,15 +81,16 @@ def subframe_payloads(raw):
     return {k: [v[30 * w:30 * w + 24] for w in range(2, 10)] for k, v in out.items()}
 
 
-def lnav_stream(raw, first_subframe_index, n_subframes, seed):
+def lnav_stream(raw, first_subframe_index, n_subframes, seed, cycle=5):
     """0/1 navigation bits of n_subframes whole subframes, the first one being subframe number first_subframe_index of the
-    week (it starts at GPS time 6 * index; its ID is index mod 5 + 1, its hand-over word announces index + 1)."""
+    week (it starts at GPS time 6 * index; its ID is index mod 5 + 1, its hand-over word announces index + 1).  cycle = 3: a
+    test signal whose frames consist of subframes 1, 2, 3 only, so that a receiver has a whole ephemeris after any three."""
     from stm32f4_sdr_gps_amd import synth
     rng = np.random.Generator(np.random.PCG64(seed))
     pay = subframe_payloads(raw)
     bits = []
     for k in range(first_subframe_index, first_subframe_index + n_subframes):
-        sub_id = k % 5 + 1
+        sub_id = k % cycle + 1
         bits += synth.lnav_subframe(sub_id, k + 1, rng, pay.get(sub_id))
     return np.array(bits, np.uint8)
 
@@ -216,7 +217,7 @@ def pick_satellites(rx, tow, n, seed, min_el_deg=25.0):
     return [(raw, q) for raw, q, _ in out]
 
 
-def make_if_from_orbits(n_ms, sats, rx, tow0, amp=0.6, noise_amp=1.0, seed=7, nav_seed=100):
+def make_if_from_orbits(n_ms, sats, rx, tow0, amp=0.6, noise_amp=1.0, seed=7, nav_seed=100, cycle=5):
     """1-bit IF blocks [n_ms, 2046] a receiver at ECEF rx records from GPS time-of-week tow0 on (its clock IS GPS time):
     per satellite (raw, row) code, LNAV data and carrier, all delayed by the travel time of that millisecond (linear inside
     it) and shifted by the satellite's own clock offset.  tow0 must be a multiple of 6 s (a subframe boundary at the
@@ -230,7 +231,7 @@ def make_if_from_orbits(n_ms, sats, rx, tow0, amp=0.6, noise_amp=1.0, seed=7, na
     n_sub = n_ms // 6000 + 3
     for j, (raw, row) in enumerate(sats):
         tau, dts, _ = travel_time(row, rx, t_edges)
-        bits = 1.0 - 2.0 * lnav_stream(raw, k0, n_sub, nav_seed + j).astype(np.float64)
+        bits = 1.0 - 2.0 * lnav_stream(raw, k0, n_sub, nav_seed + j, cycle).astype(np.float64)
         code = 1.0 - 2.0 * synth.ca_code(row["sat"]).astype(np.float64)
         per_sat.append((tau, dts, bits, code))
     frac = np.arange(synth.SAMPLES_PER_MS, dtype=np.float64) / synth.SAMPLES_PER_MS

@@ -1,0 +1,210 @@
+"""The tracking loops on the device (gpsx_track_loop: E/P/L correlators + DLL / PLL / FLL + false-lock check + SNR + the
+20 ms bit synchroniser in ONE kernel, K milliseconds per launch, channel state resident in HBM) against
+  (a) the reference's own closed-loop traces (tests/golden/f7_steps_continuous.npz: its gps_tracking_process served every
+      millisecond), within the tolerance SURVEY.md 8(c) states for float loop outputs computed with another libm --
+      |d code_phase_fine| <= 0.01 sample, |d if_freq_offset_hz| <= 0.5 Hz, over the whole trace;
+  (b) the CPU oracle, teacher-forced: the six accumulators of EVERY millisecond, from the state the device itself had, bit
+      for bit -- the integer part of the path has no tolerance;
+  (c) itself under other launch lengths (K = 1, 3, 20, 64: bit for bit) and the host mode of this library
+      (gps_tracking_process_batch) on thousands of channels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import steps_driver as sd
+from golden_util import fnv1a32, load
+
+pytestmark = pytest.mark.gpu
+
+TOL_FINE, TOL_HZ = 0.01, 0.5
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from stm32f4_sdr_gps_amd import capi
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def _states_from_records(lib, records, seeds=None):
+    from stm32f4_sdr_gps_amd import capi
+    st = np.zeros(len(records), capi.LOOP_DTYPE)
+    for i, rec in enumerate(records):
+        rec = np.ascontiguousarray(rec)
+        lib.gpsx_loop_state_from_channel(rec.ctypes.data, int(seeds[i]) if seeds is not None else i + 1, st[i:i + 1].ctypes.data)
+    return st
+
+
+def _run(eng, stream, st0, t0, t1, k, want_trace=True):
+    """device loop from tick t0 to t1 in launches of k milliseconds; returns (flags [t1 - t0, n], trace, final states)"""
+    n = len(st0)
+    d = eng.malloc(st0.nbytes)
+    try:
+        eng.h2d(d, st0)
+        flags, trace = [], []
+        t = t0
+        while t < t1:
+            kk = min(k, t1 - t)
+            f, tr = eng.track_loop(stream[t:t + kk], d, n, t, want_trace=want_trace)
+            flags.append(f)
+            trace.append(tr)
+            t += kk
+        out = np.zeros_like(st0)
+        eng.d2h(out, d)
+    finally:
+        eng.free(d)
+    return np.concatenate(flags), (np.concatenate(trace) if want_trace else None), out
+
+
+def _golden_start(g):
+    """first tick t0 with t0 & 3 == 0 from which all four channels of the trace are in GPS_TRACKING_RUN, and the channel
+    records (snapshot bytes + PRN) of the millisecond before it"""
+    snaps = g["snaps"]
+    state = snaps[:, :, 60 + 148:60 + 152].copy().view("<i4")[:, :, 0]
+    first = int(np.flatnonzero((state == sd.TRK_RUN).all(axis=1))[0])
+    t0 = (first + 1 + 3) // 4 * 4 + 8
+    recs = np.zeros((4, sd.CH_SIZE), np.uint8)
+    recs[:, :sd.SNAP] = snaps[t0 - 1]
+    recs[:, 664] = g["prns"]
+    return t0, recs
+
+
+def test_device_loop_follows_the_reference_trace_within_the_stated_tolerance(eng, oracle):
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_continuous.npz")
+    n_ms = int(g["n_ms"])
+    stream = synth.four_sv_with_nav(n_ms, seed=7)
+    assert fnv1a32(stream[::97]) == int(g["stream_fnv"])
+    t0, recs = _golden_start(g)
+    st0 = _states_from_records(eng.lib, recs)
+    flags, trace, final = _run(eng, stream, st0, t0, n_ms, 20)
+    want = g["snaps"][t0:]
+    fine_w = want[:, :, 60 + 80:60 + 84].copy().view("<f4")[:, :, 0]
+    freq_w = want[:, :, 60 + 4:60 + 8].copy().view("<f4")[:, :, 0]
+    accum_w = want[:, :, 60 + 8:60 + 12].copy().view("<u4")[:, :, 0]
+    d_fine, d_freq = np.abs(trace["code_phase_fine"] - fine_w), np.abs(trace["if_freq_offset_hz"] - freq_w)
+    print("max |d fine|", d_fine.max(), "max |d freq|", d_freq.max(), "ms with identical floats",
+          int(((d_fine == 0) & (d_freq == 0)).all(axis=1).sum()), "of", len(want),
+          "identical NCO accumulators", int((trace["if_freq_accum"] == accum_w).all(axis=1).sum()))
+    assert d_fine.max() <= TOL_FINE and d_freq.max() <= TOL_HZ
+    # (b) teacher-forced: every millisecond's accumulators from the state the device had going into it
+    chips = [oracle.ca_code(int(p)) for p in g["prns"]]
+    for c in range(4):
+        fine, freq, acc = float(st0["code_phase_fine"][c]), float(st0["if_freq_offset_hz"][c]), int(st0["if_freq_accum"][c])
+        for i in range(len(trace)):
+            iq, acc_out = oracle.track_epl(stream[t0 + i], chips[c], fine, freq, acc)
+            assert np.array_equal(iq, trace["iq"][i, c]) and acc_out == int(trace["if_freq_accum"][i, c]), (c, t0 + i)
+            fine, freq, acc = float(trace["code_phase_fine"][i, c]), float(trace["if_freq_offset_hz"][i, c]), acc_out
+    # the bit synchroniser: integer logic on the prompt signs -- the reference's flags and counters at the end of the trace
+    end = g["snaps"][-1]
+    assert np.array_equal(final["period_sync_ok_flag"], end[:, 212]) and final["period_sync_ok_flag"].any()
+    assert np.array_equal(final["old_swap_time"], end[:, 216:220].copy().view("<u4")[:, 0])
+    assert np.array_equal(final["right_period_cnt"], end[:, 213])
+    assert np.array_equal(flags[:, :] & 8, np.where(want[:, :, 212] > 0, 8, 0))          # period sync, every millisecond
+    # prompt signs: flag bit 0 of every millisecond = sign of the traced IP
+    assert np.array_equal(flags & 1, (trace["iq"][:, :, 2] > 0).astype(np.uint8))
+    # one navigation bit per 20 ms while synchronised, none otherwise
+    for c in range(4):
+        on = want[:, c, 212] > 0
+        done = (flags[:, c] & 2) > 0
+        assert abs(int(done.sum()) - int(on.sum()) // 20) <= 2 + int(np.abs(np.diff(on.astype(int))).sum()), c
+    # the SNR estimate, the only consumer of the logarithm
+    snr_w = end[:, 60 + 132:60 + 136].copy().view("<f4")[:, 0]
+    assert np.allclose(final["snr_value"], snr_w, atol=1e-3)
+
+
+@pytest.mark.parametrize("k", [1, 3, 64])
+def test_launch_length_does_not_change_a_bit(eng, k):
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_continuous.npz")
+    stream = synth.four_sv_with_nav(int(g["n_ms"]), seed=7)
+    t0, recs = _golden_start(g)
+    st0 = _states_from_records(eng.lib, recs)
+    t1 = t0 + 400
+    f20, tr20, end20 = _run(eng, stream, st0, t0, t1, 20)
+    f, tr, end = _run(eng, stream, st0, t0, t1, k)
+    assert np.array_equal(f, f20) and tr.tobytes() == tr20.tobytes() and end.tobytes() == end20.tobytes()
+
+
+def test_device_loop_on_thousands_of_channels_against_the_host_mode(eng):
+    """20 000 channels on eight signals (cpw = 4 channels per wave, a ragged last wave): the host mode --
+    gps_tracking_process_batch, the reference's loops on the CPU behind every correlator launch -- takes all of them through
+    pre-tracking into tracking; at tick 200 the channels are handed to the device loop (gpsx_loop_state_from_channel) and both
+    modes go on for 240 ms.  Same tolerance as against the reference; the NCO accumulators and the bit synchroniser's
+    state are integers and must agree exactly wherever the floats did not part."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    n, n_sig, t_hand, t_end = 20003, 8, 200, 440
+    lib = eng.lib
+    steps = sd.StepsLib(lib, False)
+    lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+    lib.gps_tracking_process_batch.restype = None
+    sats = [synth.Sat(i + 1, -2000.0 + 450.0 * i, (2000.0 * i + 37.0) % 16368, 0.25, 0.3 * i) for i in range(n_sig)]
+    stream = synth.make_if(t_end, sats, noise_amp=1.0, seed=9)
+    per_sig = np.stack([sd.preset_channel(steps, s.prn, int(round(s.doppler_hz / 500.0)) * 500, int(s.delay_samples // 8) % 2046)
+                        for s in sats])
+    table = np.ascontiguousarray(per_sig[np.arange(n) % n_sig])
+    for t in range(t_hand):
+        steps.set_time(t)
+        lib.gps_tracking_process_batch(table.ctypes.data, n, stream[t].ctypes.data, t & 3)
+    tracking = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0] == sd.TRK_RUN
+    assert tracking.sum() >= n * 7 // 8
+    st0 = _states_from_records(lib, table)
+    _, _, final = _run(eng, stream, st0, t_hand, t_end, 24, want_trace=False)
+    assert eng.lib.gpsx_last_kernel(eng.h) == b"k_track_loop"
+    for t in range(t_hand, t_end):
+        steps.set_time(t)
+        lib.gps_tracking_process_batch(table.ctypes.data, n, stream[t].ctypes.data, t & 3)
+    host = _states_from_records(lib, table)
+    m = tracking
+    d_fine = np.abs(final["code_phase_fine"][m] - host["code_phase_fine"][m])
+    d_freq = np.abs(final["if_freq_offset_hz"][m] - host["if_freq_offset_hz"][m])
+    same = (d_fine == 0) & (d_freq == 0)
+    print("channels", int(m.sum()), "bit-identical floats", int(same.sum()), "max |d fine|", d_fine.max(), "max |d freq|", d_freq.max())
+    assert d_fine.max() <= TOL_FINE and d_freq.max() <= TOL_HZ
+    assert same.mean() > 0.5
+    for f in ("if_freq_accum", "period_sync_ok_flag", "right_period_cnt", "old_swap_time", "pll_bad_state_cnt", "fll_old_i",
+              "fll_old_q", "i_part_summ", "q_part_summ", "snr_summ_cnt", "code_filt_cnt"):
+        assert np.array_equal(final[f][m][same], host[f][m][same]), f
+    assert np.array_equal(final["pll_check_buf"][m][same], host["pll_check_buf"][m][same])
+
+
+def test_device_loop_false_lock_jump_and_bad_prn(eng):
+    """A channel handed over 300 Hz off a clean carrier flips signs inside every 4 ms group: after 10 + 81 groups the
+    false-lock detector must move it to found_freq_offset_hz -+ 250 Hz, at least 200 Hz from where it stood, drawing from
+    the channel's own generator (flag bit 4, reseed_count); and a PRN outside 1..210 is reported by the call."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    sats = [synth.Sat(7, 1300.0, 4000.0, 0.8, 0.0)]
+    stream = synth.make_if(600, sats, noise_amp=0.3, seed=3)
+    st = np.zeros(2, capi.LOOP_DTYPE)
+    st["prn"] = 7
+    st["code_phase_fine"] = 4000.0
+    st["if_freq_offset_hz"] = [1000.0, 1300.0]      # channel 0: 300 Hz off; channel 1: on the carrier
+    st["found_freq_offset_hz"] = [1000, 1500]
+    st["rng"] = [12345, 54321]
+    # the FLL would pull channel 0 in; keep it where it is by handing it over again every 4 ms
+    d = eng.malloc(st.nbytes)
+    try:
+        eng.h2d(d, st)
+        moved_at = None
+        for t in range(0, 600, 4):
+            flags, _ = eng.track_loop(stream[t:t + 4], d, 2, t)
+            cur = np.zeros_like(st)
+            eng.d2h(cur, d)
+            if flags[:, 0].max() & 16:
+                moved_at = t
+                break
+            cur["if_freq_offset_hz"][0] = 1000.0     # (only the carrier is put back: the detector's counters run on)
+            cur["fll_err"][0] = 0.0
+            eng.h2d(d, cur)
+        assert moved_at is not None and 4 * 85 <= moved_at <= 4 * 140, moved_at
+        assert cur["reseed_count"][0] == 1 and cur["reseed_count"][1] == 0 and cur["rng"][0] != 12345 and cur["rng"][1] == 54321
+        assert 750 <= cur["if_freq_offset_hz"][0] <= 1260 and abs(cur["if_freq_offset_hz"][0] - 1000.0) >= 190
+        assert cur["pll_bad_state_master_cnt"][0] == 0
+        st["prn"][1] = 211
+        eng.h2d(d, st)
+        with pytest.raises(capi.GpsxError):
+            eng.track_loop(stream[:4], d, 2, 0)
+    finally:
+        eng.free(d)
