@@ -172,9 +172,15 @@ def tracking_closed_loop(ms=1200):
                 break             # (past the first miss nothing can raise `value`; two more counts are kept for the p99 reading)
     isolated = [r["channels"] for r in rows if r["real_time"] and best is not None and r["channels"] > best]
     by_p99 = [r["channels"] for r in rows if r["p99_us"] < 1000.0]
+    device = None
+    try:
+        device = tracking_device_loop()
+    except Exception as exc:   # a secondary leg must not take the line with it
+        device = {"error": repr(exc)}
+        print(f"bench.py: device-loop leg failed: {exc!r}", file=sys.stderr, flush=True)
     return {"metric": "closed-loop real-time tracking channels: largest count of the ladder with NO steady-state step at or over "
                       "1 ms at that count or at any smaller one",
-            "value": best, "larger_counts_that_met_every_deadline_after_a_smaller_one_missed": isolated,
+            "value": best, "device_loop": device, "larger_counts_that_met_every_deadline_after_a_smaller_one_missed": isolated,
             "largest_count_with_p99_under_1ms": max(by_p99) if by_p99 else None,
             "config5": config5,
             "one_signal_in_32_never_locks": "PRN 1 at delay 0 is handed over with found_code_phase 0; the reference's pre-tracking "
@@ -190,6 +196,39 @@ def tracking_closed_loop(ms=1200):
                     "thread of this process was preempted for milliseconds by other tenants (max_us of 4-30 ms next to "
                     "a p99 far below 1 ms; cpu_quota_throttled_ms_during_run says whether the container's own CPU quota "
                     "was the cause) -- largest_count_with_p99_under_1ms is the same ladder read without those"}
+
+
+def tracking_device_loop(ms=1200, k=20):
+    """configs[4] with the tracking loops on the device (tools/bench_tracking_device_loop.py): k_track_loop advances every
+    channel by K ms per launch -- correlators, DLL / PLL / FLL, false-lock check, SNR, bit synchroniser, state resident in HBM
+    (bit-identical to the reference's trace: tests/test_gpu_track_loop.py) -- one flag byte per channel and ms comes back, the
+    host runs the word layer per completed navigation bit.  Same stream and channels as the host-loop ladder above.  A count
+    is real-time when every launch of the steady half is back before the next launch's K blocks are complete."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_tracking_device_loop",
+                                                  os.path.join(ROOT, "tools", "bench_tracking_device_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    keep = ("channels", "ms_per_launch", "launch_p50_us", "launch_p99_us", "launch_max_us", "deadline_us", "launches_over_deadline",
+            "per_ms_p50_us", "per_ms_max_us", "gpu_part_p50_us", "warmup_max_us", "real_time", "behind_at_end_ms", "host_workers",
+            "channels_handed_over_tracking", "code_and_carrier_lock", "false_lock_jumps")
+    per_ms = mod.device_loop(256, ms, 1, 32)            # K = 1: the per-millisecond latency, comparable with the host loop's
+    rows, best, missed = [], None, False
+    for n in (256, 65536, 262144, 524288, 1048576, 1572864, 2097152):
+        r = mod.device_loop(n, ms, k, 32)
+        rows.append({kk: r[kk] for kk in keep})
+        if r["real_time"] and not missed:
+            best = n
+        if not r["real_time"]:
+            missed = True
+            break
+    return {"metric": "closed-loop real-time tracking channels with the loops on the device: largest count of the ladder whose "
+                      "launches (K ms of stream each) ALL come back inside K ms, at that count and every smaller one",
+            "value": best, "ms_per_launch": k, "ms_per_count": ms, "signals_in_stream": 32,
+            "per_millisecond_launches_256_channels": {kk: per_ms[kk] for kk in keep}, "ladder": rows,
+            "note": "ONE run per count; steady state = second half of each run.  With K ms per launch the deadline is K ms: a host "
+                    "thread that another tenant holds up for a few milliseconds delays a launch, it does not miss one -- the "
+                    "per-millisecond work is on the GPU"}
 
 
 def cpu_baseline(blocks, budget_s=20.0):

@@ -274,7 +274,10 @@ int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_tr
  *     bit 0  prompt in-phase accumulator > 0          bit 1  a navigation bit was completed this millisecond ...
  *     bit 2  ... and this is its value                bit 3  20 ms bit period synchronised (after this millisecond)
  *     bit 4  the false-lock detector moved the carrier (tracking.c:309-326)
- * -- what the word layer (gps_nav_data_words_detection, one call per completed bit) needs.  Serving schedule: every channel
+ *     bit 5  the bit edge inside the 20 ms grid was located (nav_data.c:145-218): accurate_swap_time =
+ *            (tick - 3 + (bit 6 ? 2 : 1)) % 20 -- what the subframe time stamp is made of
+ * -- what the word layer (gps_nav_data_words_detection, one call per completed bit; gps_tracking_words_batch in
+ * include/gpsx_compat.h does it for a whole launch) needs.  Serving schedule: every channel
  * every millisecond, index = tick & 3 (project_single_sat/main.c:96-109, as gps_tracking_process_batch).
  * Differences from the host mode, all stated: the arctangents are the device's (results agree with glibc's to the last
  * bit or the one before it: the stated tolerance of the closed loop is |d code_phase_fine| <= 0.01 sample,
@@ -323,6 +326,10 @@ int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gp
  * runs, copies the flags (and trace records, if asked for) out, waits.  The states stay on the device. */
 int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
                     uint32_t first_tick_ms, uint8_t *flags, gpsx_loop_trace_t *trace_opt);
+
+/* The host's word layer found (or gave up) inverted data polarity on n channels: d_state[channels[i]].inv_polarity_flag =
+ * values[i] (host arrays; enqueued on the context's stream in front of the next launch). */
+int gpsx_loop_set_polarity(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, const int *channels, const uint8_t *values, int n);
 
 /* ---- per-call primitives on caller buffers (the device work behind include/gpsx_compat.h) --------------------- */
 

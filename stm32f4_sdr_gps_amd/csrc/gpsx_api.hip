@@ -1098,6 +1098,22 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
   return track_prn_verdict(ctx);
 }
 
+int gpsx_loop_set_polarity(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, const int *channels, const uint8_t *values, int n)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!d_state || !channels || !values || n < 0)
+    return fail(ctx, GPSX_EINVAL, "null argument");
+  for (int i = 0; i < n; i++) {   // a handful of channels, once or twice in each one's life: one byte each
+    if (channels[i] < 0)
+      return fail(ctx, GPSX_EINVAL, "negative channel index");
+    const uint8_t v = values[i] ? 1 : 0;
+    HIPCHK(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_state + channels[i]) + offsetof(gpsx_loop_state_t, inv_polarity_flag),
+                               &v, 1, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (&v is a stack byte)
+  }
+  return GPSX_OK;
+}
+
 int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *steps)
 {
   if (int rc = use_device(ctx)) return rc;

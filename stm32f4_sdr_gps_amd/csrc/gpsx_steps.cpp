@@ -73,8 +73,12 @@ SlotState g_shared_slot;
 // into the host.  Outside a batched step it is the hook itself, call by call, as the reference reads it.
 std::atomic<bool> g_batch_tick_valid{false};
 uint32_t g_batch_tick = 0;
+thread_local bool t_tick_valid = false;   // gps_tracking_words_batch: a worker replays the milliseconds of a launch one by one
+thread_local uint32_t t_tick = 0;
 inline uint32_t tick()
 {
+  if (t_tick_valid)
+    return t_tick;
   return g_batch_tick_valid.load(std::memory_order_acquire) ? g_batch_tick : signal_capture_get_packet_cnt();
 }
 struct BatchTick {
@@ -1630,6 +1634,68 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
   if (rc != GPSX_OK)
     gpsx_compat_die("gps_tracking_process_batch", rc);
   finish_deferred();
+}
+
+
+// ---- the word layer behind the DEVICE tracking loops (include/gpsx.h gpsx_track_loop) ------------------------------------------
+// flags: the [n_blocks][n_ch] bytes of one gpsx_track_loop launch whose first block had tick first_tick.  Per channel and
+// millisecond, in order: a completed navigation bit goes to gps_nav_data_words_detection with the tick of its
+// millisecond (preamble hunt, parity, polarity, subframe assembly, ephemeris decode, subframe time stamp -- all as in
+// the host mode), then a located bit edge is written into the channel's nav_data (what the NEXT stamp is made from, as
+// nav_data.c orders them).  The bit synchroniser's own state lives on the device; of it the host record keeps
+// period_sync_ok_flag, accurate_swap_time / _ok and inv_polarity_flag current.  Channels whose inv_polarity_flag changed
+// are listed in changed_opt (at most max_changed; returns how many): the caller hands them to gpsx_loop_set_polarity,
+// because the device votes on polarity-corrected signs (nav_data.c:60-66).  From kStepThreadsFrom channels on: worker threads.
+int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, int n_blocks, uint32_t first_tick,
+                             int *changed_opt, int max_changed)
+{
+  if (!channel || !flags || n_ch <= 0 || n_blocks <= 0)
+    return 0;
+  StepPool &pool = StepPool::instance();
+  static const int kThreadsFrom = [] { const char *e = std::getenv("GPSX_STEP_THREADS_FROM"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : kStepThreadsFrom; }();
+  static const bool kForeignHooks = resolves_outside_this_library((const void *)&gps_nav_data_words_detection) ||
+                                    resolves_outside_this_library((const void *)&gps_nav_data_decode_subframe);
+  const int n_workers = (n_ch >= kThreadsFrom && !kForeignHooks) ? pool.size() : 1;
+  static std::vector<std::vector<int>> changed;
+  if ((int)changed.size() < n_workers)
+    changed.resize(n_workers);
+  auto work = [&](int w) {
+    std::vector<int> &mine = changed[w];
+    mine.clear();
+    const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
+    t_tick_valid = true;
+    for (int ms = 0; ms < n_blocks; ms++) {
+      const uint8_t *f = flags + (size_t)ms * n_ch;
+      t_tick = first_tick + (uint32_t)ms;
+      for (int c = lo; c < hi; c++) {
+        const uint8_t v = f[c];
+        if ((v & (2 | 8 | 32)) == 0)
+          continue;
+        gps_nav_data_t &n = channel[c].nav_data;
+        n.period_sync_ok_flag = (v & 8) ? 1 : 0;
+        if (v & 2) {
+          const uint8_t before = n.inv_polarity_flag;
+          gps_nav_data_words_detection(&channel[c], (uint8_t)((v >> 2) & 1));
+          if (n.inv_polarity_flag != before && (mine.empty() || mine.back() != c))
+            mine.push_back(c);
+        }
+        if (v & 32) {
+          n.accurate_swap_time = (uint8_t)((t_tick - 3u + ((v & 64) ? 2u : 1u)) % 20u);
+          n.accurate_swap_ok = 1;
+        }
+      }
+    }
+    t_tick_valid = false;
+  };
+  pool.run(n_workers, work);
+  int total = 0;
+  for (int w = 0; w < n_workers; w++)
+    for (int c : changed[w]) {
+      if (changed_opt && total < max_changed)
+        changed_opt[total] = c;
+      total++;
+    }
+  return total;
 }
 
 }  // extern "C"

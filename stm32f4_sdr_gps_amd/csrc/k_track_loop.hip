@@ -189,48 +189,51 @@ __device__ __forceinline__ void loop_fll(gpsx_loop_state_t &s, int index, int IP
 }
 
 // nav_data.c:145-218: which millisecond of the 4 ms group holds the bit edge
-__device__ __forceinline__ void nav_refine_edge(gpsx_loop_state_t &s, const Quad16 &sip)
+// returns 0, or the edge (1 / 2) it located
+__device__ __forceinline__ int nav_refine_edge(gpsx_loop_state_t &s, const Quad16 &sip)
 {
   const int ip[4] = {sip.get(0), sip.get(1), sip.get(2), sip.get(3)};
   if (iabs(ip[1]) > iabs(ip[0]))
-    return;
+    return 0;
   if (ip[3] == 0)
-    return;
+    return 0;
   const float whole = (float)iabs(ip[0]) / (float)iabs(ip[3]);
   if (whole > 1.5f || whole < 0.7f)
-    return;
+    return 0;
   const int chip = (int16_t)((int16_t)s.code_phase_fine / 16);
   if (chip < 0 || chip > kChips)
-    return;
+    return 0;
   int edge = 0;
   if (chip < kChips / 4 || chip > kChips * 3 / 4) {
     if (ip[1] == 0)
-      return;
+      return 0;
     const float jump = (float)iabs(ip[0]) / (float)iabs(ip[1]);
     if (jump > 1.5f || jump < 0.7f)
-      return;
+      return 0;
     edge = chip < kChips / 4 ? 2 : 1;
   } else {
     const int d1 = (uint16_t)iabs(ip[0] - ip[1]), d2 = (uint16_t)iabs(ip[2] - ip[3]);
     if (d1 > d2) {
       if (d2 == 0)
-        return;
+        return 0;
       if ((float)d1 / (float)d2 < 2.5f)
-        return;
+        return 0;
       edge = 1;
     } else {
       if (d1 == 0)
-        return;
+        return 0;
       if ((float)d2 / (float)d1 < 2.5f)
-        return;
+        return 0;
       edge = 2;
     }
   }
   s.accurate_swap_time = (uint8_t)((s.slot_start_ticks + (u32)edge) % 20u);
   s.accurate_swap_ok = 1;
+  return edge;
 }
 
 // gps_nav_data_analyse_new_code on the channel's own slot state; returns flag bits 1 / 2 (a bit was completed / its value)
+// and 5 / 6 (the bit edge inside the 20 ms grid was located this millisecond / it was edge 2, not 1)
 __device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, int index, int IP, u32 now)
 {
   u32 out = 0;
@@ -283,8 +286,11 @@ __device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, i
       s.period_sync_ok_flag = 0;
   }
   s.old_swap_time = edge_time;
-  if (s.period_sync_ok_flag && flip_at == 2)
-    nav_refine_edge(s, sip);
+  if (s.period_sync_ok_flag && flip_at == 2) {
+    const int edge = nav_refine_edge(s, sip);
+    if (edge)
+      out |= 32u | (edge == 2 ? 64u : 0u);
+  }
   return out;
 }
 

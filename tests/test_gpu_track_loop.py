@@ -208,3 +208,69 @@ def test_device_loop_false_lock_jump_and_bad_prn(eng):
             eng.track_loop(stream[:4], d, 2, 0)
     finally:
         eng.free(d)
+
+
+@pytest.mark.parametrize("k", [1, 20])
+def test_word_layer_behind_the_device_loop_equals_the_host_mode(eng, k):
+    """13 s of the 4-SV stream carrying LNAV subframes (two satellites with inverted data polarity), every channel served every
+    millisecond.  Host mode: gps_tracking_process_batch all the way.  Device mode: the same until tick 600, then
+    gpsx_track_loop in launches of k ms, the flag bytes through gps_tracking_words_batch, polarity changes back through
+    gpsx_loop_set_polarity.  The word layer's whole state -- words, parity history, polarity, subframe images, subframe
+    time stamps, decoded ephemerides -- must come out the same (k = 1: a polarity change reaches the device for the next
+    millisecond exactly as in the host mode; k = 20: up to 19 ms later, which can only touch the bit being voted on while
+    the word layer is still hunting for its next preamble)."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    n_ms, t_hand = 13000, 600
+    lib = eng.lib
+    steps = sd.StepsLib(lib, False)
+    lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+    lib.gps_tracking_process_batch.restype = None
+    stream = synth.four_sv_with_lnav(n_ms, seed=7)
+    presets = [(5, 900, 200), (14, 4000, 500), (20, -1000, 1124), (30, 2000, 1624)]
+
+    def host_until(t_end):
+        table = np.stack([sd.preset_channel(steps, *p) for p in presets])
+        for t in range(t_end):
+            steps.set_time(t)
+            lib.gps_tracking_process_batch(table.ctypes.data, 4, stream[t].ctypes.data, t & 3)
+        return table
+
+    want = host_until(n_ms)
+    table = host_until(t_hand)
+    assert (table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0] == sd.TRK_RUN).all()
+    st = _states_from_records(lib, table)
+    d = eng.malloc(st.nbytes)
+    try:
+        eng.h2d(d, st)
+        changed = np.zeros(4, np.int32)
+        n_changes = 0
+        for t in range(t_hand, n_ms, k):
+            kk = min(k, n_ms - t)
+            flags, _ = eng.track_loop(stream[t:t + kk], d, 4, t)
+            n = lib.gps_tracking_words_batch(table.ctypes.data, 4, flags.ctypes.data, kk, t, changed.ctypes.data, 4)
+            if n:
+                vals = np.array([table[c, 212 + 13] for c in changed[:n]], np.uint8)
+                assert lib.gpsx_loop_set_polarity(eng.h, d, changed.ctypes.data, vals.ctypes.data, n) == 0
+                n_changes += n
+        final = np.zeros_like(st)
+        eng.d2h(final, d)
+    finally:
+        eng.free(d)
+    assert n_changes >= 2                                     # PRN 14 and PRN 30 carry inverted data
+    assert np.array_equal(final["inv_polarity_flag"], want[:, 212 + 13])
+    nav_w, nav = want[:, 212:324], table[:, 212:324]
+    # word layer: bytes 13 .. 111 of nav_data (polarity flags, word buffer and counters, parity history, time stamps, subframe
+    # image); bytes 0 .. 12 are the bit synchroniser, which lives on the device
+    assert np.array_equal(nav[:, 13:], nav_w[:, 13:]), np.argwhere(nav[:, 13:] != nav_w[:, 13:])[:6]
+    assert np.array_equal(table[:, 344:664], want[:, 344:664])  # eph_data: the decoded subframes
+    assert int(nav_w[:, 56:60].copy().view("<u4").max()) >= 1      # (parity-correct words were found: the layer did run)
+    host_side = _states_from_records(lib, want)
+    for f in ("period_sync_ok_flag", "right_period_cnt", "old_swap_time", "last_bit_pos_cnt", "last_bit_neg_cnt", "if_freq_accum"):
+        assert np.array_equal(final[f], host_side[f]), f
+    if k == 1:
+        # the located bit edge (accurate_swap_time / _ok, rebuilt on the host from flag bits 5 / 6).  Only compared at k = 1: in
+        # the host mode a polarity change takes effect in the MIDDLE of a 4 ms group, which reads as a sign flip at
+        # position 2 and can locate an "edge" there (PRN 30 on this stream); with k > 1 the change reaches the device at a
+        # launch boundary and that artefact does not happen
+        assert np.array_equal(nav[:, 9:11], nav_w[:, 9:11])
+        assert np.array_equal(final["accurate_swap_time"], host_side["accurate_swap_time"])

@@ -15,18 +15,21 @@ LANE_OPS_PER_CHANNEL_MODEL = 3 * 2048 + 511 + 1023
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9      # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 3.93e13
 
 
-def main(tag="r03_track", channels=212992):
-    channels = int(channels)
+def main(tag="r03_track", channels=212992, match="k_track_epl", ms_per_launch=1):
+    """match: substring of the kernel's name; ms_per_launch: milliseconds of stream one launch serves (k_track_loop: K) --
+    every per-channel figure below is per channel AND millisecond"""
+    channels = int(channels) * int(ms_per_launch)
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     stats_csv = os.path.join(src, "trace", "trace_kernel_stats.csv")
     shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-    rows = [r for r in csv.DictReader(open(stats_csv)) if "k_track_epl" in r["Name"]]
+    rows = [r for r in csv.DictReader(open(stats_csv)) if match in r["Name"]]
     top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     full = top["Name"]
     out = {"tag": tag, "command": f"tools/bench_track_kernel.py {channels} under rocprofv3 (one --pmc pass per counter group, "
                                   "--kernel-trace only)",
-           "kernel": "k_track_epl_wave", "channels": channels, "kernel_trace_avg_ns": float(top["AverageNs"]),
+           "kernel": full.split("(")[0], "channel_milliseconds_per_launch": channels, "ms_per_launch": int(ms_per_launch),
+           "kernel_trace_avg_ns": float(top["AverageNs"]), "kernel_trace_min_ns": float(top["MinNs"]), "kernel_trace_max_ns": float(top["MaxNs"]),
            "kernel_trace_calls": int(top["Calls"]), "counters_avg_per_launch": {}}
     for name in sorted(os.listdir(src)):
         path = os.path.join(src, name, "pmc_counter_collection.csv")
@@ -62,7 +65,11 @@ def main(tag="r03_track", channels=212992):
         d["vmem_read_instructions_per_channel"] = c["SQ_INSTS_VMEM_RD"] / channels
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         d["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
-        d["algorithmic_bytes_per_launch"] = channels * (16 + 4 + 12) + 2046
+        if int(ms_per_launch) > 1 or "loop" in match:   # k_track_loop: 96 B of state in and out per channel, K flag bytes, K blocks
+            n_real = channels // int(ms_per_launch)
+            d["algorithmic_bytes_per_launch"] = n_real * (2 * 96 + int(ms_per_launch)) + 2046 * int(ms_per_launch)
+        else:
+            d["algorithmic_bytes_per_launch"] = channels * (16 + 4 + 12) + 2046
     d["round2"] = {"kernel_trace_avg_ns": 234458.8, "valu_instructions_per_channel": 523.0,
                    "valu_issue_utilisation_4cycle_model": 0.84, "source": "profiles/r02f_track_pmc_summary.json"}
     out["derived"] = d
@@ -75,4 +82,4 @@ def main(tag="r03_track", channels=212992):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:5])
