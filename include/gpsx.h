@@ -256,7 +256,9 @@ int gpsx_track_epl_batch_dev(gpsx_ctx *ctx, const void *d_if_block, gpsx_trk_sta
  * the channels go through in n_chunks (1..16) pieces on the copy / correlate / copy pipeline, and on_chunk(user, first, n) is
  * called ON THE CALLING THREAD as soon as st[first .. first + n) and iq_out of those channels are in the caller's arrays --
  * while the GPU works on the next pieces.  Page-locked arrays (gpsx_host_alloc) make the copies asynchronous.  Returns after
- * the last callback; the PRN verdict is the whole step's. */
+ * the last callback; the PRN verdict is the whole step's.  The callback must not call into the SAME context (its arena and
+ * side streams are in use by the pieces still in flight): every gpsx_* entry point on it returns GPSX_EINVAL while a callback
+ * runs; other contexts are free. */
 typedef void (*gpsx_track_chunk_fn)(void *user, int first_channel, int n_channels);
 int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_t *st, int n_ch, int16_t *iq_out,
                                  int n_chunks, gpsx_track_chunk_fn on_chunk, void *user);

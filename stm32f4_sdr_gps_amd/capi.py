@@ -376,10 +376,22 @@ class Engine:
         assert states.dtype == TRK_DTYPE and states.flags.c_contiguous
         blk = np.ascontiguousarray(if_block, np.uint8)
         iq = np.zeros((len(states), 6), np.int16) if iq_out is None else iq_out
-        cb = TRACK_CHUNK_FN(lambda user, first, n: on_chunk(first, n))
-        self._chk(self.lib.gpsx_track_epl_batch_chunked(self.h, blk.ctypes.data, states.ctypes.data, len(states),
-                                                        iq.ctypes.data, n_chunks, cb, None),
-                  "gpsx_track_epl_batch_chunked")
+        assert iq.dtype == np.int16 and iq.flags.c_contiguous and iq.shape == (len(states), 6)
+        raised = []
+
+        def trampoline(user, first, n):   # (ctypes would print and swallow an exception raised inside the callback)
+            if not raised:
+                try:
+                    on_chunk(first, n)
+                except BaseException as exc:   # noqa: BLE001 -- re-raised below, on the caller's stack
+                    raised.append(exc)
+
+        cb = TRACK_CHUNK_FN(trampoline)
+        rc = self.lib.gpsx_track_epl_batch_chunked(self.h, blk.ctypes.data, states.ctypes.data, len(states),
+                                                   iq.ctypes.data, n_chunks, cb, None)
+        if raised:
+            raise raised[0]
+        self._chk(rc, "gpsx_track_epl_batch_chunked")
         return iq
 
     def track_loop(self, if_blocks: np.ndarray, d_state: int, n_ch: int, first_tick: int, want_trace=False):

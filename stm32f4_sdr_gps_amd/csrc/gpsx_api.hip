@@ -587,9 +587,16 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     }
     if (mx) {
       uint32_t *d_planes = nullptr;
-      if (g->n_ms == 1 && n_bits == 8 && shard_count == 1 && !ctx->no_split && 2 * clusters <= ctx->prop.multiProcessorCount &&
-          ensure_acc(ctx, gpsx_acq_peaks_count(g)) == GPSX_OK)
-        d_planes = ctx->d_acc;
+      // the split form's result planes: launches of at most half a round of the chip, and launches of whole rounds plus a
+      // last one that fills at most half of it (launch_acq_mx hands that tail to the split form)
+      const long cus = ctx->prop.multiProcessorCount, tail = clusters % cus;
+      if (g->n_ms == 1 && n_bits == 8 && shard_count == 1 && !ctx->no_split &&
+          (2 * clusters <= cus || (clusters > cus && tail > 0 && 2 * tail <= cus))) {
+        if (ensure_acc(ctx, gpsx_acq_peaks_count(g)) == GPSX_OK)
+          d_planes = ctx->d_acc;
+        else
+          (void)hipGetLastError();   // (no memory for the planes: the unsplit form runs; the error must not stick to its launch)
+      }
       ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
                                        ctx->d_grid_mx_t, d_peaks, ctx->d_energy, mx_blocks, gpsx_acq_peaks_count(g), d_planes,
                                        ctx->prop.multiProcessorCount);
@@ -952,7 +959,9 @@ static int track_pipeline_run(gpsx_ctx *ctx, const uint8_t *d_if, gpsx_trk_state
       while ((q = hipEventQuery(ctx->chunk_events[3 * c + 2])) == hipErrorNotReady)
         __builtin_ia32_pause();
       CHUNKCHK(q);
+      ctx->in_chunk_callback = true;    // (the callback may not call into THIS context: use_device refuses)
       on_chunk(user, first, std::min(per, n_ch - first));
+      ctx->in_chunk_callback = false;
     }
   }
 #undef CHUNKCHK

@@ -57,6 +57,7 @@ struct gpsx_ctx {
                                      // implies $GPSX_ACQ_ALGO=poly unless another algorithm was named
   int track_wave_from = 1;           // $GPSX_TRACK_WAVE_FROM: channels from which k_track_epl_wave serves the step (default: always;
                                      // a large value selects the workgroup-per-channel kernel: tests, A/B)
+  bool in_chunk_callback = false;    // set around the on_chunk calls of gpsx_track_epl_batch_chunked: entry points refuse re-entry
   bool no_split = false;             // $GPSX_ACQ_NO_SPLIT: small single-block fine grids stay one workgroup per cluster (tests, A/B)
   int ms_mode = 0;                   // $GPSX_ACQ_MS_MODE = walk | blocks: force one multi-block form (tests, A/B); 0 = by size
   uint32_t *d_energy = nullptr;      // poly, n_ms > 1: running per-hypothesis sums between blocks (grow-only)
@@ -148,6 +149,11 @@ inline int use_device(gpsx_ctx *ctx)
 {
   if (!ctx)
     return GPSX_EINVAL;
+  if (ctx->in_chunk_callback) {
+    // gpsx_track_epl_batch_chunked is still using the context's arena and side streams while its callback runs: an entry
+    // point that resets the arena or grows a buffer would pull them from under the pieces in flight
+    return fail(ctx, GPSX_EINVAL, "called from inside a gpsx_track_epl_batch_chunked callback (use another context there)");
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device));
   return GPSX_OK;
 }

@@ -1,6 +1,11 @@
 // gpsx_group.hip -- the sharded sweep inside one process: contexts joined by RCCL communicators (include/gpsx.h), host code.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>   // declarations only: the library is dlopen'ed
+#define GPSX_HAVE_RCCL_HEADERS 1
+#else                    // a ROCm install without the RCCL development headers still builds the single-GPU library
+#define GPSX_HAVE_RCCL_HEADERS 0
+#endif
 
 #include <new>
 
@@ -9,6 +14,19 @@
 using namespace gpsx_host;
 
 /* ---- multi-GPU group: RCCL inside one process ------------------------------------------------------------------- */
+#if !GPSX_HAVE_RCCL_HEADERS
+// built without <rccl/rccl.h>: the group entry points exist and say so; everything single-GPU is unaffected
+struct gpsx_group {};
+int gpsx_group_create(gpsx_ctx *const *ctxs, int n, gpsx_group **)
+{
+  return ctxs && n > 0 && ctxs[0] ? fail(ctxs[0], GPSX_ENODEV, "group: this libgpsx was built without the RCCL headers") : GPSX_EINVAL;
+}
+void gpsx_group_destroy(gpsx_group *) {}
+int gpsx_acq_grid_sharded(gpsx_group *, const gpsx_acq_grid_t *, const void *const *, int, gpsx_peak_t *const *, int64_t *const *)
+{
+  return GPSX_ENODEV;
+}
+#else
 
 namespace {
 
@@ -130,3 +148,4 @@ int gpsx_acq_grid_sharded(gpsx_group *grp, const gpsx_acq_grid_t *g, const void 
     return fail(grp->ctxs[0], GPSX_EIO, std::string("ncclAllReduce: ") + r.GetErrorString(rc != ncclSuccess ? rc : rc_end));
   return GPSX_OK;
 }
+#endif   // GPSX_HAVE_RCCL_HEADERS

@@ -1589,6 +1589,30 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks);
     return "k_acq_mx<5>";
   }
+  // One workgroup per cluster and CU: a launch is rounds of n_cus clusters, and a last round that fills at most half of the
+  // chip takes as long as a full one.  Then the full rounds go out as they are and the leftover clusters in the split form
+  // behind them -- 2, 4 or 8 workgroups per cluster, as many as still fit ONE round, each with a run of sample offsets it
+  // starts directly (16 captures = 336 clusters: 256 + 80 x 2; 64 captures = 1344: 1280 + 64 x 4).
+  const int nc = c_hi - c_lo, tail = nc % n_cus;
+  if (d_planes && nc > n_cus && tail > 0 && 2 * tail <= n_cus) {
+    const int c_tail = c_hi - tail;
+    hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(nc - tail)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
+                       d_peaks, (u32 *)nullptr, (u32 *)nullptr);
+    AcqParams sp = prm;
+    sp.split_segs = 8 * tail <= n_cus ? 8 : 4 * tail <= n_cus ? 4 : 2;
+    sp.n_planes = n_peaks;
+    // the planes of the tail's peaks only: from the first peak of the search the tail begins in
+    const int n_sets = (prm.n_groups + 3) / 4;
+    const size_t per_search = (size_t)prm.n_prn * prm.n_dopp * prm.n_bits;
+    const size_t first = (size_t)(c_tail / (n_sets * prm.n_dopp)) * per_search;
+    (void)hipMemsetAsync(d_planes + first, 0, (n_peaks - first) * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(d_planes + n_peaks + first, 0, (n_peaks - first) * sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * tail)), dim3(kMxThreads), 0, s, sp, c_tail, d_if,
+                       d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);
+    launch_acq_finalize_from(s, d_planes, d_planes + n_peaks, first, n_peaks, d_peaks, prm.n_prn, prm.n_dopp, prm.n_bits, n_sets,
+                             c_tail);
+    return "k_acq_mx<0>";
+  }
   hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                      d_peaks, (u32 *)nullptr, (u32 *)nullptr);
   return "k_acq_mx<0>";

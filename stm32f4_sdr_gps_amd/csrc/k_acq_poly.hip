@@ -525,6 +525,30 @@ __global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__rest
   peaks[idx] = pk;
 }
 
+// The same for the peaks of clusters >= cluster_from only (a launch whose last, partly filled round went to the split form:
+// the full rounds' workgroups wrote their triplets themselves).  Peak idx = ((search n_prn + prn) n_dopp + dopp) n_bits + b;
+// cluster = (search n_dopp + dopp) n_sets + prn / 32.
+__global__ void k_acq_finalize_from(const u32 *__restrict__ keyacc, const u32 *__restrict__ sumacc, size_t first, size_t n,
+                                    gpsx_peak_t *__restrict__ peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from)
+{
+  const size_t idx = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n)
+    return;
+  const size_t pd = idx / (size_t)n_bits;
+  const int dopp = (int)(pd % (size_t)n_dopp);
+  const size_t sp = pd / (size_t)n_dopp;
+  const int prn = (int)(sp % (size_t)n_prn), search = (int)(sp / (size_t)n_prn);
+  if ((search * n_dopp + dopp) * n_sets + prn / 32 < cluster_from)
+    return;
+  const u32 k = keyacc[idx], t = sumacc[idx];
+  gpsx_peak_t pk;
+  pk.max_val = k >> 11;
+  pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
+  pk.sum = t;
+  pk.avr = t / (2u * kChips);
+  peaks[idx] = pk;
+}
+
 // Multi-block searches handled block-parallel (k_acq_poly<.., kPolyStore> wrote every block's magnitudes): sum over the
 // blocks, then correlation_search's max / first argmax / sum over the window, per replica bit shift.  One workgroup per
 // (search, PRN, Doppler) this shard owns; 32 KB per block read once, coalesced.
@@ -594,6 +618,15 @@ void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t
 {
   hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
                      d_peaks);
+}
+
+void launch_acq_finalize_from(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t first, size_t n_peaks,
+                              gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from)
+{
+  if (first >= n_peaks)
+    return;
+  hipLaunchKernelGGL(k_acq_finalize_from, dim3((unsigned)((n_peaks - first + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
+                     first, n_peaks, d_peaks, n_prn, n_dopp, n_bits, n_sets, cluster_from);
 }
 
 const char *launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,

@@ -1539,3 +1539,40 @@ def test_track_epl_wave_form_channel_counts_and_channels_per_wave(oracle, stream
             assert np.array_equal(iq_small, iq[:256][:len(small)]) and np.array_equal(small, st[:256]), n
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("n", [13, 16, 70])
+def test_last_partly_filled_round_of_a_launch_goes_to_the_split_form(n, oracle, monkeypatch):
+    """k_acq_mx<0> runs one workgroup per (capture, Doppler) cluster and CU: a launch is rounds of 256 clusters.  When the last
+    round fills at most half the chip, the full rounds go out as they are and the leftover clusters in the split form
+    (k_acq_mx<5>: 2, 4 or 8 workgroups per cluster, each started directly at its own sample offset, results merged through two
+    planes and converted for those clusters only).  13 captures = 273 clusters = 256 + 17 x 8, the tail beginning in the
+    middle of capture 12's Doppler bins; 16 = 336 = 256 + 80 x 2; 70 = 1470 = 5 x 256 + 190: more than half a round, no tail.
+    Every capture must equal its launch on a context that never splits, byte for byte; the captures around the seam
+    also equal the oracle."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    e = capi.Engine(0)
+    monkeypatch.setenv("GPSX_ACQ_NO_SPLIT", "1")
+    plain = capi.Engine(0)
+    monkeypatch.delenv("GPSX_ACQ_NO_SPLIT")
+    try:
+        assert e.device_info()[1] == 256
+        blocks = synth.cold_start_block(n, seed=23, amp_scale=0.5)
+        prns = np.arange(1, 33, dtype=np.uint8)
+        kw = dict(dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
+        pk, keys = e.acq_grid(blocks, prns, n_search=n, **kw)
+        assert e.lib.gpsx_last_kernel(e.h) == b"k_acq_mx<0>"
+        pk0, keys0 = plain.acq_grid(blocks, prns, n_search=n, **kw)
+        assert pk.tobytes() == pk0.tobytes() and np.array_equal(keys, keys0)
+        seam = {13: (11, 12), 16: (12, 13, 15), 70: (69,)}[n]
+        for i in seam:
+            want = oracle.acq_grid(blocks[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+            for f in ("max_val", "phase", "sum", "avr"):
+                assert np.array_equal(pk[i][f], want[f]), (i, f)
+        # windows reach the tail too
+        pkw, _ = e.acq_grid(blocks, prns, n_search=n, win=(300, 1700), **kw)
+        pkw0, _ = plain.acq_grid(blocks, prns, n_search=n, win=(300, 1700), **kw)
+        assert pkw.tobytes() == pkw0.tobytes()
+    finally:
+        e.close()
+        plain.close()

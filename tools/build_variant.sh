@@ -1,7 +1,7 @@
 # builds stm32f4_sdr_gps_amd/lib/libgpsx_b.so from the k_acq_mx.hip of the working tree (-DMX_VARIANT_B is defined for an
 # #ifdef'd alternative, if the source carries one) for same-box A/B timings -- boxes differ by +-3 %:
 #   git stash; bash tools/build_variant.sh; git stash pop; make -C stm32f4_sdr_gps_amd/csrc      # B = HEAD, A = working tree
-#   bash tools/gpu_ab.sh        (on the GPU box: alternates A and B through $GPSX_LIB of tools/bench_grid_kernel.py)
+#   bash tools/gpu_validate.sh ab   (on the GPU box: alternates A and B through $GPSX_LIB of tools/bench_grid_kernel.py)
 set -e
 cd "$(dirname "$0")/../stm32f4_sdr_gps_amd/csrc"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -fno-fast-math -Wno-unused-function"

@@ -41,7 +41,16 @@ def main(tag="r02", searches=256, n_ms=1, pattern=None):
                                        "rocprofv3 --pmc pass per counter group, --kernel-trace only); kernel trace: --steps 20",
                "kernel": kernel, "kernel_full_name": full_name, "searches_per_launch": searches, "n_ms": n_ms,
                "kernel_trace_avg_ns": float(top["AverageNs"]), "kernel_trace_calls": int(top["Calls"]),
+               "kernel_trace_min_ns": float(top["MinNs"]), "kernel_trace_max_ns": float(top["MaxNs"]),
+               "kernel_trace_stddev_ns": float(top["StdDev"]),
                "counters_avg_per_launch": {}}
+    # the median of the launches (the mean of a 20-launch trace moves with one slow launch): from the per-dispatch trace
+    trace_csv = os.path.join(src, "trace", "trace_kernel_trace.csv")
+    if os.path.exists(trace_csv):
+        durs = sorted(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace_csv))
+                      if r.get("Kernel_Name") == full_name)
+        if durs:
+            summary["kernel_trace_median_ns"] = durs[len(durs) // 2] if len(durs) % 2 else 0.5 * (durs[len(durs) // 2 - 1] + durs[len(durs) // 2])
     for name in sorted(os.listdir(src)):
         path = os.path.join(src, name, "pmc_counter_collection.csv")
         if not name.startswith("pmc_") or not os.path.exists(path):
