@@ -498,6 +498,8 @@ int ensure_acc(gpsx_ctx *ctx, size_t n_peaks)
   ctx->d_acc = nullptr;
   ctx->acc_entries = 0;
   HIPCHK(ctx, hipMalloc((void **)&ctx->d_acc, 2 * n_peaks * sizeof(uint32_t)));
+  // all-zero from here on: the kernels accumulate into it with atomics, k_acq_finalize* zeroes every entry it converts
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_acc, 0, 2 * n_peaks * sizeof(uint32_t), ctx->stream));
   ctx->acc_entries = n_peaks;
   return GPSX_OK;
 }
@@ -641,15 +643,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   }
   if (poly) {
     const size_t n_peaks = gpsx_acq_peaks_count(g);
-    if (n_peaks > ctx->acc_entries) {
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->d_acc)
-        (void)hipFree(ctx->d_acc);
-      ctx->d_acc = nullptr;
-      ctx->acc_entries = 0;
-      HIPCHK(ctx, hipMalloc((void **)&ctx->d_acc, 2 * n_peaks * sizeof(uint32_t)));
-      ctx->acc_entries = n_peaks;
-    }
+    if (int rc = ensure_acc(ctx, n_peaks))   // (zeroed when allocated, kept zero by k_acq_finalize)
+      return rc;
     ctx->last_kernel = launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
                     ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1,
                     ctx->d_energy, block_parallel, ctx->seg_force);

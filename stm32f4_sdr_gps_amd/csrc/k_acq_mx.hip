@@ -1582,8 +1582,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
       const int v = std::atoi(e);
       sp.split_segs = v == 8 ? 8 : v == 4 ? 4 : 2;
     }
-    (void)hipMemsetAsync(d_planes, 0, 2 * n_peaks * sizeof(uint32_t), s);
-    sp.n_planes = n_peaks;
+    sp.n_planes = n_peaks;   // (the planes are all-zero between launches: k_acq_finalize puts back what it reads)
     hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * (c_hi - c_lo))), dim3(kMxThreads), 0, s, sp, c_lo, d_if,
                        d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);
     launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks);
@@ -1605,8 +1604,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     const int n_sets = (prm.n_groups + 3) / 4;
     const size_t per_search = (size_t)prm.n_prn * prm.n_dopp * prm.n_bits;
     const size_t first = (size_t)(c_tail / (n_sets * prm.n_dopp)) * per_search;
-    (void)hipMemsetAsync(d_planes + first, 0, (n_peaks - first) * sizeof(uint32_t), s);
-    (void)hipMemsetAsync(d_planes + n_peaks + first, 0, (n_peaks - first) * sizeof(uint32_t), s);
+    // (no memset: the planes are all-zero between launches, k_acq_finalize* puts back what it reads)
     hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * tail)), dim3(kMxThreads), 0, s, sp, c_tail, d_if,
                        d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);
     launch_acq_finalize_from(s, d_planes, d_planes + n_peaks, first, n_peaks, d_peaks, prm.n_prn, prm.n_dopp, prm.n_bits, n_sets,

@@ -510,13 +510,16 @@ __global__ __launch_bounds__(kThreads, MODE == kPolyMulti ? 2 : 3) void k_acq_po
 }
 
 // (packed key, sum) planes -> gpsx_peak_t
-__global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__restrict__ sumacc, size_t n,
-                               gpsx_peak_t *__restrict__ peaks)
+// The planes are all-zero between launches (allocated so, and every entry read here is put back to zero): no memset in front of
+// the kernels that accumulate into them.
+__global__ void k_acq_finalize(u32 *__restrict__ keyacc, u32 *__restrict__ sumacc, size_t n, gpsx_peak_t *__restrict__ peaks)
 {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n)
     return;
   const u32 k = keyacc[idx], t = sumacc[idx];
+  keyacc[idx] = 0u;
+  sumacc[idx] = 0u;
   gpsx_peak_t pk;
   pk.max_val = k >> 11;
   pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
@@ -528,7 +531,7 @@ __global__ void k_acq_finalize(const u32 *__restrict__ keyacc, const u32 *__rest
 // The same for the peaks of clusters >= cluster_from only (a launch whose last, partly filled round went to the split form:
 // the full rounds' workgroups wrote their triplets themselves).  Peak idx = ((search n_prn + prn) n_dopp + dopp) n_bits + b;
 // cluster = (search n_dopp + dopp) n_sets + prn / 32.
-__global__ void k_acq_finalize_from(const u32 *__restrict__ keyacc, const u32 *__restrict__ sumacc, size_t first, size_t n,
+__global__ void k_acq_finalize_from(u32 *__restrict__ keyacc, u32 *__restrict__ sumacc, size_t first, size_t n,
                                     gpsx_peak_t *__restrict__ peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from)
 {
   const size_t idx = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,6 +544,8 @@ __global__ void k_acq_finalize_from(const u32 *__restrict__ keyacc, const u32 *_
   if ((search * n_dopp + dopp) * n_sets + prn / 32 < cluster_from)
     return;
   const u32 k = keyacc[idx], t = sumacc[idx];
+  keyacc[idx] = 0u;
+  sumacc[idx] = 0u;
   gpsx_peak_t pk;
   pk.max_val = k >> 11;
   pk.phase = pk.max_val ? 2047u - (k & 2047u) : 0u;
@@ -613,14 +618,14 @@ void launch_acq_vals_search(hipStream_t s, const AcqParams &prm, const uint16_t 
   hipLaunchKernelGGL(k_acq_vals_search, dim3((unsigned)(n_peaks / 8)), dim3(kThreads), 0, s, prm, d_vals, d_peaks);
 }
 
-void launch_acq_finalize(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t n_peaks,
+void launch_acq_finalize(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks)
 {
   hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
                      d_peaks);
 }
 
-void launch_acq_finalize_from(hipStream_t s, const uint32_t *d_keyacc, const uint32_t *d_sumacc, size_t first, size_t n_peaks,
+void launch_acq_finalize_from(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t first, size_t n_peaks,
                               gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from)
 {
   if (first >= n_peaks)
@@ -670,7 +675,7 @@ const char *launch_acq_poly(hipStream_t s, long local_units, const AcqParams &pr
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
     return "k_acq_poly<8,16,0>";
   }
-  (void)hipMemsetAsync(d_keyacc, 0, 2 * n_peaks * sizeof(uint32_t), s);   // d_sumacc = d_keyacc + n_peaks
+  // (d_sumacc = d_keyacc + n_peaks; the planes are all-zero between launches: k_acq_finalize puts back what it reads)
   if (seg == 4)
     hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 4, kPolySingle>), dim3((unsigned)(wg16 * 4)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
