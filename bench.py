@@ -52,18 +52,18 @@ BYTES_PER_HYP = 6138                                 # I + Q + r
 LANE_OPS_PER_HYP_REF = 2048                          # 1024 xor + 1024 bcnt (the reference's formulation)
 HBM_PEAK_GBS = 8000.0                                # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_INT_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12         # 39.3 T lane-ops/s: 64 int lanes/clk/CU measured (tools/microbench)
-# Lower bound of the polyphase formulation itself, lane-ops per hypothesis: 2 streams x 32 words x
+# Lower bound of the polyphase formulation itself, lane-ops per hypothesis (EXPERIMENTS.md "4.1b"): 2 streams x 32 words x
 # (v_and + accumulating v_bcnt) = 128 for the bit-plane correlation, 4 for the recurrence M += X(q+1) - X(q), and the
 # cheapest epilogue that still yields the reference's integers (2 centre/scale, 2 clips, 2 squares+add, 4 issue slots of
 # quarter-rate v_sqrt_f32, 1 truncate, 3 for key/max/sum) = 14
 LANE_OPS_PER_HYP_MIN_MODEL = 146
-# Matrix-core kernel (k_acq_mx, DESIGN.md 4.1d): the correlations of one (search, Doppler) pair x 32 PRNs are 17 FP4 GEMM
+# Matrix-core kernel (k_acq_mx, DESIGN.md 4.1): the correlations of one (search, Doppler) pair x 32 PRNs are 17 FP4 GEMM
 # passes (2 for the first sample offset, 15 recurrence steps) x 2 streams of M = 32 PRNs, N = 1024 chip offsets, K = 1024
 # chips: 2 * 32 * 1024 * 1024 flops each -> per hypothesis (32 PRN x 16368 phases per pair) 17 * 2 * 2 * 1024 * 1024 / 16368
 MFMA_FLOPS_PER_HYP = 17 * 2 * 2.0 * 32 * 1024 * 1024 / (32 * 16368)      # = 4356 algorithmic FP4 flops per hypothesis
 MFMA_FP4_PEAK_TFLOPS = 10000.0                       # MI355X_MICROARCH.md: ~10 PF dense MX-FP4 (9.1 PF micro-benchmarked)
 LANE_OPS_PER_HYP_MIN_MODEL_MX = 10.25                # the kernel's own formulation, per hypothesis: 2 clip-squares, add, fma,
-                                                     # root, rounding add, key, 1/2 max3, 1/2 add3 = 8 (DESIGN.md 4.1d) + the
+                                                     # root, rounding add, key, 1/2 max3, 1/2 add3 = 8 (DESIGN.md 4.1) + the
                                                      # MFMAs' own issue slots, 17 x 136 x 8 per 8192 lane-hypotheses = 2.25
 
 

@@ -20,7 +20,7 @@
 // and walks the anti-diagonals f = Q + 2 kappa, 19 fragment loads for 64 MFMAs per stream.
 //
 // Nothing linear is left to the vector ALU.  What the reference's quirks add to a popcount is linear in chip bits
-// (DESIGN.md 4.1d), so it rides in the same accumulators: the accumulator of (q, PRN p) holds, after the pass of sample
+// (DESIGN.md 4.1), so it rides in the same accumulators: the accumulator of (q, PRN p) holds, after the pass of sample
 // offset t0, exactly  cnt(q, t0, p) - 8184  -- the number gps_correlation8 clips and squares:
 //   * the vector carries -2 e (values 0, +-2), the accumulators start at pop(D) + 8192 - 8184 (or at -2^20 for byte offsets
 //     outside the search window: they clip to zero by themselves);
