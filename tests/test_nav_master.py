@@ -189,3 +189,83 @@ def test_perfect_channels_through_the_step_and_the_solver_return_the_receiver_po
     ref = int(np.argmin([ch.nav_data.last_subframe_time for ch in table]))
     assert abs(sol2.dtr[0]) < 2e-3
     assert table[ref].obs_data.pseudorange_m <= min(ch.obs_data.pseudorange_m for ch in table) + 1e-3 * CLIGHT
+
+
+_WORDS_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import pvt_chain as pc
+from pvt_types import geodetic_to_ecef
+from stm32f4_sdr_gps_amd import build
+lib = C.CDLL(build.build())
+lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
+rx = geodetic_to_ecef(48.1374, 11.5755, 520.0)
+n, K, n_ms = 40, 20, 54000
+sats = pc.pick_satellites(rx, 388800, 4, seed=29)
+streams = [pc.lnav_stream(sats[c % 4][0], 64800, 10, 500 + c % 4, cycle=3) for c in range(n)]
+inverted = np.array([c % 3 == 1 for c in range(n)])          # these channels' Costas loops locked upside down
+offset = np.array([(7 * c) % 20 for c in range(n)])           # bit edges at different milliseconds of the 20 ms grid
+table = (pc.GpsCh * n)()
+for c in range(n):
+    table[c].prn = sats[c % 4][1]["sat"]
+inv_dev = np.zeros(n, np.uint8)                               # the device's copy of inv_polarity_flag
+changed = np.zeros(n, np.int32)
+n_changed = 0
+for t0 in range(0, n_ms, K):
+    flags = np.zeros((K, n), np.uint8)
+    for ms in range(K):
+        t = t0 + ms
+        for c in range(n):
+            f = 8                                             # bit period synchronised
+            k = (t - offset[c]) // 20                         # the bit that completes at this millisecond
+            if (t - offset[c]) % 20 == 0 and k >= 1:
+                bit = int(streams[c][k - 1]) ^ int(inverted[c]) ^ int(inv_dev[c])
+                f |= 2 | (bit << 2)
+            if t == 3 + offset[c]:                            # the bit edge located once, at index 3 of its group: edge 1
+                f |= 32
+            flags[ms, c] = f
+    m = lib.gps_tracking_words_batch(table, n, flags.ctypes.data, K, t0, changed.ctypes.data, n)
+    for c in changed[:m]:
+        inv_dev[c] = table[c].nav_data.inv_polarity_flag      # gpsx_loop_set_polarity
+    n_changed += m
+out = []
+for c in range(n):
+    ch = table[c]
+    out.append((ch.eph_data.received_mask_proc, ch.nav_data.word_cnt_test, ch.nav_data.subframe_cnt, ch.nav_data.last_subframe_time,
+                ch.nav_data.inv_polarity_flag, ch.nav_data.accurate_swap_time, ch.eph_data.eph.A == sats[c % 4][1]["A"],
+                ch.eph_data.eph.M0 == sats[c % 4][1]["M0"], ch.eph_data.tow_gpst))
+print("RESULT", n_changed, repr(out))
+"""
+
+
+def test_word_layer_batch_decodes_lnav_from_the_device_loops_flag_bytes():
+    """gps_tracking_words_batch (host code: the word layer behind the device tracking loops) on synthetic flag bytes: 40
+    channels whose completed navigation bits are parity-correct LNAV subframes carrying four satellites' ephemerides, bit
+    edges at different milliseconds, every third channel inverted until the word layer finds it out (two inverted
+    preambles) and reports the channel for gpsx_loop_set_polarity.  Every channel must end with subframes 1-3 decoded into
+    the transmitted elements, a subframe stamp on its own bit edge, and the same result on one thread and on worker threads."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"GPSX_STEP_THREADS": "3", "GPSX_STEP_THREADS_FROM": "8"}):
+        r = subprocess.run([sys.executable, "-c", _WORDS_SCRIPT, root], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        outs.append(line[0])
+    assert outs[0] == outs[1]
+    n_changed = int(outs[0].split()[1])
+    rows = eval(outs[0].split(" ", 2)[2], {"np": np})
+    assert n_changed == sum(1 for c in range(40) if c % 3 == 1)
+    for c, (mask, words, subframes, last, inv, swap, a_ok, m0_ok, tow) in enumerate(rows):
+        assert (mask & 7) == 7 and a_ok and m0_ok, c
+        assert words >= 30 and subframes >= 3, (c, words, subframes)   # (a false preamble inside one satellite's payload costs the
+        #                                                                  inverted channels on it a subframe: hence 54 s, not 36)
+        assert inv == (1 if c % 3 == 1 else 0), c
+        off = (7 * c) % 20
+        assert swap == (3 + off - 3 + 1) % 20, (c, swap)                       # edge 1 located at tick 3 + off
+        assert last % 20 == swap and 40000 < last <= 54000, (c, last)           # the stamp sits on the channel's own bit edge
+        assert tow % 6 == 0 and tow > 388800
