@@ -148,6 +148,10 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     ctx->seg_force = (v == 4 || v == 8 || v == 16) ? v : 0;
   }
   ctx->no_split = std::getenv("GPSX_ACQ_NO_SPLIT") != nullptr;
+  if (const char *sp = std::getenv("GPSX_ACQ_SPLIT")) {
+    const int v = std::atoi(sp);
+    ctx->split_force = v == 8 ? 8 : v == 4 ? 4 : 2;
+  }
   if (const char *w = std::getenv("GPSX_TRACK_WAVE_FROM"))
     ctx->track_wave_from = std::atoi(w) > 0 ? std::atoi(w) : 1;
   if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
@@ -530,6 +534,7 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     HIPCHK(ctx, hipMemsetAsync(d_peaks, 0, gpsx_acq_peaks_count(g) * sizeof(gpsx_peak_t), ctx->stream));
   }
   AcqParams prm{};
+  prm.split_segs = ctx->split_force;   // 0: launch_acq_mx picks by launch size
   prm.n_ms = g->n_ms;
   prm.search_stride_blocks = g->search_stride_blocks;
   prm.n_prn = g->n_prn;

@@ -1578,10 +1578,8 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     AcqParams sp = prm;
     const int nc = c_hi - c_lo;
     sp.split_segs = 8 * nc <= n_cus ? 8 : 4 * nc <= n_cus ? 4 : 2;   // (a lone cold start: 21 clusters -> 168 workgroups)
-    if (const char *e = std::getenv("GPSX_ACQ_SPLIT")) {   // (tests, A/B: 2, 4 or 8 whatever the launch size)
-      const int v = std::atoi(e);
-      sp.split_segs = v == 8 ? 8 : v == 4 ? 4 : 2;
-    }
+    if (prm.split_segs)   // ($GPSX_ACQ_SPLIT, read when the context was created: 2, 4 or 8 whatever the launch size -- tests, A/B)
+      sp.split_segs = prm.split_segs;
     sp.n_planes = n_peaks;   // (the planes are all-zero between launches: k_acq_finalize puts back what it reads)
     hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * (c_hi - c_lo))), dim3(kMxThreads), 0, s, sp, c_lo, d_if,
                        d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);

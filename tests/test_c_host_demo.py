@@ -97,3 +97,41 @@ def test_c_coldstart_finds_the_satellites_of_a_recording(coldstart_exe, tmp_path
         #  whose residual carrier keeps I and Q positive over the window)
         assert abs(found[prn][0] - dopp) <= 750 and abs(found[prn][1] - delay) <= 2 and found[prn][2] > 2.5, (prn, found[prn])
     assert f"hypotheses={32 * 21 * 16368 * 4}" in out
+
+
+@pytest.fixture(scope="module")
+def track_loop_exe():
+    from stm32f4_sdr_gps_amd import build
+    build.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "gpsx_track_loop"], stdout=subprocess.DEVNULL)
+    return os.path.join(ROOT, "examples", "gpsx_track_loop")
+
+
+def test_c_track_loop_host_builds(track_loop_exe):
+    assert os.access(track_loop_exe, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_c_track_loop_host_ends_in_the_reference_state(track_loop_exe, tmp_path):
+    """examples/gpsx_track_loop.c: host mode to tick 600, then the tracking loops on the GPU (K = 20 ms per launch) to the end of
+    the 2500 ms stream -- code phase, carrier and NCO accumulator of every channel must be, bit for bit, what the reference's
+    own gps_tracking_process reaches on that stream (tests/golden/f7_steps_continuous.npz)."""
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_continuous.npz")
+    n_ms = int(g["n_ms"])
+    cap = tmp_path / "rec_file.bin"
+    synth.four_sv_with_nav(n_ms, seed=7).tofile(cap)
+    presets = [f"{int(p)}:{int(f)}:{int(c)}" for p, f, c in zip(g["prns"], g["found_freq"], g["found_phase"])]
+    out = subprocess.run([track_loop_exe, str(cap), "600"] + presets, capture_output=True, text=True, check=True).stdout
+    lines = [l for l in out.splitlines() if l.startswith("PRN=")]
+    assert len(lines) == 4 and f"processed_ms={n_ms} handed_over_at_ms=600" in out
+    last = g["snaps"][-1]
+    for i, line in enumerate(lines):
+        m = re.search(r"trk_state=(\d+) code_phase_fine=\S+\(0x(\w+)\) if_freq_offset_hz=\S+\(0x(\w+)\) nco=0x(\w+) snr_db=\S+ "
+                      r"bit_sync=(\d+) false_lock_jumps=(\d+)", line)
+        a = last[i]
+        assert int(m.group(1)) == 4 and int(m.group(6)) == 0
+        assert int(m.group(2), 16) == int(a[60 + 80:60 + 84].view("<u4")[0])
+        assert int(m.group(3), 16) == int(a[60 + 4:60 + 8].view("<u4")[0])
+        assert int(m.group(4), 16) == int(a[60 + 8:60 + 12].view("<u4")[0])
+        assert int(m.group(5)) == int(a[212])
