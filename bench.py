@@ -213,6 +213,7 @@ def tracking_device_loop(ms=1200, k=20):
             "per_ms_p50_us", "per_ms_max_us", "gpu_part_p50_us", "warmup_max_us", "real_time", "behind_at_end_ms", "host_workers",
             "channels_handed_over_tracking", "code_and_carrier_lock", "false_lock_jumps")
     per_ms = mod.device_loop(256, ms, 1, 32)            # K = 1: the per-millisecond latency, comparable with the host loop's
+    literal = mod.device_loop(256, 10000, k, 0, literal=True)   # SURVEY.md 8(d) config 5 to the letter, loops on the device
     rows, best, missed = [], None, False
     for n in (256, 65536, 262144, 524288, 1048576, 1572864, 2097152):
         r = mod.device_loop(n, ms, k, 32)
@@ -225,7 +226,9 @@ def tracking_device_loop(ms=1200, k=20):
     return {"metric": "closed-loop real-time tracking channels with the loops on the device: largest count of the ladder whose "
                       "launches (K ms of stream each) ALL come back inside K ms, at that count and every smaller one",
             "value": best, "ms_per_launch": k, "ms_per_count": ms, "signals_in_stream": 32,
-            "per_millisecond_launches_256_channels": {kk: per_ms[kk] for kk in keep}, "ladder": rows,
+            "per_millisecond_launches_256_channels": {kk: per_ms[kk] for kk in keep},
+            "config5": {kk: literal[kk] for kk in keep + ("ms", "signals_in_stream", "code_and_carrier_lock_in_the_reference_on_this_stream")},
+            "ladder": rows,
             "note": "ONE run per count; steady state = second half of each run.  With K ms per launch the deadline is K ms: a host "
                     "thread that another tenant holds up for a few milliseconds delays a launch, it does not miss one -- the "
                     "per-millisecond work is on the GPU"}

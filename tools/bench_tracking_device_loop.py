@@ -33,19 +33,19 @@ _cache = {}
 T_HAND = 240
 
 
-def _prepare(n_sig, ms, amp, lib):
+def _prepare(n_sig, ms, amp, lib, literal=False):
     """stream [ms, 2046], per-signal channel records and device loop states at tick T_HAND (host mode up to there)"""
     import steps_driver as sd
     from stm32f4_sdr_gps_amd import capi, synth
-    key = (n_sig, ms, amp)
+    key = (n_sig, ms, amp, literal)
     if key in _cache:
         return _cache[key]
     _cache.clear()
     sig_prn = [(i % 32) + 1 for i in range(n_sig)]
-    sig_dopp = [-5000.0 + 39.0 * i + 7.0 for i in range(n_sig)]
+    sig_dopp = [-5000.0 + 39.0 * i + (0.0 if literal else 7.0) for i in range(n_sig)]
     sig_delay = [(61.0 * i) % 16368 for i in range(n_sig)]
     sats = [synth.Sat(sig_prn[i], sig_dopp[i], sig_delay[i], amp, 0.37 * i) for i in range(n_sig)]
-    stream = synth.make_if(ms, sats, noise_amp=1.0, seed=5)
+    stream = (synth.make_if_static if literal else synth.make_if)(ms, sats, noise_amp=1.0, seed=5)
     steps = sd.StepsLib(lib, False)
     lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
     lib.gps_tracking_process_batch.restype = None
@@ -62,17 +62,20 @@ def _prepare(n_sig, ms, amp, lib):
     return _cache[key]
 
 
-def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, bind=True):
+def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, bind=True, literal=False):
+    """literal: SURVEY.md 8(d) config 5 to the letter -- one signal per channel at -5000 + 39 i Hz (no 7 Hz offset), the stream
+    tests/golden/f7_steps_config5_256ch.npz was recorded on when channels = 256 and ms = 10000 (the reference's own lock count on
+    it is reported beside the device loop's)."""
     from stm32f4_sdr_gps_amd import capi
     n = channels
-    n_sig = signals if 0 < signals < n else n
+    n_sig = signals if 0 < signals < n and not literal else n
     eng = capi.Engine(0)
     lib = eng.lib
     affinity = os.sched_getaffinity(0)
     bound = eng.bind_thread_to_device() if bind else False
     try:
         t0 = time.time()
-        stream, sig_table, sig_st, sig_tracking, sig_dopp, sig_delay = _prepare(n_sig, ms, amp, lib)
+        stream, sig_table, sig_st, sig_tracking, sig_dopp, sig_delay = _prepare(n_sig, ms, amp, lib, literal)
         prep_s = time.time() - t0
         idx = np.arange(n) % n_sig
         table = np.ascontiguousarray(sig_table[idx])              # the host's records: word layer state per channel
@@ -117,6 +120,14 @@ def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, b
         steady = lat[n_launch // 2:]
         late = int((steady >= k * 1e-3).sum())
         words = int(table[:, 212 + 56:212 + 60].copy().view("<u4").sum())
+        ref_locked = None
+        if literal and (n, ms) == (256, 10000):
+            try:
+                from golden_util import load
+                ref_mask = load("f7_steps_config5_256ch.npz")["locked"]
+                ref_locked = {"count": int(ref_mask.sum()), "same_channels": int((ref_mask == locked).sum())}
+            except Exception:
+                ref_locked = None
         return {"metric": "closed-loop real-time tracking channels, loops on the device (k_track_loop: correlators + DLL / PLL / FLL + "
                           "false-lock check + SNR + bit synchroniser per channel and ms in one kernel, state in HBM; host: word "
                           "layer per completed navigation bit)",
@@ -131,6 +142,7 @@ def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, b
                 "real_time": bool(late == 0),
                 "channels_handed_over_tracking": int(sig_tracking[idx].sum()), "code_and_carrier_lock": int(locked.sum()),
                 "false_lock_jumps": int(final["reseed_count"].sum()), "good_words_on_the_host": words,
+                "code_and_carrier_lock_in_the_reference_on_this_stream": ref_locked,
                 "prepare_seconds": prep_s,
                 "note": "latency of a launch = K blocks into page-locked memory -> H2D -> k_track_loop -> D2H of K flag bytes per "
                         "channel -> word layer on the host; real_time = every launch of the steady half (the second half of the "
@@ -149,9 +161,11 @@ def main():
     ap.add_argument("--amp", type=float, default=0.12)
     ap.add_argument("--unpaced", action="store_true")
     ap.add_argument("--no-bind", action="store_true")
+    ap.add_argument("--literal", action="store_true", help="SURVEY.md 8(d) config 5 to the letter (see device_loop)")
     args = ap.parse_args()
     for n in args.channels:
-        print(json.dumps(device_loop(n, args.ms, args.k, args.signals, args.amp, not args.unpaced, not args.no_bind)), flush=True)
+        print(json.dumps(device_loop(n, args.ms, args.k, args.signals, args.amp, not args.unpaced, not args.no_bind, args.literal)),
+              flush=True)
 
 
 if __name__ == "__main__":
