@@ -333,6 +333,10 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
  * values[i] (host arrays; enqueued on the context's stream in front of the next launch). */
 int gpsx_loop_set_polarity(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, const int *channels, const uint8_t *values, int n);
 
+/* The pseudorange step consumed the code-phase averaging window (gps_master_code_phase_filter_reset, gps_master.c:383-389):
+ * code_phase_fine_filt = 0, code_filt_cnt = 0 for all n_ch device states (enqueued on the context's stream). */
+int gpsx_loop_reset_code_filter(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, int n_ch);
+
 /* ---- per-call primitives on caller buffers (the device work behind include/gpsx_compat.h) --------------------- */
 
 /* gps_shift_to_zero_freq(_track): *accum is the NCO accumulator in/out (0 for the stateless call).  Writes bytes

@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_track_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.gpsx_track_loop_dev.argtypes = lib.gpsx_track_loop.argtypes
     lib.gpsx_loop_set_polarity.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.gpsx_loop_reset_code_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.gpsx_loop_state_from_channel.restype = None

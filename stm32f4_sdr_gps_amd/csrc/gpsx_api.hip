@@ -1123,6 +1123,19 @@ int gpsx_loop_set_polarity(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, const int 
   return GPSX_OK;
 }
 
+int gpsx_loop_reset_code_filter(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, int n_ch)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (!d_state || n_ch < 1)
+    return fail(ctx, GPSX_EINVAL, "null/empty argument");
+  static_assert(offsetof(gpsx_loop_state_t, code_phase_fine_filt) == offsetof(gpsx_loop_state_t, code_filt_cnt) + 2,
+                "the two window fields are adjacent");
+  // six bytes per state: a strided fill (rows of 96 B, 6 B wide)
+  HIPCHK(ctx, hipMemset2DAsync(reinterpret_cast<uint8_t *>(d_state) + offsetof(gpsx_loop_state_t, code_filt_cnt), sizeof(gpsx_loop_state_t),
+                               0, 6, (size_t)n_ch, ctx->stream));
+  return GPSX_OK;
+}
+
 int gpsx_rewind(gpsx_ctx *ctx, gpsx_trk_state_t *st, int n_ch, const uint8_t *steps)
 {
   if (int rc = use_device(ctx)) return rc;
