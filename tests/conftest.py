@@ -14,6 +14,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def oracle_threads():
+    """threads for the oracle's grid sweeps: the CPUs this process may use, 8 at least (GPU boxes cap the container at ~16 CPUs
+    of a 256-thread host), 32 at most"""
+    return max(8, min(32, len(os.sched_getaffinity(0))))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / on the GPU box)")
 

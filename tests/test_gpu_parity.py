@@ -8,7 +8,10 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from conftest import oracle_threads
 from golden_util import IF_HZ, fnv1a32, known_answers, load
+
+ORC_THREADS = oracle_threads()
 
 pytestmark = pytest.mark.gpu
 
@@ -279,7 +282,7 @@ def test_acq_grid_full_cold_start_grid_vs_oracle(eng, oracle):
     prns = np.arange(1, 33, dtype=np.uint8)
     peaks, keys = eng.acq_grid(blk, prns, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
     assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<5>"       # a lone capture: 21 clusters as 42 workgroups (split form)
-    want = oracle.acq_grid(blk, 1, prns, -5000, 500, 21, 8, n_threads=8)
+    want = oracle.acq_grid(blk, 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(peaks[0][f], want[f]), f
     # packed keys: energy and lowest fine phase of the best bit shift
@@ -300,7 +303,7 @@ def test_acq_grid_reference_native_grid_29_bins_byte_phases(eng, oracle, stream)
     peaks, _ = eng.acq_grid(stream[4:6], prns, n_search=2, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=PHASES_BYTE)
     assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<4>"
     for s_ in range(2):
-        want = oracle.acq_grid(stream[4 + s_:5 + s_], 1, prns, -7000, 500, 29, 1, n_threads=8)
+        want = oracle.acq_grid(stream[4 + s_:5 + s_], 1, prns, -7000, 500, 29, 1, n_threads=ORC_THREADS)
         for f in ("max_val", "phase", "sum", "avr"):
             assert np.array_equal(peaks[s_][f], want[f]), (s_, f)
     prns5 = np.array([5, 14, 20, 30, 1, 33, 210], np.uint8)
@@ -349,7 +352,7 @@ def test_acq_grid_non_coherent_10ms_and_per_ms_triplets(eng, oracle, stream):
     prns = np.array([5, 14, 20, 30, 7, 9, 11, 13, 15], np.uint8)   # 9 PRNs: exercises a partial PRN group
     out = eng.acq_grid_debug(stream[:10], prns, n_ms=10, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5,
                              want_per_ms=True, want_energy=True)
-    want = oracle.acq_grid(stream[:10], 10, prns, -1000, 500, 5, 8, n_threads=8)
+    want = oracle.acq_grid(stream[:10], 10, prns, -1000, 500, 5, 8, n_threads=ORC_THREADS)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(out["peaks"][0][f], want[f]), f
     for p, d, b in [(0, 3, 0), (1, 4, 5), (8, 0, 7), (3, 2, 2)]:
@@ -891,7 +894,7 @@ def test_alternative_grid_kernels_match_the_oracle(oracle, stream, algo, monkeyp
         alt.set_if_format(capi.IF_2BIT_SM)
         pk, keys = alt.acq_grid(two, prns4, n_search=3, dopp_min_hz=500, dopp_step_hz=500, n_dopp=4)
         for s_ in range(3):
-            want = oracle.acq_grid(one[s_:s_ + 1], 1, prns4, 500, 500, 4, 8, n_threads=8)
+            want = oracle.acq_grid(one[s_:s_ + 1], 1, prns4, 500, 500, 4, 8, n_threads=ORC_THREADS)
             for f in ("max_val", "phase", "sum", "avr"):
                 assert np.array_equal(pk[s_][f], want[f]), (algo, s_, f)
     finally:
@@ -946,13 +949,13 @@ def test_matrix_core_grid_vs_oracle(eng_mx, oracle, stream):
     peaks, keys = eng_mx.acq_grid(stream[:2], prns, n_search=2, dopp_min_hz=500, dopp_step_hz=1500, n_dopp=3)
     assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<0>"
     for s in range(2):
-        want = oracle.acq_grid(stream[s:s + 1], 1, prns, 500, 1500, 3, 8, n_threads=8)
+        want = oracle.acq_grid(stream[s:s + 1], 1, prns, 500, 1500, 3, 8, n_threads=ORC_THREADS)
         for f in ("max_val", "phase", "sum", "avr"):
             assert np.array_equal(peaks[s][f], want[f]), (s, f)
     prns5 = np.array([5, 14, 20, 30, 7], np.uint8)
     peaks, _ = eng_mx.acq_grid(stream[:10], prns5, n_search=1, n_ms=10, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
     assert eng_mx.lib.gpsx_last_kernel(eng_mx.h) == b"k_acq_mx<2>"
-    want = oracle.acq_grid(stream[:10], 10, prns5, -1000, 500, 5, 8, n_threads=8)
+    want = oracle.acq_grid(stream[:10], 10, prns5, -1000, 500, 5, 8, n_threads=ORC_THREADS)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(peaks[0][f], want[f]), f
 
@@ -974,7 +977,7 @@ def test_matrix_core_grid_windows_sets_and_shards(eng_mx, eng_poly, oracle, stre
     # a single PRN (one row of the GEMM in use) and 33 (a second cluster holding one PRN), against the oracle
     for plist in (np.array([17], np.uint8), np.arange(1, 34, dtype=np.uint8)):
         pk, _ = eng_mx.acq_grid(stream[3:4], plist, n_search=1, dopp_min_hz=-750, dopp_step_hz=1500, n_dopp=2)
-        want = oracle.acq_grid(stream[3:4], 1, plist, -750, 1500, 2, 8, n_threads=8)
+        want = oracle.acq_grid(stream[3:4], 1, plist, -750, 1500, 2, 8, n_threads=ORC_THREADS)
         for f in ("max_val", "phase", "sum", "avr"):
             assert np.array_equal(pk[0][f], want[f]), (len(plist), f)
     kw = dict(n_search=2, dopp_min_hz=-2000, dopp_step_hz=1000, n_dopp=5)
@@ -1016,7 +1019,7 @@ def test_bench_size_batch_equals_single_capture_launches_and_finds_the_satellite
             pk1, keys1 = e.acq_grid(blocks2[i:i + 1], prns, n_search=1, **kw)
             assert np.array_equal(pk1[0], pk[i]) and np.array_equal(keys1[0], keys[i]), i
         for i in (0, 131, 255):
-            want = oracle.acq_grid(blocks1[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+            want = oracle.acq_grid(blocks1[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
             for f in ("max_val", "phase", "sum", "avr"):
                 assert np.array_equal(pk[i][f], want[f]), (i, f)
         assert (keys >> 14).min() > 0                              # every (capture, PRN, Doppler) search produced a peak
@@ -1076,7 +1079,7 @@ def test_acq_grid_async_four_contexts_in_rotation_vs_oracle_and_device_path(orac
         for j in range(n_calls):
             pin_pk, pin_keys = bufs[j]
             for s_ in range(2):
-                want = oracle.acq_grid(blocks1[2 * j + s_:2 * j + s_ + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+                want = oracle.acq_grid(blocks1[2 * j + s_:2 * j + s_ + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
                 for f in ("max_val", "phase", "sum", "avr"):
                     assert np.array_equal(pin_pk[s_][f], want[f]), (j, s_, f)
                 fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
@@ -1117,7 +1120,7 @@ def test_acq_grid_async_four_contexts_in_rotation_vs_oracle_and_device_path(orac
             assert np.array_equal(pin_pk, dev_pk), i
             assert np.array_equal(pin_keys, dev_keys), i
         for i in (7, 128, 249):
-            want = oracle.acq_grid(blocks1[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+            want = oracle.acq_grid(blocks1[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
             for f in ("max_val", "phase", "sum", "avr"):
                 assert np.array_equal(dev_pk[i][f], want[f]), (i, f)
     finally:
@@ -1203,7 +1206,7 @@ def test_in_process_group_of_n_devices_all_reduces_over_rccl(stream, oracle, n_d
         want_keys = np.zeros((2, 32, 21), np.int64)
         want_pk = []
         for s_ in range(2):
-            w = oracle.acq_grid(stream[s_:s_ + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+            w = oracle.acq_grid(stream[s_:s_ + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
             fine = 8 * w["phase"].astype(np.int64) + np.arange(8)[None, None, :]
             want_keys[s_] = ((w["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)
             want_pk.append(w)
@@ -1566,7 +1569,7 @@ def test_last_partly_filled_round_of_a_launch_goes_to_the_split_form(n, oracle, 
         assert pk.tobytes() == pk0.tobytes() and np.array_equal(keys, keys0)
         seam = {13: (11, 12), 16: (12, 13, 15), 70: (69,)}[n]
         for i in seam:
-            want = oracle.acq_grid(blocks[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=8)
+            want = oracle.acq_grid(blocks[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
             for f in ("max_val", "phase", "sum", "avr"):
                 assert np.array_equal(pk[i][f], want[f]), (i, f)
         # windows reach the tail too

@@ -23,6 +23,15 @@ LAT, LON, HGT = 48.1374, 11.5755, 520.0
 RX = geodetic_to_ecef(LAT, LON, HGT)
 TOW0 = 388800 + 30 * 37            # a subframe boundary at the satellites
 N_MS = 39000
+_signal = {}
+
+
+def _orbit_signal():
+    """the satellites and N_MS milliseconds of their signal at RX (synthesised once for both tests)"""
+    if not _signal:
+        sats = pc.pick_satellites(RX, TOW0, 4, seed=29)
+        _signal["v"] = (sats,) + pc.make_if_from_orbits(N_MS, sats, RX, TOW0, cycle=3)
+    return _signal["v"]
 
 
 def test_if_samples_to_position_through_the_reference_named_calls():
@@ -40,8 +49,7 @@ def test_if_samples_to_position_through_the_reference_named_calls():
     (alone worth 76 m with perfect measurements) pull in opposite directions.  Asserted: every fix, either way, within
     150 m of the truth; final_pos likewise."""
     from stm32f4_sdr_gps_amd import capi
-    sats = pc.pick_satellites(RX, TOW0, 4, seed=29)
-    stream, first = pc.make_if_from_orbits(N_MS, sats, RX, TOW0, cycle=3)
+    sats, stream, first = _orbit_signal()
     lib = capi.load_library()
     lib.gps_master_handling.argtypes = [C.c_void_p, C.c_uint8]
     lib.acquisition_process.argtypes = [C.c_void_p, C.c_void_p]
@@ -126,8 +134,7 @@ def test_device_loops_track_satellites_on_orbits_and_decode_their_ephemerides():
     mode's (test above).  Also here: gpsx_loop_reset_code_filter touches the two window fields and nothing else."""
     from stm32f4_sdr_gps_amd import capi
     n_ms, k = 26000, 20
-    sats = pc.pick_satellites(RX, TOW0, 4, seed=29)
-    stream, first = pc.make_if_from_orbits(n_ms, sats, RX, TOW0, cycle=3)
+    sats, stream, first = _orbit_signal()
     eng = capi.Engine(0)
     lib = eng.lib
     lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
