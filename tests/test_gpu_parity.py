@@ -1579,3 +1579,44 @@ def test_last_partly_filled_round_of_a_launch_goes_to_the_split_form(n, oracle, 
     finally:
         e.close()
         plain.close()
+
+
+def test_chunk_callback_may_not_reenter_its_context_and_its_exceptions_reach_the_caller(oracle, stream):
+    """gpsx_track_epl_batch_chunked calls back while later pieces are in flight on the context's arena and side streams: an
+    entry point of the SAME context called from inside the callback is refused (GPSX_EINVAL), another context works; and
+    an exception raised in a Python callback is not swallowed by ctypes but re-raised by Engine.track_epl_chunked."""
+    from stm32f4_sdr_gps_amd import capi
+    e, other = capi.Engine(0), capi.Engine(0)
+    try:
+        n = 70001
+        st = np.zeros(n, capi.TRK_DTYPE)
+        st["prn"] = (np.arange(n) % 32) + 1
+        st["code_phase_fine"] = (61 * np.arange(n) % 16368).astype(np.float32)
+        small = np.zeros(8, capi.TRK_DTYPE)
+        small["prn"] = np.arange(1, 9)
+        seen = []
+
+        def cb(first, cnt):
+            try:
+                e.track_epl(stream[1], small.copy())
+                seen.append("same context accepted")
+            except capi.GpsxError as exc:
+                seen.append(str(exc))
+            iq = other.track_epl(stream[1], small.copy())        # another context is free
+            w, _ = oracle.track_epl(stream[1], oracle.ca_code(3), 0.0, 0.0, 0)
+            assert np.array_equal(iq[2], w)
+
+        iq = e.track_epl_chunked(stream[1], st, 4, cb)
+        assert len(seen) == 4 and all("callback" in s_ for s_ in seen), seen
+        w, _ = oracle.track_epl(stream[1], oracle.ca_code(int(st["prn"][n - 1])), float(st["code_phase_fine"][n - 1]), 0.0, 0)
+        assert np.array_equal(iq[n - 1], w)
+        e.track_epl(stream[1], small.copy())                       # and the context is usable again afterwards
+
+        def boom(first, cnt):
+            raise KeyError("from the callback")
+
+        with pytest.raises(KeyError):
+            e.track_epl_chunked(stream[1], st, 4, boom)
+    finally:
+        e.close()
+        other.close()

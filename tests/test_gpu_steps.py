@@ -311,3 +311,73 @@ def test_config5_to_the_letter_256_channels_10_seconds_follow_the_reference(gpsx
     assert np.array_equal(sd.snapshot(table), g["final"])
     locked = sd.lock_mask(table, dopp, delay)
     assert np.array_equal(locked, g["locked"]) and int(locked.sum()) == 229
+
+
+_HOOK_SHIM = r"""
+#include <pthread.h>
+#include <stdint.h>
+static uint32_t tick;
+static int calls, foreign;
+static pthread_t first;
+static int have_first;
+uint32_t signal_capture_get_packet_cnt(void)        /* the host's own time source: overrides libgpsx's weak default */
+{
+  pthread_t me = pthread_self();
+  if (!have_first) { first = me; have_first = 1; }
+  else if (!pthread_equal(me, first)) __sync_fetch_and_add(&foreign, 1);
+  __sync_fetch_and_add(&calls, 1);
+  return tick;
+}
+void shim_set(uint32_t t) { tick = t; }
+int shim_calls(void) { return calls; }
+int shim_foreign(void) { return foreign; }
+"""
+
+_HOOK_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import steps_driver as sd
+from stm32f4_sdr_gps_amd import capi, synth
+shim = C.CDLL(sys.argv[2])
+shim.shim_set.argtypes = [C.c_uint32]
+lib = capi.load_library()
+steps = sd.StepsLib(lib, False)
+lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+lib.gps_tracking_process_batch.restype = None
+n, ms = 4096, 260
+sats = [synth.Sat(i + 1, -2000.0 + 450.0 * i, (2000.0 * i + 37.0) % 16368, 0.25, 0.3 * i) for i in range(8)]
+stream = synth.make_if(ms, sats, noise_amp=1.0, seed=9)
+per_sig = np.stack([sd.preset_channel(steps, s.prn, int(round(s.doppler_hz / 500.0)) * 500, int(s.delay_samples // 8) % 2046) for s in sats])
+table = np.ascontiguousarray(per_sig[np.arange(n) % 8])
+per_step = []
+for t in range(ms):
+    shim.shim_set(t)
+    before = shim.shim_calls()
+    lib.gps_tracking_process_batch(table.ctypes.data, n, stream[t].ctypes.data, t & 3)
+    per_step.append(shim.shim_calls() - before)
+stamps = table[:, 60 + 76:60 + 80].copy().view("<u4")[:, 0]     # prev_track_timestamp of channels that track
+print("RESULT", max(per_step), min(per_step), shim.shim_foreign(), int(stamps.max()), lib.gps_tracking_batch_workers())
+"""
+
+
+def test_batched_step_under_an_overridden_time_source_calls_it_once_from_the_calling_thread(tmp_path):
+    """the weak hooks are the host's.  A host that brings its own signal_capture_get_packet_cnt (here: an LD_PRELOADed
+    definition that counts its calls and remembers its first caller) must see it called from the thread that called the
+    step, never from a worker and never concurrently: the batched step reads the tick ONCE per step and, seeing the symbol
+    resolve outside the library, runs without workers -- at 4096 channels, where it would otherwise use its pool."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hook_shim.c"
+    src.write_text(_HOOK_SHIM)
+    so = tmp_path / "libhookshim.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", str(src), "-o", str(so), "-lpthread"])
+    env = dict(os.environ, LD_PRELOAD=str(so), GPSX_STEP_THREADS="6")
+    r = subprocess.run([sys.executable, "-c", _HOOK_SCRIPT, root, str(so)], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    most, least, foreign, last_stamp, workers = (int(x) for x in line[0].split()[1:])
+    assert (most, least) == (1, 1), line[0]          # one read per step, whatever the channel count
+    assert foreign == 0
+    assert last_stamp == 259 and workers == 6           # the channels did see the host's tick; the pool exists, and was not used
