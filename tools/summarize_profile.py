@@ -98,6 +98,9 @@ def main(tag="r02", searches=256, n_ms=1, pattern=None):
             summary["derived"]["effective_clock_ghz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / summary["kernel_trace_avg_ns"]
             entry["gpu_cycles_per_launch"] = c["GRBM_GUI_ACTIVE"] / 8.0
             entry["kernel_trace_avg_ns"] = summary["kernel_trace_avg_ns"]
+            for k in ("kernel_trace_median_ns", "kernel_trace_min_ns", "kernel_trace_max_ns"):
+                if k in summary:
+                    entry[k] = summary[k]
     with open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     kc_path = os.path.join(dst, "kernel_counters.json")
