@@ -1112,14 +1112,21 @@ int gpsx_loop_set_polarity(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, const int 
   if (int rc = use_device(ctx)) return rc;
   if (!d_state || !channels || !values || n < 0)
     return fail(ctx, GPSX_EINVAL, "null argument");
-  for (int i = 0; i < n; i++) {   // a handful of channels, once or twice in each one's life: one byte each
+  if (n == 0)
+    return GPSX_OK;
+  for (int i = 0; i < n; i++)
     if (channels[i] < 0)
       return fail(ctx, GPSX_EINVAL, "negative channel index");
-    const uint8_t v = values[i] ? 1 : 0;
-    HIPCHK(ctx, hipMemcpyAsync(reinterpret_cast<uint8_t *>(d_state + channels[i]) + offsetof(gpsx_loop_state_t, inv_polarity_flag),
-                               &v, 1, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (&v is a stack byte)
-  }
+  // one small kernel for all of them (half of a million channels can find their polarity within the same second)
+  if (int rc = arena_reset(ctx, arena_size((size_t)n * sizeof(int)) + arena_size((size_t)n)))
+    return rc;
+  int *d_idx = arena_take<int>(ctx, (size_t)n);
+  uint8_t *d_val = arena_take<uint8_t>(ctx, (size_t)n);
+  HIPCHK(ctx, hipMemcpyAsync(d_idx, channels, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_val, values, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  launch_loop_set_polarity(ctx->stream, d_state, d_idx, d_val, n);
+  LAUNCHCHK(ctx, "k_loop_set_polarity");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (the caller's arrays are free again, and so is the arena)
   return GPSX_OK;
 }
 

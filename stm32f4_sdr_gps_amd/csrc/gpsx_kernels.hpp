@@ -141,6 +141,7 @@ void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, const uint32_t *d_chipbits, const uint32_t *d_trk_rep,
                        uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn);
+void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int *d_channels, const uint8_t *d_values, int n);
 constexpr int kTrackPadPrn = -2147483647 - 1;   // gpsx_trk_state_t.prn of a padding channel: the empty code, not an error
 // N3: 2-bit sign/magnitude samples -> two 1-bit planes
 void launch_unpack2(hipStream_t s, const uint8_t *d_in, int n_blocks, uint8_t *d_sign, uint8_t *d_mag);

@@ -381,6 +381,21 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
   }
 }
 
+// the host's word layer changed its mind about the data polarity of n channels
+__global__ void k_loop_set_polarity(gpsx_loop_state_t *__restrict__ st, const int *__restrict__ channels,
+                                    const uint8_t *__restrict__ values, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    st[channels[i]].inv_polarity_flag = values[i] ? 1 : 0;
+}
+
+void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int *d_channels, const uint8_t *d_values, int n)
+{
+  if (n > 0)
+    hipLaunchKernelGGL(k_loop_set_polarity, dim3((n + 255) / 256), dim3(256), 0, s, d_st, d_channels, d_values, n);
+}
+
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, const uint32_t *d_chipbits, const uint32_t *d_trk_rep,
                        uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
