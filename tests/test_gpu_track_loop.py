@@ -278,3 +278,85 @@ def test_word_layer_behind_the_device_loop_equals_the_host_mode(eng, k):
         # launch boundary and that artefact does not happen
         assert np.array_equal(nav[:, 9:11], nav_w[:, 9:11])
         assert np.array_equal(final["accurate_swap_time"], host_side["accurate_swap_time"])
+
+
+def test_device_loop_from_random_loop_states_equals_the_host_mode(eng):
+    """Not only channels in lock: 6000 channels whose loop state is RANDOM -- code phases anywhere in [0, 16368] including the
+    wrap region where Early / Prompt / Late are not neighbours and the DLL's wrap expressions fire, carriers anywhere in
+    +-6 kHz, random loop-filter memories, false-lock counters and bit-synchroniser state (below the reseed threshold: the two
+    modes draw from different generators there) -- on a stream with eight signals and on pure noise, 24 ms.  Every field of
+    every channel must come out of the device loop as the host mode (the reference's loops on the CPU behind the same
+    correlators) leaves it: floats within the stated tolerance and, where they are bit-identical, every integer too."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    n, t0, t1 = 6000, 400, 424
+    lib = eng.lib
+    steps = sd.StepsLib(lib, False)
+    lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+    lib.gps_tracking_process_batch.restype = None
+    sats = [synth.Sat(i + 1, -2000.0 + 450.0 * i, (2000.0 * i + 37.0) % 16368, 0.25, 0.3 * i) for i in range(8)]
+    for name, stream in (("signals", synth.make_if(t1, sats, noise_amp=1.0, seed=9)),
+                         ("noise", synth.make_if(t1, [], noise_amp=1.0, seed=10))):
+        rng = np.random.default_rng(77)
+        table = np.zeros((n, sd.CH_SIZE), np.uint8)
+        for c in range(n):
+            table[c] = sd.preset_channel(steps, int(rng.integers(1, 33)), int(rng.integers(-12, 13)) * 500, int(rng.integers(0, 2046)))
+        trk = table[:, 60:212]
+
+        def put(off, arr, dt):
+            a = np.ascontiguousarray(arr.astype(dt))
+            trk[:, off:off + a.dtype.itemsize] = a.view(np.uint8).reshape(n, -1)
+
+        fine = rng.uniform(0.0, 16368.0, n)
+        fine[:400] = rng.choice([0.0, 0.4, 7.9, 8.0, 16360.2, 16367.9, 16368.0], 400)       # the edges
+        put(80, fine, "<f4")
+        put(4, rng.uniform(-6000.0, 6000.0, n), "<f4")
+        put(8, rng.integers(0, 2**32, n, dtype=np.uint64), "<u4")
+        put(92, rng.uniform(-1, 1, n), "<f4")             # dll_code_err
+        put(96, rng.uniform(-1, 1, n), "<f4")             # pll_code_err
+        put(100, rng.integers(-3000, 3000, n), "<i2")     # fll_old_i / q
+        put(102, rng.integers(-3000, 3000, n), "<i2")
+        put(104, rng.uniform(-1.5, 1.5, n), "<f4")        # fll_err
+        for k in range(4):
+            put(108 + 2 * k, rng.integers(-3000, 3000, n), "<i2")
+        put(116, rng.integers(0, 11, n), "u1")            # pll_bad_state_cnt
+        put(118, rng.integers(0, 70, n), "<u2")           # pll_bad_state_master_cnt: cannot reach 81 within 6 groups
+        put(120, rng.integers(0, 100000, n), "<u4")
+        put(124, rng.integers(0, 100000, n), "<u4")
+        put(128, rng.integers(0, 202, n), "<u2")          # snr_summ_cnt: some cross kSnrLength inside the run
+        put(140, rng.integers(0, 300, n), "<u2")          # code_filt_cnt
+        put(144, rng.uniform(0, 1e6, n), "<f4")           # code_phase_fine_filt
+        put(76, np.full(n, t0 - 1), "<u4")                # prev_track_timestamp: served last millisecond
+        put(148, np.full(n, sd.TRK_RUN), "<i4")
+        nav = table[:, 212:324]
+        nav[:, 0] = rng.integers(0, 2, n)                 # period_sync_ok_flag
+        nav[:, 1] = rng.integers(0, 11, n)                # right_period_cnt
+        nav[:, 4:8] = np.ascontiguousarray(rng.integers(t0 - 40, t0, n).astype("<u4")).view(np.uint8).reshape(n, 4)   # old_swap_time
+        nav[:, 8] = rng.integers(0, 20, n)                # old_reminder
+        nav[:, 11] = rng.integers(0, 20, n)               # votes
+        nav[:, 12] = rng.integers(0, 20, n)
+        nav[:, 13] = rng.integers(0, 2, n)                # inv_polarity_flag
+        st0 = _states_from_records(lib, table)
+        _, _, final = _run(eng, stream, st0, t0, t1, 8, want_trace=False)
+        for t in range(t0, t1):
+            steps.set_time(t)
+            lib.gps_tracking_process_batch(table.ctypes.data, n, stream[t].ctypes.data, t & 3)
+        host = _states_from_records(lib, table)
+        d_fine = np.abs(final["code_phase_fine"] - host["code_phase_fine"])
+        d_freq = np.abs(final["if_freq_offset_hz"] - host["if_freq_offset_hz"])
+        same = (d_fine == 0) & (d_freq == 0)
+        print(name, "channels", n, "bit-identical floats", int(same.sum()), "max |d fine|", d_fine.max(), "max |d freq|", d_freq.max())
+        assert d_fine.max() <= TOL_FINE and d_freq.max() <= TOL_HZ, name
+        assert same.mean() > 0.98, name
+        # the loop-filter memories that hold an arctangent (units of pi / radians): SURVEY.md 8(c)'s 1e-6 -- the device's
+        # arctangents are the correctly rounded ones, glibc 2.35's float versions are good to an ulp: on random inputs the two
+        # differ in the last bit now and then (on the reference's lock-in traces they never did)
+        for f in ("pll_code_err", "fll_err", "dll_code_err"):
+            assert np.abs(final[f] - host[f]).max() <= 1e-6, (name, f)
+        assert np.allclose(final["code_phase_fine_filt"], host["code_phase_fine_filt"], rtol=1e-6), name
+        assert np.allclose(final["snr_value"], host["snr_value"], rtol=1e-5, atol=1e-5), name
+        for f in final.dtype.names:
+            if f in ("rng", "reseed_count", "slot_start_ticks", "slot_ip", "slot_bits", "found_freq_offset_hz", "snr_value",
+                     "code_phase_fine", "if_freq_offset_hz", "pll_code_err", "fll_err", "dll_code_err", "code_phase_fine_filt"):
+                continue       # (not part of gps_ch_t / floats, compared above)
+            assert np.array_equal(final[f][same], host[f][same]), (name, f, np.flatnonzero(final[f][same] != host[f][same])[:5])
+        assert (final["reseed_count"] == 0).all()
