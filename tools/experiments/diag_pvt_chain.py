@@ -1,3 +1,6 @@
+"""Diagnostic (GPU box): the IF-samples-to-position chain of tests/test_gpu_pvt_chain.py with a status line per channel every 3 s
+(code phase / Doppler error against the orbit, SNR, bit sync, polarity, words, subframes, stamps, ephemeris mask) and every
+position fix with its error.  usage: diag_pvt_chain.py [n_ms [satellite seed]]"""
 import ctypes as C, os, sys, math
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")

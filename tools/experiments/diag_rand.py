@@ -1,3 +1,6 @@
+"""Diagnostic (GPU box): who moves libc's rand() state during the 64-channel reference scenario?  The state buffer is installed
+with initstate() so that every change is visible; run under LD_PRELOAD=tools/experiments/randshim.so (gcc -shared -fPIC randshim.c -ldl)
+to see the callers -- libamd_comgr draws hundreds of values whenever a code object is loaded (EXPERIMENTS.md, round 4)."""
 import ctypes as C, os, sys, zlib
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
