@@ -223,9 +223,21 @@ def tracking_device_loop(ms=1200, k=20):
         if not r["real_time"]:
             missed = True
             break
+    # the ladder's runs are 1.2 s; the count it ends on is confirmed over 5 s (250 launches), stepping down until one holds
+    confirmed, counts = [], [r["channels"] for r in rows if r["real_time"]]
+    ladder_best = best
+    while counts:
+        r = mod.device_loop(counts[-1], 5240, k, 32, fast_synth=True)
+        confirmed.append({kk: r[kk] for kk in keep + ("ms",)})
+        if r["real_time"]:
+            break
+        counts.pop()
+    best = counts[-1] if counts else None
     return {"metric": "closed-loop real-time tracking channels with the loops on the device: largest count of the ladder whose "
-                      "launches (K ms of stream each) ALL come back inside K ms, at that count and every smaller one",
-            "value": best, "ms_per_launch": k, "ms_per_count": ms, "signals_in_stream": 32,
+                      "launches (K ms of stream each) ALL come back inside K ms, at that count and every smaller one -- in its 1.2 s "
+                      "ladder run AND in a 5 s confirmation run",
+            "value": best, "largest_count_of_the_1200_ms_ladder": ladder_best, "confirmation_runs": confirmed,
+            "ms_per_launch": k, "ms_per_count": ms, "signals_in_stream": 32,
             "per_millisecond_launches_256_channels": {kk: per_ms[kk] for kk in keep},
             "config5": {kk: literal[kk] for kk in keep + ("ms", "signals_in_stream", "code_and_carrier_lock_in_the_reference_on_this_stream")},
             "ladder": rows,

@@ -33,11 +33,11 @@ _cache = {}
 T_HAND = 240
 
 
-def _prepare(n_sig, ms, amp, lib, literal=False):
+def _prepare(n_sig, ms, amp, lib, literal=False, fast_synth=False):
     """stream [ms, 2046], per-signal channel records and device loop states at tick T_HAND (host mode up to there)"""
     import steps_driver as sd
     from stm32f4_sdr_gps_amd import capi, synth
-    key = (n_sig, ms, amp, literal)
+    key = (n_sig, ms, amp, literal, fast_synth)
     if key in _cache:
         return _cache[key]
     _cache.clear()
@@ -45,7 +45,7 @@ def _prepare(n_sig, ms, amp, lib, literal=False):
     sig_dopp = [-5000.0 + 39.0 * i + (0.0 if literal else 7.0) for i in range(n_sig)]
     sig_delay = [(61.0 * i) % 16368 for i in range(n_sig)]
     sats = [synth.Sat(sig_prn[i], sig_dopp[i], sig_delay[i], amp, 0.37 * i) for i in range(n_sig)]
-    stream = (synth.make_if_static if literal else synth.make_if)(ms, sats, noise_amp=1.0, seed=5)
+    stream = (synth.make_if_static if literal or fast_synth else synth.make_if)(ms, sats, noise_amp=1.0, seed=5)
     steps = sd.StepsLib(lib, False)
     lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
     lib.gps_tracking_process_batch.restype = None
@@ -62,7 +62,7 @@ def _prepare(n_sig, ms, amp, lib, literal=False):
     return _cache[key]
 
 
-def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, bind=True, literal=False):
+def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, bind=True, literal=False, fast_synth=False):
     """literal: SURVEY.md 8(d) config 5 to the letter -- one signal per channel at -5000 + 39 i Hz (no 7 Hz offset), the stream
     tests/golden/f7_steps_config5_256ch.npz was recorded on when channels = 256 and ms = 10000 (the reference's own lock count on
     it is reported beside the device loop's)."""
@@ -75,7 +75,7 @@ def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, b
     bound = eng.bind_thread_to_device() if bind else False
     try:
         t0 = time.time()
-        stream, sig_table, sig_st, sig_tracking, sig_dopp, sig_delay = _prepare(n_sig, ms, amp, lib, literal)
+        stream, sig_table, sig_st, sig_tracking, sig_dopp, sig_delay = _prepare(n_sig, ms, amp, lib, literal, fast_synth)
         prep_s = time.time() - t0
         idx = np.arange(n) % n_sig
         table = np.ascontiguousarray(sig_table[idx])              # the host's records: word layer state per channel
@@ -162,10 +162,11 @@ def main():
     ap.add_argument("--unpaced", action="store_true")
     ap.add_argument("--no-bind", action="store_true")
     ap.add_argument("--literal", action="store_true", help="SURVEY.md 8(d) config 5 to the letter (see device_loop)")
+    ap.add_argument("--fast-synth", action="store_true", help="synthesise the stream with synth.make_if_static (long soaks)")
     args = ap.parse_args()
     for n in args.channels:
-        print(json.dumps(device_loop(n, args.ms, args.k, args.signals, args.amp, not args.unpaced, not args.no_bind, args.literal)),
-              flush=True)
+        print(json.dumps(device_loop(n, args.ms, args.k, args.signals, args.amp, not args.unpaced, not args.no_bind, args.literal,
+                                     args.fast_synth)), flush=True)
 
 
 if __name__ == "__main__":
