@@ -247,6 +247,7 @@ void      gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data,
 /* threads (the caller included) the batched step spreads its per-channel host loops over from 2048 channels on: sized at the
  * first such call from the calling thread's CPUs and the container's CPU quota ($GPSX_STEP_THREADS overrides) */
 int       gps_tracking_batch_workers(void);
+int       gps_tracking_batch_last_workers(void);   /* ... and how many the last call used (1 when the host overrides a hook) */
 
 /* Link-time dependencies of the step logic, as in the reference.  libgpsx provides WEAK defaults that a host program
  * overrides simply by defining the symbol:

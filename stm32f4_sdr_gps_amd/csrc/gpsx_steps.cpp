@@ -1392,6 +1392,12 @@ void gps_tracking_process(gps_ch_t *channel, uint8_t *data, uint8_t index)
 // cycles 0..3 or is 0xFF for an idle slot).  All pre-tracking searches go out as ONE job list and all E/P/L correlators
 // as ONE launch; the per-channel loop logic is the same code gps_tracking_process runs.
 int gps_tracking_batch_workers(void) { return StepPool::instance().size(); }
+namespace {
+int g_last_batch_workers = 0;
+}
+// how many of them the last gps_tracking_process_batch call actually used (1 below the threshold, and whenever the host
+// overrides one of the weak hooks the per-channel logic reaches)
+int gps_tracking_batch_last_workers(void) { return g_last_batch_workers; }
 
 void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint8_t index)
 {
@@ -1425,6 +1431,7 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
                                     resolves_outside_this_library((const void *)&gps_nav_data_words_detection) ||
                                     resolves_outside_this_library((const void *)&gps_nav_data_decode_subframe);
   const int n_workers = (n_ch >= kThreadsFrom && !kForeignHooks) ? pool.size() : 1;
+  g_last_batch_workers = n_workers;
   static const int kAhead = [] { const char *e = std::getenv("GPSX_STEP_PREFETCH"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 2; }();
   static std::vector<WorkerLists> lists;
   if ((int)lists.size() < n_workers)

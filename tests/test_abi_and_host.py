@@ -190,3 +190,46 @@ def test_reference_step_sources_relink_against_libgpsx_unmodified(lib_path, tmp_
     assert {"acquisition_process", "gps_tracking_process"} <= own
     needed = subprocess.check_output(["readelf", "-d", str(exe)], text=True)
     assert "libgpsx.so" in needed
+
+
+def test_loop_state_conversion_round_trips_and_touches_only_the_loops_fields(lib_path):
+    """gpsx_loop_state_from_channel / gpsx_loop_state_to_channel (host code): a tracking channel's record -> the 96-byte
+    device-resident loop state -> back.  Everything the loops own survives the round trip bit for bit; nothing else of the
+    record (acquisition result, word layer, observations, ephemeris, PRN code) is written."""
+    import ctypes as C
+
+    import numpy as np
+
+    from stm32f4_sdr_gps_amd import capi
+    lib = C.CDLL(lib_path)
+    lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.gpsx_loop_state_to_channel.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    rec = rng.integers(0, 256, 1688, dtype=np.uint8)
+    rec[60 + 80:60 + 84] = np.frombuffer(np.float32(1234.5).tobytes(), np.uint8)     # (keep the floats finite)
+    for off in (4, 92, 96, 104, 132, 144):
+        rec[60 + off:60 + off + 4] = np.frombuffer(np.float32(rng.uniform(-100, 100)).tobytes(), np.uint8)
+    rec[664] = 17
+    st = np.zeros(1, capi.LOOP_DTYPE)
+    lib.gpsx_loop_state_from_channel(rec.ctypes.data, 99, st.ctypes.data)
+    assert int(st["prn"][0]) == 17 and int(st["rng"][0]) == 99 and float(st["code_phase_fine"][0]) == 1234.5
+    assert int(st["found_freq_offset_hz"][0]) == int(rec[2:4].view("<i2")[0])
+    assert int(st["if_freq_accum"][0]) == int(rec[60 + 8:60 + 12].view("<u4")[0])
+    assert int(st["old_swap_time"][0]) == int(rec[212 + 4:212 + 8].view("<u4")[0]) and int(st["inv_polarity_flag"][0]) == rec[212 + 13]
+    back = rec.copy()
+    back[60:212] ^= 0xFF                        # scramble what the loops own, then restore it from the state
+    back[212:225] ^= 0xFF
+    lib.gpsx_loop_state_to_channel(st.ctypes.data, back.ctypes.data)
+    st2 = np.zeros(1, capi.LOOP_DTYPE)
+    lib.gpsx_loop_state_from_channel(back.ctypes.data, 99, st2.ctypes.data)
+    for f in st.dtype.names:
+        if f not in ("inv_polarity_flag",):     # (written by the host's word layer, never by the device: not copied back)
+            assert st[f].tobytes() == st2[f].tobytes(), f
+    untouched = np.ones(1688, bool)
+    untouched[60:212] = False                   # tracking_data
+    untouched[212:225] = False                  # the bit synchroniser's part of nav_data
+    assert np.array_equal(back[untouched], rec[untouched])
+    # inside tracking_data the fields the loops do NOT own stay as they were (here: scrambled): code_search_*, pre_track_*,
+    # prev_track_timestamp, old_code_phase_fine, code_phase_swap_flag, filt_start_time_ms, state
+    for lo, hi in ((0, 4), (12, 76), (76, 80), (84, 89), (136, 140), (148, 152)):
+        assert np.array_equal(back[60 + lo:60 + hi], rec[60 + lo:60 + hi] ^ 0xFF), (lo, hi)

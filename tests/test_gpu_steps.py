@@ -357,7 +357,8 @@ for t in range(ms):
     lib.gps_tracking_process_batch(table.ctypes.data, n, stream[t].ctypes.data, t & 3)
     per_step.append(shim.shim_calls() - before)
 stamps = table[:, 60 + 76:60 + 80].copy().view("<u4")[:, 0]     # prev_track_timestamp of channels that track
-print("RESULT", max(per_step), min(per_step), shim.shim_foreign(), int(stamps.max()), lib.gps_tracking_batch_workers())
+print("RESULT", max(per_step), min(per_step), shim.shim_foreign(), int(stamps.max()), lib.gps_tracking_batch_workers(),
+      lib.gps_tracking_batch_last_workers())
 """
 
 
@@ -377,7 +378,14 @@ def test_batched_step_under_an_overridden_time_source_calls_it_once_from_the_cal
     r = subprocess.run([sys.executable, "-c", _HOOK_SCRIPT, root, str(so)], env=env, capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
     assert r.returncode == 0 and line, r.stderr[-2000:]
-    most, least, foreign, last_stamp, workers = (int(x) for x in line[0].split()[1:])
+    most, least, foreign, last_stamp, workers, used = (int(x) for x in line[0].split()[1:])
     assert (most, least) == (1, 1), line[0]          # one read per step, whatever the channel count
     assert foreign == 0
-    assert last_stamp == 259 and workers == 6           # the channels did see the host's tick; the pool exists, and was not used
+    assert last_stamp == 259 and workers == 6 and used == 1   # the channels saw the host's tick; the pool exists, and was not used
+    # the same run without the override: the pool is used (only the worker count is looked at: the script cannot set the
+    # library's own counter through the shim)
+    env2 = dict(os.environ, GPSX_STEP_THREADS="6")
+    r2 = subprocess.run([sys.executable, "-c", _HOOK_SCRIPT, root, str(so)], env=env2, capture_output=True, text=True, timeout=600)
+    line2 = [l for l in r2.stdout.splitlines() if l.startswith("RESULT")]
+    assert r2.returncode == 0 and line2, r2.stderr[-2000:]
+    assert int(line2[0].split()[-1]) == 6
