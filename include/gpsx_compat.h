@@ -338,7 +338,8 @@ void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch);
 
 /* The word layer behind the device tracking loops: feeds the completed navigation bits of one gpsx_track_loop launch
  * (flags [n_blocks][n_ch], first block at tick first_tick) to gps_nav_data_words_detection with each bit's own tick and
- * keeps the records' bit-edge time current; returns how many channels changed their inv_polarity_flag (listed in
+ * keeps the records' bit-edge time current (and period_sync_ok_flag as of the channel's last completed bit or located edge:
+ * the bit synchroniser itself lives on the device); returns how many channels changed their inv_polarity_flag (listed in
  * changed_opt up to max_changed -- hand them to gpsx_loop_set_polarity).  Host code. */
 int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, int n_blocks, uint32_t first_tick,
                              int *changed_opt, int max_changed);
