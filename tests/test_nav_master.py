@@ -269,3 +269,70 @@ def test_word_layer_batch_decodes_lnav_from_the_device_loops_flag_bytes():
         assert swap == (3 + off - 3 + 1) % 20, (c, swap)                       # edge 1 located at tick 3 + off
         assert last % 20 == swap and 40000 < last <= 54000, (c, last)           # the stamp sits on the channel's own bit edge
         assert tow % 6 == 0 and tow > 388800
+
+
+def _plain_table(lib, n=4):
+    """n channel records with stamps 12070 + 3 i, one subframe counted, windows of 120 points opened 300 ms ago"""
+    table = (pc.GpsCh * n)()
+    for i, ch in enumerate(table):
+        ch.prn = i + 1
+        ch.nav_data.last_subframe_time = 12070 + 3 * i
+        ch.nav_data.first_subframe_time = 6070 + 3 * i
+        ch.nav_data.subframe_cnt = 1
+        ch.tracking_data.code_phase_fine = ch.tracking_data.old_code_phase_fine = 1000.0 * (i + 1)
+        ch.tracking_data.code_phase_fine_filt = 1000.0 * (i + 1) * 120
+        ch.tracking_data.code_filt_cnt = 120
+        ch.tracking_data.filt_start_time_ms = 12200
+        ch.tracking_data.if_freq_offset_hz = 500.0
+        ch.eph_data.tow_gpst = 388812.0
+    return table
+
+
+def test_pseudorange_step_epoch_bookkeeping_branch_by_branch(lib):
+    """gps_master_nav_handling's bookkeeping as the source text has it (gps_master.c:159-286), one branch at a time."""
+    c_ms = CLIGHT / 1e3
+    # every channel stamped, zero moment locked, one subframe later: whole milliseconds from the stamps, fraction from the phase
+    t = _plain_table(lib)
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == 1
+    for i, ch in enumerate(t):
+        want = (68.802 + 3 * i + 1000.0 * (i + 1) / 16368.0) * c_ms
+        assert abs(ch.obs_data.pseudorange_m - want) < 1e-6, i
+        assert abs(ch.obs_data.tow_s - (388812.0 + (12500 - 12070 - 150 + 4 * i) / 1e3)) < 1e-6
+    # a channel without a stamp: nothing happens (min_subframe_time == 0)
+    t = _plain_table(lib)
+    t[2].nav_data.last_subframe_time = 0
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == -1 and t[0].obs_data.pseudorange_m == 0.0
+    # one channel already has the next subframe (stamps more than 100 ms apart): wait for the others
+    t = _plain_table(lib)
+    t[1].nav_data.last_subframe_time = 18073
+    assert lib.gpsx_nav_pseudoranges(t, 4, 18100) == -1 and t[0].tracking_data.code_filt_cnt == 120
+    # the zero moment ("This works once!"): first_subframe_time = last_subframe_time, counts zeroed -- and THIS call's epoch
+    # still uses the count from before the zeroing, as the reference's locals hold it: whole milliseconds come out 6000 short
+    t = _plain_table(lib)
+    for ch in t:
+        ch.nav_data.first_subframe_time = 0
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == 1
+    assert [ch.nav_data.first_subframe_time for ch in t] == [12070, 12073, 12076, 12079] and all(ch.nav_data.subframe_cnt == 0 for ch in t)
+    assert abs(t[1].obs_data.pseudorange_m - (68.802 + 3 - 6000 + 2000.0 / 16368.0) * c_ms) < 1e-3
+    # channel 0 decides whether anything is computed at all (channels[0].first_subframe_time == 0: return)
+    t = _plain_table(lib)
+    t[0].nav_data.first_subframe_time = 0
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == -1
+    # a window older than a second is thrown away and reopened
+    t = _plain_table(lib)
+    for ch in t:
+        ch.tracking_data.filt_start_time_ms = 11400
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == 0
+    assert all(ch.tracking_data.code_filt_cnt == 0 and ch.tracking_data.filt_start_time_ms == 12500 for ch in t)
+    # a wrap since the stamp is absorbed by the next subframe: swap flag and new_subframe_flag cleared together
+    t = _plain_table(lib)
+    t[3].tracking_data.code_phase_swap_flag = 1
+    t[3].nav_data.new_subframe_flag = 1
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == 1
+    assert t[3].tracking_data.code_phase_swap_flag == 0 and t[3].nav_data.new_subframe_flag == 0
+    # the reference satellite is the FIRST of equal earliest stamps
+    t = _plain_table(lib)
+    t[2].nav_data.last_subframe_time = 12070
+    assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == 1
+    assert abs(t[0].obs_data.pseudorange_m - (68.802 + 1000.0 / 16368.0) * c_ms) < 1e-6
+    assert abs(t[2].obs_data.pseudorange_m - (68.802 + 0 + 3000.0 / 16368.0) * c_ms) < 1e-6
