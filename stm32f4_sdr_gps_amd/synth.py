@@ -100,7 +100,8 @@ def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, s
     return out
 
 
-def make_if_static(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, batch_ms: int = 250) -> np.ndarray:
+def make_if_static(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, batch_ms: int = 250,
+                   two_bit: bool = False, mag_threshold: float = 0.6) -> np.ndarray:
     """make_if for MANY satellites over MANY milliseconds (BASELINE.json configs[4] as SURVEY.md 8(d) words it: 256 signals,
     10 000 ms), for satellites without navigation data.  One millisecond is exactly 1023 chips and 4092 IF cycles, so a
     satellite's samples of millisecond m are those of millisecond 0 with the carrier turned by alpha = 2 pi fd m / 1000:
@@ -123,7 +124,7 @@ def make_if_static(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int
         basis[2 * k] = np.rint(s.amp * code[chip] * np.cos(theta) * 32768.0)
         basis[2 * k + 1] = np.rint(s.amp * code[chip] * np.sin(theta) * 32768.0)
     fd = np.array([s.doppler_hz for s in sats])
-    out = np.zeros((n_ms, BYTES_PER_MS), np.uint8)
+    out = np.zeros((n_ms, 4092 if two_bit else BYTES_PER_MS), np.uint8)
     for m0 in range(0, n_ms, batch_ms):
         m = np.arange(m0, min(n_ms, m0 + batch_ms), dtype=np.float64)
         alpha = 2.0 * np.pi * np.outer(m, fd) / 1000.0
@@ -133,7 +134,13 @@ def make_if_static(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int
         x = turn @ basis
         if noise_amp > 0:
             x += np.rint(rng.uniform(-noise_amp, noise_amp, x.shape) * float(1 << 30))
-        out[m0:m0 + len(m)] = np.packbits(x >= 0, axis=1, bitorder="little")
+        if two_bit:      # sign / magnitude pairs as pack_2bit lays them out: sample n in bits 2 (n & 3), 2 (n & 3) + 1 of byte n >> 2
+            pairs = np.empty((len(m), 2 * SAMPLES_PER_MS), bool)
+            pairs[:, 0::2] = x >= 0
+            pairs[:, 1::2] = np.abs(x) > mag_threshold * float(1 << 30)
+            out[m0:m0 + len(m)] = np.packbits(pairs, axis=1, bitorder="little")
+        else:
+            out[m0:m0 + len(m)] = np.packbits(x >= 0, axis=1, bitorder="little")
     return out
 
 
@@ -230,4 +237,6 @@ def cold_start_block(n_ms: int = 1, seed: int = 11, amp_scale: float = 1.0, two_
     base = [(3, -3210.0, 777.0, 0.5, 0.7), (5, 912.5, 1600.0, 0.6, 0.3), (11, 4480.0, 12001.0, 0.5, 5.1),
             (14, 4037.0, 4000.0, 0.6, 1.1), (20, -1025.0, 9000.0, 0.6, 2.5), (30, 2018.0, 13000.0, 0.6, 4.0)]
     sats = [Sat(p, f, d, a * amp_scale, ph) for (p, f, d, a, ph) in base]
-    return make_if(n_ms, sats, noise_amp=1.0, seed=seed, two_bit=two_bit)   # same samples either way: same sign plane
+    # (make_if_static: the same signal model in exact integer arithmetic, ~20 x faster than make_if -- the 8-GPU bench synthesises
+    #  20 480 blocks per rank; same samples with and without two_bit: same sign plane)
+    return make_if_static(n_ms, sats, noise_amp=1.0, seed=seed, two_bit=two_bit)
