@@ -601,12 +601,13 @@ constexpr float kOutside = -1048576.0f * kAccScale;   // start value (scaled) of
                                                       // below -1, clips to 0
 
 // Start of a block: every accumulator = the part of  cnt - 8184  that does not depend on the code (even byte offsets)
+// (ones: pop(D) of the two streams -- sh.ones, or the other block's pair in the pipelined byte-phase form)
 template <int NT>
-__device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][NT], int win_start,
+__device__ __forceinline__ void mx_init_acc(const u32 *ones, int lane, int q0_tile, v16f (&acc)[2][NT], int win_start,
                                             int win_stop)
 {
   const int n = lane & 31;
-  const float base_i = (float)((int)sh.ones[0] + 8192 - kHalf) * kAccScale, base_q = (float)((int)sh.ones[1] + 8192 - kHalf) * kAccScale;
+  const float base_i = (float)((int)ones[0] + 8192 - kHalf) * kAccScale, base_q = (float)((int)ones[1] + 8192 - kHalf) * kAccScale;
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
@@ -629,12 +630,13 @@ __device__ __forceinline__ void mx_init_acc(const MxShared &sh, int lane, int q0
 // byte of W (data byte 2045, never mixed) is zero.  At b = 0: A = 0, alpha = 0.
 // DIRECT: the accumulators were started afresh for sample offset 8 (mx_vector_build_direct) -- they never held A_7 of the even
 // offsets, so only the odd offset's own terms are put in.
+// (d_i / d_q: the block's wiped streams -- sh.d[0] / sh.d[1], or the other block's pair in the pipelined byte-phase form)
 template <bool DIRECT, int NT>
-__device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][NT], int win_start,
-                                               int win_stop)
+__device__ __forceinline__ void mx_half_switch(const MxShared &sh, const u32 *d_i, const u32 *d_q, int lane, int q0_tile,
+                                               v16f (&acc)[2][NT], int win_start, int win_stop)
 {
   const int n = lane & 31, h = lane >> 5;
-  const u32 wrap_i = (sh.d[0][0] & 0xFFu) << 8, wrap_q = (sh.d[1][0] & 0xFFu) << 8;
+  const u32 wrap_i = (d_i[0] & 0xFFu) << 8, wrap_q = (d_q[0] & 0xFFu) << 8;
   const float beta0_i = (float)(16 - 2 * (int)__popc(wrap_i)) * kAccScale, beta0_q = (float)(16 - 2 * (int)__popc(wrap_q)) * kAccScale;
   const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
   const u32 f22 = sh.chip_t[1022 + 1] >> (4 * h);
@@ -646,12 +648,12 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
     const bool in0 = exists && 2 * q >= win_start && 2 * q < win_stop;
     const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
     // A_7 of the even offset goes, A_0 = 0 of the odd one comes
-    int fa_i = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(sh.d[0], 2 * qc) & 0x7Fu) - 7);
-    int fa_q = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(sh.d[1], 2 * qc) & 0x7Fu) - 7);
+    int fa_i = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(d_i, 2 * qc) & 0x7Fu) - 7);
+    int fa_q = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(d_q, 2 * qc) & 0x7Fu) - 7);
     int fk_i = -popw_i, fk_q = -popw_q;
     if (q > 0 && exists) {
-      const u32 prev_i = lds_byte(sh.d[0], 2 * qc - 1) | (lds_byte(sh.d[0], 2 * qc) << 8);
-      const u32 prev_q = lds_byte(sh.d[1], 2 * qc - 1) | (lds_byte(sh.d[1], 2 * qc) << 8);
+      const u32 prev_i = lds_byte(d_i, 2 * qc - 1) | (lds_byte(d_i, 2 * qc) << 8);
+      const u32 prev_q = lds_byte(d_q, 2 * qc - 1) | (lds_byte(d_q, 2 * qc) << 8);
       fk_i -= (int)__popc(prev_i);
       fk_q -= (int)__popc(prev_q);
       fa_i -= 16 - 2 * (int)__popc(prev_i);
@@ -671,6 +673,64 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int
       acc[0][j][r] += fkf_i + c22 * faf_i - c1 * beta0_i;
       acc[1][j][r] += fkf_q + c22 * faf_q - c1 * beta0_q;
     }
+  }
+}
+
+// ---- sample offset 8 started directly, with the odd byte offset's terms in the start values and in ONE extra K step per pass -----
+// (the pipelined byte-phase form; mx_half_switch<DIRECT> is the same sum patched in by the vector ALU after the passes.)
+//   extra(q, p) = - pop(W) - chip_p[1022 - q] beta_0 + T(q) [ (2 c1022_p - 1) S_8[q - 1] - 16 c1022_p ]
+// because P = data bytes (2 q - 1, 2 q) IS the block D[16 (q - 1) + 8, +16) whose popcount the offset-8 vectors already carry
+// as entry q - 1: the tail word acts as one more chip, "chip -1" = chip 1022 in +-1 form.  So
+//   * start values:  base - pop(W) - chip_p[1022 - q] beta_0   (one multiply-add per accumulator: mx_init_acc_odd);
+//   * per pass one MFMA per tile and stream (mx_odd_tail_step): A column 0 of lane half 0 = -(2 c1022 - 1) / 2 against nibble
+//     q - 1 of the pass's own vector (-2 (S & 3), then -(S >> 2) at 2^3), and in the high pass column 0 of lane half 1 = c1022
+//     against -2 at 2^3; both B entries zero for q = 0.
+template <int NT>
+__device__ __forceinline__ void mx_init_acc_odd(const MxShared &sh, const u32 *ones, const u32 *d_i, const u32 *d_q, int lane,
+                                                int q0_tile, v16f (&acc)[2][NT], int win_start, int win_stop)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const int popw_i = (int)__popc(d_i[0] & 0xFFu), popw_q = (int)__popc(d_q[0] & 0xFFu);
+  const float base_i = (float)((int)ones[0] + 8192 - kHalf - popw_i) * kAccScale;
+  const float base_q = (float)((int)ones[1] + 8192 - kHalf - popw_q) * kAccScale;
+  const float nb_i = (float)(2 * popw_i - 16) * kAccScale, nb_q = (float)(2 * popw_q - 16) * kAccScale;   // -beta_0
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    const bool exists = q < kChips;
+    const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
+    const float start_i = in1 ? base_i : base_i + kOutside, start_q = in1 ? base_q : base_q + kOutside;
+    const u32 w1 = sh.chip_t[(exists ? kChips - 1 - q : 0) + 1] >> (4 * h);   // chip 1022 - q of the lane's PRNs
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float c1 = (float)((w1 >> ((r & 3) + 8 * (r >> 2))) & 1u);
+      acc[0][j][r] = __builtin_fmaf(c1, nb_i, start_i);   // (exact either way: multiples of 2^-13 below 2^8)
+      acc[1][j][r] = __builtin_fmaf(c1, nb_q, start_q);
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void mx_odd_tail_step(const MxShared &sh, const u32 *vec, bool high, int lane, int q0_tile,
+                                                 v16f (&acc)[2][NT], u32 scale_b)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const u32 c22 = (sh.chip_t[1022 + 1] >> n) & 1u;   // A row n = PRN n of the cluster
+  const u32 a0 = h == 0 ? (c22 ? 0x9u : 0x1u) : (high ? c22 << 1 : 0u);   // FP4: -0.5 / +0.5; 1.0
+  const v4i a = v4i{(int)a0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int q = 32 * (q0_tile + 2 * j) + n;
+    const int e = q > 0 ? q - 1 : 0;
+    // entry q - 1 of the vector (copy 0, dword e / 8) moved to nibble 0; what is left above it meets zero columns of A
+    u32 bi = vec[e >> 3] >> (4 * (e & 7)), bq = vec[8 * kCopyDwords + (e >> 3)] >> (4 * (e & 7));
+    if (h)
+      bi = bq = high ? 0xCu : 0u;   // FP4 -2
+    if (q == 0)
+      bi = bq = 0;
+    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a), widen(v4i{(int)bi, 0, 0, 0}), acc[0][j], 4, 4, 0, kScaleA, 0,
+                                                                 scale_b);
+    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a), widen(v4i{(int)bq, 0, 0, 0}), acc[1][j], 4, 4, 0, kScaleA, 0,
+                                                                 scale_b);
   }
 }
 
@@ -1029,11 +1089,13 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
 constexpr u32 kRootBias = 0x4B000000u;
 template <int NT>
 __device__ __forceinline__ void mx_epilogue_single(MxShared &sh, int lane, const u32 (&kq)[NT], int t0,
-                                                   const v16f (&acc)[2][NT], bool half_only = false, bool half_atomics = false)
+                                                   const v16f (&acc)[2][NT], bool half_only = false, bool half_atomics = false,
+                                                   int slots = -1)
 {
+  // (slots: which eighth of sh.part takes the results -- the bit shift's own, unless the pipelined byte-phase form says otherwise)
   const int n = lane & 31, h = lane >> 5;
   const int b = t0 & 7, half = t0 >> 3;
-  u32 *slot = &sh.part[b][4 * h][0][n];
+  u32 *slot = &sh.part[slots < 0 ? b : slots][4 * h][0][n];
   u32 best[16], total[16];
   // key = (magnitude << 11) | (2047 - byte offset), byte offset = 2 q + half: kq = 2047 - 2 q is the lane's own constant
   // (>= 1), the wave-uniform half comes off it here, once per tile
@@ -1143,7 +1205,7 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
 
 
 
-constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5;   // k_acq_mx's MODE
+constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5, kMxBytePipe = 6;   // k_acq_mx's MODE
 
 }  // namespace
 
@@ -1325,11 +1387,11 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         const int item = x >> 1, o = item >> 1, q0t = q0_tile + 4 * (item & 1);   // sample offset 8 o, q-tiles q0t and q0t + 2
         if ((x & 1) == 0) {
           const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + 2 * 8 * kCopyDwords : &sh.e8[1][0][0][0];
-          mx_init_acc(sh, lane, q0t, acc, prm.win_start, prm.win_stop);
+          mx_init_acc(sh.ones, lane, q0t, acc, prm.win_start, prm.win_stop);
           mx_pass<true>(sh, 0, lane, q0t, acc, kScaleOne, a_corr, false, va);
           mx_pass<true>(sh, 1, lane, q0t, acc, kScaleEight, a_corr, false, vb);
           if (o)
-            mx_half_switch<true>(sh, lane, q0t, acc, prm.win_start, prm.win_stop);
+            mx_half_switch<true>(sh, sh.d[0], sh.d[1], lane, q0t, acc, prm.win_start, prm.win_stop);
         } else {
           const u32 kq2[2] = {(u32)(2047 - 2 * (32 * q0t + (lane & 31))), (u32)(2047 - 2 * (32 * (q0t + 2) + (lane & 31)))};
           mx_epilogue_single(sh, lane, kq2, 8 * o, acc);
@@ -1355,7 +1417,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     }
 
     v16f acc[2][kMxTiles];
-    mx_init_acc(sh, lane_p, q0_tile, acc, prm.win_start, prm.win_stop);
+    mx_init_acc(sh.ones, lane_p, q0_tile, acc, prm.win_start, prm.win_stop);
     if ((ex & 2) || ((ex & 32) && role)) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
 #pragma unroll
       for (int j = 0; j < kMxTiles; j++)
@@ -1419,7 +1481,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
           }
         } else {
           if (p == 9)
-            mx_half_switch<false>(sh, lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
+            mx_half_switch<false>(sh, sh.d[0], sh.d[1], lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
         }
       }
       if (STORE) {
@@ -1499,6 +1561,294 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
   }
 }
 
+// ---- the byte-phase grid as ONE software pipeline over the clusters of a persistent workgroup (k_acq_mx<6>) -----------------
+// Same stages as the BYTE branch of mx_unit -- per cluster four (tile pair, sample offset) items per wave, each a pass half
+// (start values, two passes on two q-tiles, the odd offset's terms) and an epilogue half, the two waves of a SIMD half a stage
+// apart -- but the clusters follow each other WITHOUT a fill and a drain half stage and without a preamble between them:
+// cluster c is half stages H = 8 c .. 8 c + 7 for waves 0..3 and one later for waves 4..7, and what cluster c + 1 needs is made
+// by all eight waves behind the barriers of cluster c's stages, one piece per barrier, each in a buffer nobody reads then:
+//   h = 0  the offset-8 vectors of cluster c itself (from the block sums; their buffer was read until h = 7 of cluster c - 1;
+//          first use h = 4), and the request for cluster c + 1's capture block -- into registers, not waited for;
+//   h = 2  those registers -> LDS; the triplets of cluster c - 1 (its last epilogue ran in h = 0), result slots zeroed again;
+//   h = 4  cluster c + 1's wipe-off, pop(D), block sums of both sample offsets -> the OTHER copy of d / ones, the sums' bytes;
+//   h = 6  cluster c + 1's offset-0 vectors (their buffer was read until h = 3; first use h = 8).
+// Two copies of what a stage reads of its block (d, ones) and two result slots (sh.part[0] / [6]), by the cluster's parity.
+struct MxBlockRegs {
+  u32 v[4];
+};
+__device__ __forceinline__ MxBlockRegs mx_block_request(const uint8_t *blk, int if_format, int tid)
+{
+  // thread t: 16-bit words 2 t and 2 t + 1 of the sign plane (1023 exist), as load_sign16 reads them
+  MxBlockRegs r;
+  const uint16_t *p = reinterpret_cast<const uint16_t *>(blk);
+  const bool second = 2 * tid + 1 < kWords16;
+  if (if_format == GPSX_IF_2BIT_SM) {
+    r.v[0] = p[4 * tid];
+    r.v[1] = p[4 * tid + 1];
+    r.v[2] = second ? p[4 * tid + 2] : 0;
+    r.v[3] = second ? p[4 * tid + 3] : 0;
+  } else {
+    r.v[0] = p[2 * tid];
+    r.v[1] = second ? p[2 * tid + 1] : 0;
+    r.v[2] = r.v[3] = 0;
+  }
+  return r;
+}
+__device__ __forceinline__ void mx_block_commit(MxShared &sh, const MxBlockRegs &r, int if_format, int tid)
+{
+  u32 lo = r.v[0], hi = r.v[1];
+  if (if_format == GPSX_IF_2BIT_SM) {
+    lo = even_bits16(r.v[0] | (r.v[1] << 16));
+    hi = even_bits16(r.v[2] | (r.v[3] << 16));
+  }
+  reinterpret_cast<u32 *>(sh.x)[tid] = (lo & 0xFFFFu) | (hi << 16);
+}
+
+// wipe-off of the block in sh.x -> d[2][514] (word 511 = the wrap-around copy), pop(D) -> ones (zeroed beforehand), and the block
+// sums S_0 / S_8 as bytes -> sums[stream][offset 0 / 8][1024]: one word per thread, the neighbour word wiped a second time
+// instead of a barrier between the stream and its sums
+__device__ __forceinline__ void mx_byte_wipe_sums(const MxShared &sh, u32 *d, u32 *ones, uint8_t *sums, u32 step_word, int tid,
+                                                  int lane)
+{
+  const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
+  const int w = tid;
+  const u32 x_first = x32[0], x_cur = x32[w], x_next = x32[w < 511 ? w + 1 : 0];
+  const u32 quad_cur = (step_word * (u32)w) >> 30, quad_next = (step_word * (u32)(w + 1)) >> 30;
+  u32 cnt[2];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const u32 wrap = ((s ? carrier_q(0u) : carrier_i(0u)) ^ x_first) << 16;   // samples 16352..16367 are zero, then sample 0 again
+    const u32 cur = w < kWords32 ? (s ? carrier_q(quad_cur) : carrier_i(quad_cur)) ^ x_cur : wrap;
+    const u32 nxt = w + 1 < kWords32 ? (s ? carrier_q(quad_next) : carrier_i(quad_next)) ^ x_next : (w + 1 == kWords32 ? wrap : 0u);
+    d[s * 514 + w] = cur;
+    cnt[s] = w < kWords32 ? (u32)__popc(cur) : 0u;
+    const u32 x8 = __builtin_amdgcn_alignbit(nxt, cur, 8u);
+    reinterpret_cast<uint16_t *>(sums + (2 * s) * 1024)[w] = (uint16_t)(pop16(cur) | ((u32)__popc(cur >> 16) << 8));
+    reinterpret_cast<uint16_t *>(sums + (2 * s + 1) * 1024)[w] = (uint16_t)(pop16(x8) | ((u32)__popc(x8 >> 16) << 8));
+  }
+  cnt[0] = wave_sum_to_lane63(cnt[0]);
+  cnt[1] = wave_sum_to_lane63(cnt[1]);
+  if (lane == 63) {
+    atomicAdd(&ones[0], cnt[0]);
+    atomicAdd(&ones[1], cnt[1]);
+  }
+}
+
+// the low and the high vector of sample offset 8 o from the block sums' bytes (mx_build_byte_vectors, one offset)
+__device__ __forceinline__ void mx_byte_vector_pair(const uint8_t *sums, int o, u32 *dst_low, u32 *dst_high, int tid)
+{
+  const int iq = tid >> 8, j = tid & 255;
+  const uint8_t *sv = sums + (2 * iq + o) * 1024;
+  u32 lo[2] = {0, 0}, hi[2] = {0, 0};   // [which]: dwords j and j + 1 of copy 0
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const u32 sum = sv[wrap1023(8 * j + e)];
+    const u32 c0 = (0xFEC0u >> (4u * (sum & 3u))) & 0xFu;
+    const u32 c1 = (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;
+    if (e < 8) {
+      lo[0] |= c0 << (4 * e);
+      lo[1] |= c1 << (4 * e);
+    } else {
+      hi[0] |= c0 << (4 * (e - 8));
+      hi[1] |= c1 << (4 * (e - 8));
+    }
+  }
+#pragma unroll
+  for (int which = 0; which < 2; which++) {
+    u32 *dst = (which ? dst_high : dst_low) + (iq * 8) * kCopyDwords + j;
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi[which], lo[which], 4u * (u32)c) : lo[which];
+  }
+}
+
+// the triplets of one cluster from result slots `slots` of sh.part (bit shift 0 only), and the slots back to zero: thread
+// (which, PRN, eighth) folds four lane slots, the eight threads of a PRN meet over DPP / permutes
+__device__ __forceinline__ void mx_byte_fold(MxShared &sh, int slots, u32 group_mask, int set, int search, int dopp,
+                                             const AcqParams &prm, gpsx_peak_t *__restrict__ peaks, int tid)
+{
+  const int which = tid >> 8, p = (tid >> 3) & 31, part = tid & 7;
+  uint4 *row = reinterpret_cast<uint4 *>(&sh.part[slots][p][which][4 * part]);
+  const uint4 v = *row;
+  *row = make_uint4(0, 0, 0, 0);
+  u32 k = max(max(v.x, v.y), max(v.z, v.w)), t = v.x + v.y + v.z + v.w;
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+    const u32 ko = (u32)__shfl_xor((int)k, m, 64), to = (u32)__shfl_xor((int)t, m, 64);
+    k = ko > k ? ko : k;
+    t += to;
+  }
+  const int slot = 32 * set + p;
+  if (part == 0 && ((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn) {
+    const size_t idx = ((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits;
+    uint2 *pk = reinterpret_cast<uint2 *>(&peaks[idx]);
+    if (which == 0) {
+      const u32 max_val = k >> 11;
+      pk[0] = make_uint2(max_val, max_val ? 2047u - (k & 2047u) : 0u);   // gpsx_peak_t: max_val, phase
+    } else {
+      pk[1] = make_uint2(t, t / (2u * kChips));                          //              sum, avr
+    }
+  }
+}
+
+__device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm, int cluster_lo,
+                                             const uint8_t *__restrict__ if_blocks, const u32 *__restrict__ mx_a,
+                                             const u32 *__restrict__ mx_t, gpsx_peak_t *__restrict__ peaks)
+{
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2;                            // waves w and w + 4 share a SIMD: half a stage apart
+  const int q0_tile = 8 * (wave >> 1) + (wave & 1);
+  const int n_sets = (prm.n_groups + 3) / 4;
+  const int stride = (int)gridDim.x, first = cluster_lo + (int)blockIdx.x;
+  const int n_my = (prm.n_clusters - (int)blockIdx.x + stride - 1) / stride;   // clusters first, first + stride, ...: >= 1
+  const int set = first % n_sets;                        // (the launcher's grid is a multiple of n_sets: one PRN set per workgroup)
+  const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
+
+  // what the stages read of a block, twice; the sums' bytes (in the polyphase planes' LDS, which this form does not use)
+  uint8_t *overlay = reinterpret_cast<uint8_t *>(&sh.plane[0][0][0]);
+  uint8_t *sums = overlay;
+  u32 *d_alt = reinterpret_cast<u32 *>(overlay + 4096), *ones_alt = d_alt + 2 * 514;
+  static_assert(sizeof(sh.plane) >= 4096 + (2 * 514 + 2) * sizeof(u32), "block sums and the second copy of d / ones fit the planes");
+  u32 *e8x = &sh.part[1][0][0][0];                       // the offset-8 vectors: result slots of bit shifts 1..5
+  constexpr int kVec = 2 * 8 * kCopyDwords, kSlotsEven = 0, kSlotsOdd = 6;
+  static_assert(2 * kVec * sizeof(u32) <= 5 * sizeof(sh.part[0]), "two vectors below result slots 6");
+
+  auto decode = [&](int i, int &search, int &dopp, u32 &mask) {
+    const int sd = (first + i * stride) / n_sets;
+    dopp = sd % prm.n_dopp;
+    search = sd / prm.n_dopp;
+    mask = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int group = 4 * set + g, unit = sd * prm.n_groups + group;
+      if (group < prm.n_groups && unit >= prm.unit_lo && unit < prm.unit_hi)
+        mask |= 1u << g;
+    }
+  };
+  auto block_of = [&](int i) {
+    int search, dopp;
+    u32 mask;
+    decode(i, search, dopp, mask);
+    return if_blocks + (size_t)(search * prm.search_stride_blocks) * block_bytes;
+  };
+  auto step_of = [&](int i) {
+    int search, dopp;
+    u32 mask;
+    decode(i, search, dopp, mask);
+    return nco_step_per_word((float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz));   // PM/GPS/acquisition.c:285-289
+  };
+
+  // ---- fill: tables of the PRN set, cluster 0 up to its offset-0 vectors ---------------------------------------------------
+  {
+    MxBlockRegs b0 = mx_block_request(block_of(0), prm.if_format, tid);
+    const u32 *src_a = mx_a + (size_t)set * (16 * 2 * 32 * 4);
+    u32 *dst_a = reinterpret_cast<u32 *>(&sh.chips_a[0][0][0]);
+    for (int i = tid; i < 16 * 2 * 32 * 4; i += kMxThreads)
+      dst_a[i] = src_a[i];
+    const u32 *src_t = mx_t + (size_t)set * 1032;
+    for (int i = tid; i < 1032; i += kMxThreads)
+      sh.chip_t[i] = src_t[i];
+    for (int i = tid; i < 2 * (int)(sizeof(sh.part[0]) / sizeof(uint4)); i += kMxThreads) {
+      const int s = i / (int)(sizeof(sh.part[0]) / sizeof(uint4)), k = i % (int)(sizeof(sh.part[0]) / sizeof(uint4));
+      reinterpret_cast<uint4 *>(&sh.part[s ? kSlotsOdd : kSlotsEven][0][0][0])[k] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid < 2) {
+      sh.ones[tid] = 0;
+      ones_alt[tid] = 0;
+    }
+    if (tid < 4) {   // the zero pad behind the wrap-around word, both copies
+      sh.d[tid >> 1][512 + (tid & 1)] = 0;
+      d_alt[(tid >> 1) * 514 + 512 + (tid & 1)] = 0;
+    }
+    mx_block_commit(sh, b0, prm.if_format, tid);
+    __syncthreads();
+    mx_byte_wipe_sums(sh, &sh.d[0][0], sh.ones, sums, step_of(0), tid, lane);
+    __syncthreads();
+    mx_byte_vector_pair(sums, 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], tid);
+  }
+  const v4i a_corr = v4i{0, 0, 0, 0};   // (no extra K step in this form)
+
+  MxBlockRegs next_block = {{0, 0, 0, 0}};
+  v16f acc[2][2];
+  const int n_half = 8 * n_my;
+#ifdef GPSX_MX_TIMELINE   // (tools/experiments/byte_timeline.py: cycle stamps of workgroup 0's waves 0 and 4 behind the peaks)
+  unsigned long long *tl = blockIdx.x == 0 && lane == 0 && (wave & 3) == 0
+                               ? reinterpret_cast<unsigned long long *>(peaks + (size_t)prm.n_clusters * 32) + role * 2048 : nullptr;
+  int tli = 0;
+#define MX_TL() do { if (tl && tli < 2048) tl[tli++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MX_TL() do { } while (0)
+#endif
+#pragma unroll 1
+  for (int hs = 0; hs <= n_half; hs++) {
+    MX_TL();
+    if ((hs & 1) == 0) {
+      __syncthreads();
+      MX_TL();
+      int t = tid;
+      asm volatile("" : "+v"(t));   // (per-thread addresses of these pieces are recomputed, not kept across the stages)
+      const int c = hs >> 3, h = hs & 7;
+      const bool more = c + 1 < n_my;
+      if (h == 0) {
+        if (c < n_my)
+          mx_byte_vector_pair(sums, 1, e8x, e8x + kVec, t);
+        if (more)
+          next_block = mx_block_request(block_of(c + 1), prm.if_format, t);
+      } else if (h == 2) {
+        if (more) {
+          mx_block_commit(sh, next_block, prm.if_format, t);
+          if (t < 2)
+            ((c + 1) & 1 ? ones_alt : sh.ones)[t] = 0;
+        }
+        if (c >= 1) {
+          int search, dopp;
+          u32 mask;
+          decode(c - 1, search, dopp, mask);
+          mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
+        }
+      } else if (h == 4) {
+        if (more)
+          mx_byte_wipe_sums(sh, (c + 1) & 1 ? d_alt : &sh.d[0][0], (c + 1) & 1 ? ones_alt : sh.ones, sums, step_of(c + 1), t, t & 63);
+      } else {
+        if (more)
+          mx_byte_vector_pair(sums, 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+      }
+    }
+    MX_TL();
+    const int x = hs - role;   // this role's half stage
+    if (x < 0 || x >= n_half)
+      continue;
+    const int cc = x >> 3, item = (x & 7) >> 1, o = item >> 1, q0t = q0_tile + 4 * (item & 1);   // sample offset 8 o, q-tiles q0t, q0t + 2
+    if ((x & 1) == 0) {
+      const u32 *dd = cc & 1 ? d_alt : &sh.d[0][0];
+      const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + kVec : &sh.e8[1][0][0][0];
+      const u32 *ones = cc & 1 ? ones_alt : sh.ones;
+      if (o)
+        mx_init_acc_odd(sh, ones, dd, dd + 514, lane, q0t, acc, prm.win_start, prm.win_stop);
+      else
+        mx_init_acc(ones, lane, q0t, acc, prm.win_start, prm.win_stop);
+      mx_pass<true>(sh, 0, lane, q0t, acc, kScaleOne, a_corr, false, va);
+      if (o)
+        mx_odd_tail_step(sh, va, false, lane, q0t, acc, kScaleOne);
+      mx_pass<true>(sh, 1, lane, q0t, acc, kScaleEight, a_corr, false, vb);
+      if (o)
+        mx_odd_tail_step(sh, vb, true, lane, q0t, acc, kScaleEight);
+    } else {
+      const u32 kq2[2] = {(u32)(2047 - 2 * (32 * q0t + (lane & 31))), (u32)(2047 - 2 * (32 * (q0t + 2) + (lane & 31)))};
+      mx_epilogue_single(sh, lane, kq2, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
+    }
+  }
+  __syncthreads();
+  {
+    int search, dopp;
+    u32 mask;
+    decode(n_my - 1, search, dopp, mask);
+    mx_byte_fold(sh, (n_my - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, tid);
+  }
+}
+
+
 template <int MODE>
 __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,
                                                           const u32 *__restrict__ mx_a, const u32 *__restrict__ mx_t,
@@ -1507,7 +1857,9 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
 {
   __shared__ MxShared sh;
   int tables_set = -1;
-  if constexpr (MODE == kMxByte) {
+  if constexpr (MODE == kMxBytePipe) {
+    mx_byte_pipe(sh, prm, cluster_lo, if_blocks, mx_a, mx_t, peaks);
+  } else if constexpr (MODE == kMxByte) {
     // persistent: one workgroup per CU walks the clusters -- no dispatch gap between them, the PRN set's tables loaded once
 #pragma unroll 1
     for (int wg = (int)blockIdx.x; wg < prm.n_clusters; wg += (int)gridDim.x) {
@@ -1567,6 +1919,14 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   if (prm.n_bits == 1) {   // byte-phase grid: sample offsets 0 and 8, each started from its own block sums
     AcqParams bp = prm;
     bp.n_clusters = c_hi - c_lo;
+    if (!prm.byte_legacy) {
+      // one software pipeline per persistent workgroup; a workgroup keeps ONE PRN set's tables: the grid is a multiple of n_sets
+      const int n_sets = (prm.n_groups + 3) / 4;
+      const int grid = bp.n_clusters < n_cus ? bp.n_clusters : n_cus - n_cus % n_sets;
+      hipLaunchKernelGGL(k_acq_mx<kMxBytePipe>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t,
+                         d_peaks, (u32 *)nullptr, (u32 *)nullptr);
+      return "k_acq_mx<6>";
+    }
     const int grid = c_hi - c_lo < n_cus ? c_hi - c_lo : n_cus;
     hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t,
                        d_peaks, (u32 *)nullptr, (u32 *)nullptr);
