@@ -1562,17 +1562,12 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
 }
 
 // ---- the byte-phase grid as ONE software pipeline over the clusters of a persistent workgroup (k_acq_mx<6>) -----------------
-// Same stages as the BYTE branch of mx_unit -- per cluster four (tile pair, sample offset) items per wave, each a pass half
-// (start values, two passes on two q-tiles, the odd offset's terms) and an epilogue half, the two waves of a SIMD half a stage
-// apart -- but the clusters follow each other WITHOUT a fill and a drain half stage and without a preamble between them:
-// cluster c is half stages H = 8 c .. 8 c + 7 for waves 0..3 and one later for waves 4..7, and what cluster c + 1 needs is made
-// by all eight waves behind the barriers of cluster c's stages, one piece per barrier, each in a buffer nobody reads then:
-//   h = 0  the offset-8 vectors of cluster c itself (from the block sums; their buffer was read until h = 7 of cluster c - 1;
-//          first use h = 4), and the request for cluster c + 1's capture block -- into registers, not waited for;
-//   h = 2  those registers -> LDS; the triplets of cluster c - 1 (its last epilogue ran in h = 0), result slots zeroed again;
-//   h = 4  cluster c + 1's wipe-off, pop(D), block sums of both sample offsets -> the OTHER copy of d / ones, the sums' bytes;
-//   h = 6  cluster c + 1's offset-0 vectors (their buffer was read until h = 3; first use h = 8).
-// Two copies of what a stage reads of its block (d, ones) and two result slots (sh.part[0] / [6]), by the cluster's parity.
+// Per cluster and wave two stages -- sample offset 0, sample offset 8, each started from its own block sums: start values, two
+// passes on the wave's four q-tiles, an epilogue of 64 hypotheses per lane -- the two waves of a SIMD half a stage apart, one
+// barrier per stage.  The clusters follow each other WITHOUT a fill and a drain half stage and without a preamble between them:
+// what cluster c + 1 and c + 2 need is made by all eight waves behind the barriers of cluster c's stages, each piece in a buffer
+// nobody reads then (mx_byte_pipe).  Two copies of what a stage reads of its block (d), of the sums' bytes and of the result
+// slots (sh.part[0] / [6]) by the cluster's parity; three of pop(D).
 struct MxBlockRegs {
   u32 v[4];
 };
@@ -1698,19 +1693,20 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2;                            // waves w and w + 4 share a SIMD: half a stage apart
-  const int q0_tile = 8 * (wave >> 1) + (wave & 1);
+  const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
   const int n_sets = (prm.n_groups + 3) / 4;
   const int stride = (int)gridDim.x, first = cluster_lo + (int)blockIdx.x;
   const int n_my = (prm.n_clusters - (int)blockIdx.x + stride - 1) / stride;   // clusters first, first + stride, ...: >= 1
   const int set = first % n_sets;                        // (the launcher's grid is a multiple of n_sets: one PRN set per workgroup)
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
 
-  // what the stages read of a block, twice; the sums' bytes (in the polyphase planes' LDS, which this form does not use)
+  // LDS this form has to itself: the polyphase planes (second copy of d, three of ones, the sums' bytes of even clusters), the
+  // extra K step's vectors (the sums' bytes of odd clusters), result slots 1..5 (the offset-8 vectors) and 6 (odd clusters' results)
   uint8_t *overlay = reinterpret_cast<uint8_t *>(&sh.plane[0][0][0]);
-  uint8_t *sums = overlay;
-  u32 *d_alt = reinterpret_cast<u32 *>(overlay + 4096), *ones_alt = d_alt + 2 * 514;
-  static_assert(sizeof(sh.plane) >= 4096 + (2 * 514 + 2) * sizeof(u32), "block sums and the second copy of d / ones fit the planes");
-  u32 *e8x = &sh.part[1][0][0][0];                       // the offset-8 vectors: result slots of bit shifts 1..5
+  uint8_t *sums_even = overlay, *sums_odd = reinterpret_cast<uint8_t *>(&sh.corr[0][0][0][0]);
+  u32 *d_alt = reinterpret_cast<u32 *>(overlay + 4096), *ones3 = d_alt + 2 * 514;   // ones3[3][2]
+  static_assert(sizeof(sh.plane) >= 4096 + (2 * 514 + 6) * sizeof(u32) && sizeof(sh.corr) >= 4096, "overlays fit");
+  u32 *e8x = &sh.part[1][0][0][0];
   constexpr int kVec = 2 * 8 * kCopyDwords, kSlotsEven = 0, kSlotsOdd = 6;
   static_assert(2 * kVec * sizeof(u32) <= 5 * sizeof(sh.part[0]), "two vectors below result slots 6");
 
@@ -1738,10 +1734,14 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     decode(i, search, dopp, mask);
     return nco_step_per_word((float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz));   // PM/GPS/acquisition.c:285-289
   };
+  auto d_of = [&](int i) { return i & 1 ? d_alt : &sh.d[0][0]; };
+  auto ones_of = [&](int i) { return ones3 + 2 * (i % 3); };
+  auto sums_of = [&](int i) { return i & 1 ? sums_odd : sums_even; };
 
-  // ---- fill: tables of the PRN set, cluster 0 up to its offset-0 vectors ---------------------------------------------------
+  // ---- fill: tables of the PRN set, cluster 0 up to its offset-0 vectors, cluster 1's block in LDS ------------------------------
   {
     MxBlockRegs b0 = mx_block_request(block_of(0), prm.if_format, tid);
+    MxBlockRegs b1 = n_my > 1 ? mx_block_request(block_of(1), prm.if_format, tid) : b0;
     const u32 *src_a = mx_a + (size_t)set * (16 * 2 * 32 * 4);
     u32 *dst_a = reinterpret_cast<u32 *>(&sh.chips_a[0][0][0]);
     for (int i = tid; i < 16 * 2 * 32 * 4; i += kMxThreads)
@@ -1749,29 +1749,38 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     const u32 *src_t = mx_t + (size_t)set * 1032;
     for (int i = tid; i < 1032; i += kMxThreads)
       sh.chip_t[i] = src_t[i];
-    for (int i = tid; i < 2 * (int)(sizeof(sh.part[0]) / sizeof(uint4)); i += kMxThreads) {
-      const int s = i / (int)(sizeof(sh.part[0]) / sizeof(uint4)), k = i % (int)(sizeof(sh.part[0]) / sizeof(uint4));
-      reinterpret_cast<uint4 *>(&sh.part[s ? kSlotsOdd : kSlotsEven][0][0][0])[k] = make_uint4(0, 0, 0, 0);
-    }
-    if (tid < 2) {
-      sh.ones[tid] = 0;
-      ones_alt[tid] = 0;
-    }
+    constexpr int kSlotVecs = (int)(sizeof(sh.part[0]) / sizeof(uint4));
+    for (int i = tid; i < 2 * kSlotVecs; i += kMxThreads)
+      reinterpret_cast<uint4 *>(&sh.part[i / kSlotVecs ? kSlotsOdd : kSlotsEven][0][0][0])[i % kSlotVecs] = make_uint4(0, 0, 0, 0);
+    if (tid < 6)
+      ones3[tid] = 0;
     if (tid < 4) {   // the zero pad behind the wrap-around word, both copies
       sh.d[tid >> 1][512 + (tid & 1)] = 0;
       d_alt[(tid >> 1) * 514 + 512 + (tid & 1)] = 0;
     }
     mx_block_commit(sh, b0, prm.if_format, tid);
     __syncthreads();
-    mx_byte_wipe_sums(sh, &sh.d[0][0], sh.ones, sums, step_of(0), tid, lane);
+    mx_byte_wipe_sums(sh, d_of(0), ones_of(0), sums_of(0), step_of(0), tid, lane);
     __syncthreads();
-    mx_byte_vector_pair(sums, 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], tid);
+    mx_byte_vector_pair(sums_of(0), 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], tid);
+    mx_block_commit(sh, b1, prm.if_format, tid);
   }
-  const v4i a_corr = v4i{0, 0, 0, 0};   // (no extra K step in this form)
+  const v4i a_corr = v4i{0, 0, 0, 0};   // (the fine grid's extra K step: not in this form)
+  u32 kq[kMxTiles];   // 2047 - (even byte offset of the lane's chip offset in tile j): the low field of its search keys
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++)
+    kq[j] = (u32)(2047 - 2 * (32 * (q0_tile + 2 * j) + (lane & 31)));
 
+  // Half stages: per cluster four -- passes of sample offset 0 (start values, two passes on the wave's four q-tiles), its epilogue
+  // (64 hypotheses per lane), passes of offset 8 (with the odd offset's extra K step), its epilogue; role 1 one half stage
+  // behind role 0.  One barrier per stage, i.e. two per cluster, and behind them by everybody (c = the cluster role 0 is in):
+  //   start of the offset-0 stage:  the offset-8 vectors of c (read until the half stage before); wipe-off / pop(D) / sums of
+  //                                 c + 1 into the copies c - 1 had; the request for c + 2's block (registers);
+  //   start of the offset-8 stage:  the offset-0 vectors of c + 1; c + 2's block -> LDS, its pop(D) counters zeroed; the
+  //                                 triplets of c - 1 (its last epilogue ran in the half stage before), its slots zeroed.
   MxBlockRegs next_block = {{0, 0, 0, 0}};
-  v16f acc[2][2];
-  const int n_half = 8 * n_my;
+  v16f acc[2][kMxTiles];
+  const int n_half = 4 * n_my;
 #ifdef GPSX_MX_TIMELINE   // (tools/experiments/byte_timeline.py: cycle stamps of workgroup 0's waves 0 and 4 behind the peaks)
   unsigned long long *tl = blockIdx.x == 0 && lane == 0 && (wave & 3) == 0
                                ? reinterpret_cast<unsigned long long *>(peaks + (size_t)prm.n_clusters * 32) + role * 2048 : nullptr;
@@ -1788,18 +1797,21 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
       MX_TL();
       int t = tid;
       asm volatile("" : "+v"(t));   // (per-thread addresses of these pieces are recomputed, not kept across the stages)
-      const int c = hs >> 3, h = hs & 7;
-      const bool more = c + 1 < n_my;
-      if (h == 0) {
+      const int c = hs >> 2;
+      if ((hs & 2) == 0) {
         if (c < n_my)
-          mx_byte_vector_pair(sums, 1, e8x, e8x + kVec, t);
-        if (more)
-          next_block = mx_block_request(block_of(c + 1), prm.if_format, t);
-      } else if (h == 2) {
-        if (more) {
+          mx_byte_vector_pair(sums_of(c), 1, e8x, e8x + kVec, t);
+        if (c + 1 < n_my)
+          mx_byte_wipe_sums(sh, d_of(c + 1), ones_of(c + 1), sums_of(c + 1), step_of(c + 1), t, t & 63);
+        if (c + 2 < n_my)
+          next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
+      } else {
+        if (c + 1 < n_my)
+          mx_byte_vector_pair(sums_of(c + 1), 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+        if (c + 2 < n_my) {
           mx_block_commit(sh, next_block, prm.if_format, t);
           if (t < 2)
-            ((c + 1) & 1 ? ones_alt : sh.ones)[t] = 0;
+            ones_of(c + 2)[t] = 0;
         }
         if (c >= 1) {
           int search, dopp;
@@ -1807,36 +1819,28 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
           decode(c - 1, search, dopp, mask);
           mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
         }
-      } else if (h == 4) {
-        if (more)
-          mx_byte_wipe_sums(sh, (c + 1) & 1 ? d_alt : &sh.d[0][0], (c + 1) & 1 ? ones_alt : sh.ones, sums, step_of(c + 1), t, t & 63);
-      } else {
-        if (more)
-          mx_byte_vector_pair(sums, 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
       }
     }
     MX_TL();
     const int x = hs - role;   // this role's half stage
     if (x < 0 || x >= n_half)
       continue;
-    const int cc = x >> 3, item = (x & 7) >> 1, o = item >> 1, q0t = q0_tile + 4 * (item & 1);   // sample offset 8 o, q-tiles q0t, q0t + 2
+    const int cc = x >> 2, o = (x >> 1) & 1;   // sample offset 8 o
     if ((x & 1) == 0) {
-      const u32 *dd = cc & 1 ? d_alt : &sh.d[0][0];
+      const u32 *dd = d_of(cc), *ones = ones_of(cc);
       const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + kVec : &sh.e8[1][0][0][0];
-      const u32 *ones = cc & 1 ? ones_alt : sh.ones;
       if (o)
-        mx_init_acc_odd(sh, ones, dd, dd + 514, lane, q0t, acc, prm.win_start, prm.win_stop);
+        mx_init_acc_odd(sh, ones, dd, dd + 514, lane, q0_tile, acc, prm.win_start, prm.win_stop);
       else
-        mx_init_acc(ones, lane, q0t, acc, prm.win_start, prm.win_stop);
-      mx_pass<true>(sh, 0, lane, q0t, acc, kScaleOne, a_corr, false, va);
+        mx_init_acc(ones, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+      mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
       if (o)
-        mx_odd_tail_step(sh, va, false, lane, q0t, acc, kScaleOne);
-      mx_pass<true>(sh, 1, lane, q0t, acc, kScaleEight, a_corr, false, vb);
+        mx_odd_tail_step(sh, va, false, lane, q0_tile, acc, kScaleOne);
+      mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
       if (o)
-        mx_odd_tail_step(sh, vb, true, lane, q0t, acc, kScaleEight);
+        mx_odd_tail_step(sh, vb, true, lane, q0_tile, acc, kScaleEight);
     } else {
-      const u32 kq2[2] = {(u32)(2047 - 2 * (32 * q0t + (lane & 31))), (u32)(2047 - 2 * (32 * (q0t + 2) + (lane & 31)))};
-      mx_epilogue_single(sh, lane, kq2, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
+      mx_epilogue_single(sh, lane, kq, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
     }
   }
   __syncthreads();
@@ -1847,7 +1851,6 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     mx_byte_fold(sh, (n_my - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, tid);
   }
 }
-
 
 template <int MODE>
 __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, int cluster_lo, const uint8_t *__restrict__ if_blocks,

@@ -52,7 +52,7 @@ for role in range(2):
         hs += 1
     rows = np.array(rows)
     steady = rows[(rows[:, 0] >= 16) & (rows[:, 0] < rows[-1, 0] - 16)]
-    for h in range(8):
-        sel = steady[steady[:, 0] % 8 == h]
+    for h in range(4):
+        sel = steady[steady[:, 0] % 4 == h]
         print("  h =", h, "barrier wait %6.0f  piece %6.0f  own half %6.0f  (n = %d)" % (sel[:, 1].mean(), sel[:, 2].mean(), sel[:, 3].mean(), len(sel)))
-    print("  per cluster:", steady[:, 1:].sum() / (len(steady) / 8.0))
+    print("  per cluster:", steady[:, 1:].sum() / (len(steady) / 4.0))
