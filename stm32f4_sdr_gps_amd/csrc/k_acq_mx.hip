@@ -86,6 +86,8 @@ struct MxShared {
   u32 ones[2];                           // pop(D) per stream
   u32 t_lut[768];                        // [0, 512): 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7;
                                          // [512, 768): 8 bits -> FP4 codes of 2 bit - 1 (mx_fill_tables)
+  u32 bbase[3][2][2][258];               // pipelined byte-phase form: copy 0 of the vectors as the wipe-off piece leaves them --
+                                         // [offset 0 | offset 8 of even / odd clusters][stream][low / high][dword]
   alignas(16) u32 part[8][32][2][32];              // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
                                          // PRN: every lane folds its own results in with LDS atomics (no return value, no
                                          // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
@@ -1599,61 +1601,71 @@ __device__ __forceinline__ void mx_block_commit(MxShared &sh, const MxBlockRegs 
   reinterpret_cast<u32 *>(sh.x)[tid] = (lo & 0xFFFFu) | (hi << 16);
 }
 
-// wipe-off of the block in sh.x -> d[2][514] (word 511 = the wrap-around copy), pop(D) -> ones (zeroed beforehand), and the block
-// sums S_0 / S_8 as bytes -> sums[stream][offset 0 / 8][1024]: one word per thread, the neighbour word wiped a second time
-// instead of a barrier between the stream and its sums
-__device__ __forceinline__ void mx_byte_wipe_sums(const MxShared &sh, u32 *d, u32 *ones, uint8_t *sums, u32 step_word, int tid,
-                                                  int lane)
+// FP4 codes of the two parts of a block sum S = 0 .. 16: -2 (S & 3) -> 0, C, E, F; -(S >> 2) -> 0, A, C, D, E
+__device__ __forceinline__ u32 sum_code_low(u32 s) { return (0xFEC0u >> ((s << 2) & 0xCu)) & 0xFu; }
+__device__ __forceinline__ u32 sum_code_high(u32 s) { return (0xEDCA0u >> (s & 0x1Cu)) & 0xFu; }
+
+// Wipe-off of the block in sh.x -> d[2][514] (word 511 = the wrap-around copy), pop(D) -> ones (zeroed beforehand), and copy 0
+// of the four vectors of each stream -- entry k = the FP4 code of a part of the block sum S_t0[k mod 1023], k < 2056 -- as bytes
+// of two entries: thread w has word w and wipes word w + 1 a second time (no barrier between the stream and its sums), i.e.
+// sums 2 w, 2 w + 1, 2 w + 2 of either sample offset: byte w of the first period, byte 512 + w of the second (which starts at
+// the odd entry 1023), and bytes 0..4 again as 1023..1027 (entries from 2046).  Entry 1023 = entry 0.
+__device__ __forceinline__ void mx_byte_wipe_codes(const MxShared &sh, u32 *d, u32 *ones, u32 *base0, u32 *base8, u32 step_word,
+                                                   int tid, int lane)
 {
   const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
   const int w = tid;
   const u32 x_first = x32[0], x_cur = x32[w], x_next = x32[w < 511 ? w + 1 : 0];
   const u32 quad_cur = (step_word * (u32)w) >> 30, quad_next = (step_word * (u32)(w + 1)) >> 30;
-  u32 cnt[2];
+  u32 cnt = 0;   // both streams' counts in one register (each below 2^16 per wave)
 #pragma unroll
   for (int s = 0; s < 2; s++) {
-    const u32 wrap = ((s ? carrier_q(0u) : carrier_i(0u)) ^ x_first) << 16;   // samples 16352..16367 are zero, then sample 0 again
+    const u32 first = (s ? carrier_q(0u) : carrier_i(0u)) ^ x_first;
+    const u32 wrap = first << 16;   // samples 16352..16367 are zero, then sample 0 again
     const u32 cur = w < kWords32 ? (s ? carrier_q(quad_cur) : carrier_i(quad_cur)) ^ x_cur : wrap;
     const u32 nxt = w + 1 < kWords32 ? (s ? carrier_q(quad_next) : carrier_i(quad_next)) ^ x_next : (w + 1 == kWords32 ? wrap : 0u);
     d[s * 514 + w] = cur;
-    cnt[s] = w < kWords32 ? (u32)__popc(cur) : 0u;
+    cnt += (w < kWords32 ? (u32)__popc(cur) : 0u) << (16 * s);
     const u32 x8 = __builtin_amdgcn_alignbit(nxt, cur, 8u);
-    reinterpret_cast<uint16_t *>(sums + (2 * s) * 1024)[w] = (uint16_t)(pop16(cur) | ((u32)__popc(cur >> 16) << 8));
-    reinterpret_cast<uint16_t *>(sums + (2 * s + 1) * 1024)[w] = (uint16_t)(pop16(x8) | ((u32)__popc(x8 >> 16) << 8));
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+      const u32 s0 = pop16(o ? x8 : cur), s2 = pop16(o ? nxt >> 8 : nxt);
+      u32 s1 = (u32)__popc((o ? x8 : cur) >> 16);
+      if (o && w == 511)
+        s1 = pop16(first >> 8);   // entry 1023 = entry 0 (offset 0: the wrap word's upper half already is D[0, 16))
+      uint8_t *base = reinterpret_cast<uint8_t *>(o ? base8 : base0) + s * (2 * 258 * 4);   // [stream][low / high][258 dwords]
+#pragma unroll
+      for (int which = 0; which < 2; which++) {
+        const u32 c0 = which ? sum_code_high(s0) : sum_code_low(s0), c1 = which ? sum_code_high(s1) : sum_code_low(s1);
+        const u32 c2 = which ? sum_code_high(s2) : sum_code_low(s2);
+        uint8_t *v = base + which * (258 * 4);
+        v[w] = (uint8_t)(c0 | (c1 << 4));
+        if (w < 511)
+          v[512 + w] = (uint8_t)(c1 | (c2 << 4));
+        if (w < 5)
+          v[1023 + w] = (uint8_t)(c0 | (c1 << 4));
+      }
+    }
   }
-  cnt[0] = wave_sum_to_lane63(cnt[0]);
-  cnt[1] = wave_sum_to_lane63(cnt[1]);
+  cnt = wave_sum_to_lane63(cnt);
   if (lane == 63) {
-    atomicAdd(&ones[0], cnt[0]);
-    atomicAdd(&ones[1], cnt[1]);
+    atomicAdd(&ones[0], cnt & 0xFFFFu);
+    atomicAdd(&ones[1], cnt >> 16);
   }
 }
 
-// the low and the high vector of sample offset 8 o from the block sums' bytes (mx_build_byte_vectors, one offset)
-__device__ __forceinline__ void mx_byte_vector_pair(const uint8_t *sums, int o, u32 *dst_low, u32 *dst_high, int tid)
+// the low and the high vector of one sample offset: the eight shifted copies of each from its copy 0
+__device__ __forceinline__ void mx_byte_vector_pair(const u32 *base, u32 *dst_low, u32 *dst_high, int tid)
 {
   const int iq = tid >> 8, j = tid & 255;
-  const uint8_t *sv = sums + (2 * iq + o) * 1024;
-  u32 lo[2] = {0, 0}, hi[2] = {0, 0};   // [which]: dwords j and j + 1 of copy 0
-#pragma unroll
-  for (int e = 0; e < 16; e++) {
-    const u32 sum = sv[wrap1023(8 * j + e)];
-    const u32 c0 = (0xFEC0u >> (4u * (sum & 3u))) & 0xFu;
-    const u32 c1 = (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;
-    if (e < 8) {
-      lo[0] |= c0 << (4 * e);
-      lo[1] |= c1 << (4 * e);
-    } else {
-      hi[0] |= c0 << (4 * (e - 8));
-      hi[1] |= c1 << (4 * (e - 8));
-    }
-  }
 #pragma unroll
   for (int which = 0; which < 2; which++) {
+    const u32 *v = base + (iq * 2 + which) * 258 + j;
+    const u32 lo = v[0], hi = v[1];
     u32 *dst = (which ? dst_high : dst_low) + (iq * 8) * kCopyDwords + j;
 #pragma unroll
     for (int c = 0; c < 8; c++)
-      dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi[which], lo[which], 4u * (u32)c) : lo[which];
+      dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi, lo, 4u * (u32)c) : lo;
   }
 }
 
@@ -1700,12 +1712,10 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   const int set = first % n_sets;                        // (the launcher's grid is a multiple of n_sets: one PRN set per workgroup)
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
 
-  // LDS this form has to itself: the polyphase planes (second copy of d, three of ones, the sums' bytes of even clusters), the
-  // extra K step's vectors (the sums' bytes of odd clusters), result slots 1..5 (the offset-8 vectors) and 6 (odd clusters' results)
-  uint8_t *overlay = reinterpret_cast<uint8_t *>(&sh.plane[0][0][0]);
-  uint8_t *sums_even = overlay, *sums_odd = reinterpret_cast<uint8_t *>(&sh.corr[0][0][0][0]);
-  u32 *d_alt = reinterpret_cast<u32 *>(overlay + 4096), *ones3 = d_alt + 2 * 514;   // ones3[3][2]
-  static_assert(sizeof(sh.plane) >= 4096 + (2 * 514 + 6) * sizeof(u32) && sizeof(sh.corr) >= 4096, "overlays fit");
+  // LDS this form has to itself: the polyphase planes (second copy of d, three of ones), result slots 1..5 (the offset-8
+  // vectors) and 6 (odd clusters' results)
+  u32 *d_alt = &sh.plane[0][0][0], *ones3 = d_alt + 2 * 514;   // ones3[3][2]
+  static_assert(sizeof(sh.plane) >= (2 * 514 + 6) * sizeof(u32), "overlays fit");
   u32 *e8x = &sh.part[1][0][0][0];
   constexpr int kVec = 2 * 8 * kCopyDwords, kSlotsEven = 0, kSlotsOdd = 6;
   static_assert(2 * kVec * sizeof(u32) <= 5 * sizeof(sh.part[0]), "two vectors below result slots 6");
@@ -1736,7 +1746,8 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   };
   auto d_of = [&](int i) { return i & 1 ? d_alt : &sh.d[0][0]; };
   auto ones_of = [&](int i) { return ones3 + 2 * (i % 3); };
-  auto sums_of = [&](int i) { return i & 1 ? sums_odd : sums_even; };
+  u32 *base0 = &sh.bbase[0][0][0][0];
+  auto base8_of = [&](int i) { return &sh.bbase[1 + (i & 1)][0][0][0]; };
 
   // ---- fill: tables of the PRN set, cluster 0 up to its offset-0 vectors, cluster 1's block in LDS ------------------------------
   {
@@ -1760,9 +1771,9 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     }
     mx_block_commit(sh, b0, prm.if_format, tid);
     __syncthreads();
-    mx_byte_wipe_sums(sh, d_of(0), ones_of(0), sums_of(0), step_of(0), tid, lane);
+    mx_byte_wipe_codes(sh, d_of(0), ones_of(0), base0, base8_of(0), step_of(0), tid, lane);
     __syncthreads();
-    mx_byte_vector_pair(sums_of(0), 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], tid);
+    mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], tid);
     mx_block_commit(sh, b1, prm.if_format, tid);
   }
   const v4i a_corr = v4i{0, 0, 0, 0};   // (the fine grid's extra K step: not in this form)
@@ -1800,14 +1811,14 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
       const int c = hs >> 2;
       if ((hs & 2) == 0) {
         if (c < n_my)
-          mx_byte_vector_pair(sums_of(c), 1, e8x, e8x + kVec, t);
+          mx_byte_vector_pair(base8_of(c), e8x, e8x + kVec, t);
         if (c + 1 < n_my)
-          mx_byte_wipe_sums(sh, d_of(c + 1), ones_of(c + 1), sums_of(c + 1), step_of(c + 1), t, t & 63);
+          mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step_of(c + 1), t, t & 63);
         if (c + 2 < n_my)
           next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
       } else {
         if (c + 1 < n_my)
-          mx_byte_vector_pair(sums_of(c + 1), 0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+          mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
         if (c + 2 < n_my) {
           mx_block_commit(sh, next_block, prm.if_format, t);
           if (t < 2)
