@@ -1800,59 +1800,67 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
 #else
 #define MX_TL() do { } while (0)
 #endif
+  // the pieces behind the barrier of even half stage hs_even, thread t's share
+  auto piece = [&](int hs_even, int t) {
+    asm volatile("" : "+v"(t));   // (per-thread addresses of these pieces are recomputed, not kept across the stages)
+    const int c = hs_even >> 2;
+    if ((hs_even & 2) == 0) {
+      if (c < n_my)
+        mx_byte_vector_pair(base8_of(c), e8x, e8x + kVec, t);
+      if (c + 1 < n_my)
+        mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step_of(c + 1), t, t & 63);
+      if (c + 2 < n_my)
+        next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
+    } else {
+      if (c + 1 < n_my)
+        mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+      if (c + 2 < n_my) {
+        mx_block_commit(sh, next_block, prm.if_format, t);
+        if (t < 2)
+          ones_of(c + 2)[t] = 0;
+      }
+      if (c >= 1) {
+        int search, dopp;
+        u32 mask;
+        decode(c - 1, search, dopp, mask);
+        mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
+      }
+    }
+  };
 #pragma unroll 1
   for (int hs = 0; hs <= n_half; hs++) {
     MX_TL();
-    if ((hs & 1) == 0) {
+    if ((hs & 1) == 0)
       __syncthreads();
-      MX_TL();
-      int t = tid;
-      asm volatile("" : "+v"(t));   // (per-thread addresses of these pieces are recomputed, not kept across the stages)
-      const int c = hs >> 2;
-      if ((hs & 2) == 0) {
-        if (c < n_my)
-          mx_byte_vector_pair(base8_of(c), e8x, e8x + kVec, t);
-        if (c + 1 < n_my)
-          mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step_of(c + 1), t, t & 63);
-        if (c + 2 < n_my)
-          next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
-      } else {
-        if (c + 1 < n_my)
-          mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
-        if (c + 2 < n_my) {
-          mx_block_commit(sh, next_block, prm.if_format, t);
-          if (t < 2)
-            ones_of(c + 2)[t] = 0;
-        }
-        if (c >= 1) {
-          int search, dopp;
-          u32 mask;
-          decode(c - 1, search, dopp, mask);
-          mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
-        }
-      }
-    }
+    MX_TL();
+    // A stage's pieces only have to be done before the NEXT barrier, and what they write nobody reads before it: role 1 does
+    // its threads' share at once (pieces, epilogue, passes), role 0 at the end of its stage (passes, epilogue, pieces) -- the
+    // two waves of a SIMD are then on the matrix pipe one after the other from the barrier on.
+    if (role == 1 && (hs & 1) == 0)
+      piece(hs, tid);
     MX_TL();
     const int x = hs - role;   // this role's half stage
-    if (x < 0 || x >= n_half)
-      continue;
-    const int cc = x >> 2, o = (x >> 1) & 1;   // sample offset 8 o
-    if ((x & 1) == 0) {
-      const u32 *dd = d_of(cc), *ones = ones_of(cc);
-      const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + kVec : &sh.e8[1][0][0][0];
-      if (o)
-        mx_init_acc_odd(sh, ones, dd, dd + 514, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-      else
-        mx_init_acc(ones, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-      mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
-      if (o)
-        mx_odd_tail_step(sh, va, false, lane, q0_tile, acc, kScaleOne);
-      mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
-      if (o)
-        mx_odd_tail_step(sh, vb, true, lane, q0_tile, acc, kScaleEight);
-    } else {
-      mx_epilogue_single(sh, lane, kq, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
+    if (x >= 0 && x < n_half) {
+      const int cc = x >> 2, o = (x >> 1) & 1;   // sample offset 8 o
+      if ((x & 1) == 0) {
+        const u32 *dd = d_of(cc), *ones = ones_of(cc);
+        const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + kVec : &sh.e8[1][0][0][0];
+        if (o)
+          mx_init_acc_odd(sh, ones, dd, dd + 514, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        else
+          mx_init_acc(ones, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
+        if (o)
+          mx_odd_tail_step(sh, va, false, lane, q0_tile, acc, kScaleOne);
+        mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
+        if (o)
+          mx_odd_tail_step(sh, vb, true, lane, q0_tile, acc, kScaleEight);
+      } else {
+        mx_epilogue_single(sh, lane, kq, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
+      }
     }
+    if (role == 0 && (hs & 1) != 0)
+      piece(hs - 1, tid);
   }
   __syncthreads();
   {

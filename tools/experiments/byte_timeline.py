@@ -38,21 +38,13 @@ for role in range(2):
     print("role", role, "stamps", n, "total cycles", t[-1] - t[0])
     # stamps per half stage: even hs: top, after barrier, after piece ; odd hs: top, before role work
     i, hs, rows = 0, 0, []
-    while i < n - 1:
-        if hs % 2 == 0:
-            if i + 3 >= n:
-                break
-            rows.append((hs, t[i + 1] - t[i], t[i + 2] - t[i + 1], t[i + 3] - t[i + 2]))
-            i += 3
-        else:
-            if i + 2 >= n:
-                break
-            rows.append((hs, 0, 0, t[i + 2] - t[i + 1]))
-            i += 2
+    while i + 3 < n:   # three stamps per half stage: top, behind the barrier (even ones), behind role 1's pieces
+        rows.append((hs, t[i + 1] - t[i], t[i + 2] - t[i + 1], t[i + 3] - t[i + 2]))
+        i += 3
         hs += 1
     rows = np.array(rows)
     steady = rows[(rows[:, 0] >= 16) & (rows[:, 0] < rows[-1, 0] - 16)]
     for h in range(4):
         sel = steady[steady[:, 0] % 4 == h]
-        print("  h =", h, "barrier wait %6.0f  piece %6.0f  own half %6.0f  (n = %d)" % (sel[:, 1].mean(), sel[:, 2].mean(), sel[:, 3].mean(), len(sel)))
+        print("  h =", h, "barrier wait %6.0f  pieces (role 1) %6.0f  own half (+ role 0 pieces) %6.0f  (n = %d)" % (sel[:, 1].mean(), sel[:, 2].mean(), sel[:, 3].mean(), len(sel)))
     print("  per cluster:", steady[:, 1:].sum() / (len(steady) / 4.0))
