@@ -683,31 +683,27 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, const u32 *d_
 //   extra(q, p) = - pop(W) - chip_p[1022 - q] beta_0 + T(q) [ (2 c1022_p - 1) S_8[q - 1] - 16 c1022_p ]
 // because P = data bytes (2 q - 1, 2 q) IS the block D[16 (q - 1) + 8, +16) whose popcount the offset-8 vectors already carry
 // as entry q - 1: the tail word acts as one more chip, "chip -1" = chip 1022 in +-1 form.  So
-//   * start values:  base - pop(W) - chip_p[1022 - q] beta_0   (one multiply-add per accumulator: mx_init_acc_odd);
+//   * start values:  base - pop(W)   (mx_init_acc_odd);
+//   * - chip_p[1022 - q] beta_0 is entry 1022 of the offset-8 vectors' first period lowered by beta_0 = 16 - 2 pop(W) -- and
+//     pop(W) is that entry's own block sum: the entry is the constant -16 (mx_byte_wipe_codes): nothing to compute at all;
 //   * per pass one MFMA per tile and stream (mx_odd_tail_step): A column 0 of lane half 0 = -(2 c1022 - 1) / 2 against nibble
 //     q - 1 of the pass's own vector (-2 (S & 3), then -(S >> 2) at 2^3), and in the high pass column 0 of lane half 1 = c1022
 //     against -2 at 2^3; both B entries zero for q = 0.
 template <int NT>
-__device__ __forceinline__ void mx_init_acc_odd(const MxShared &sh, const u32 *ones, const u32 *d_i, const u32 *d_q, int lane,
-                                                int q0_tile, v16f (&acc)[2][NT], int win_start, int win_stop)
+__device__ __forceinline__ void mx_init_acc_odd(const u32 *ones, const u32 *d_i, const u32 *d_q, int lane, int q0_tile,
+                                                v16f (&acc)[2][NT], int win_start, int win_stop)
 {
-  const int n = lane & 31, h = lane >> 5;
-  const int popw_i = (int)__popc(d_i[0] & 0xFFu), popw_q = (int)__popc(d_q[0] & 0xFFu);
-  const float base_i = (float)((int)ones[0] + 8192 - kHalf - popw_i) * kAccScale;
-  const float base_q = (float)((int)ones[1] + 8192 - kHalf - popw_q) * kAccScale;
-  const float nb_i = (float)(2 * popw_i - 16) * kAccScale, nb_q = (float)(2 * popw_q - 16) * kAccScale;   // -beta_0
+  const int n = lane & 31;
+  const float base_i = (float)((int)ones[0] + 8192 - kHalf - (int)__popc(d_i[0] & 0xFFu)) * kAccScale;
+  const float base_q = (float)((int)ones[1] + 8192 - kHalf - (int)__popc(d_q[0] & 0xFFu)) * kAccScale;
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
-    const bool exists = q < kChips;
-    const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
-    const float start_i = in1 ? base_i : base_i + kOutside, start_q = in1 ? base_q : base_q + kOutside;
-    const u32 w1 = sh.chip_t[(exists ? kChips - 1 - q : 0) + 1] >> (4 * h);   // chip 1022 - q of the lane's PRNs
+    const bool in1 = q < kChips && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float c1 = (float)((w1 >> ((r & 3) + 8 * (r >> 2))) & 1u);
-      acc[0][j][r] = __builtin_fmaf(c1, nb_i, start_i);   // (exact either way: multiples of 2^-13 below 2^8)
-      acc[1][j][r] = __builtin_fmaf(c1, nb_q, start_q);
+      acc[0][j][r] = in1 ? base_i : base_i + kOutside;
+      acc[1][j][r] = in1 ? base_q : base_q + kOutside;
     }
   }
 }
@@ -1633,13 +1629,18 @@ __device__ __forceinline__ void mx_byte_wipe_codes(const MxShared &sh, u32 *d, u
       u32 s1 = (u32)__popc((o ? x8 : cur) >> 16);
       if (o && w == 511)
         s1 = pop16(first >> 8);   // entry 1023 = entry 0 (offset 0: the wrap word's upper half already is D[0, 16))
+      // Offset 8, entry 1022 of the FIRST period (the only one chip 1022 - q ever meets): the odd byte offsets skip the replica
+      // word at the wrap (quirk Q3) -- - chip[1022 - q] beta_0 with beta_0 = 16 - 2 pop(W), and pop(W) IS this entry's block sum
+      // S_8[1022] = pop(D[0, 8)): entry -2 S - beta_0 = -16 whatever the data, i.e. "S = 8".
+      const bool wrap_entry = o && w == 511;
       uint8_t *base = reinterpret_cast<uint8_t *>(o ? base8 : base0) + s * (2 * 258 * 4);   // [stream][low / high][258 dwords]
 #pragma unroll
       for (int which = 0; which < 2; which++) {
         const u32 c0 = which ? sum_code_high(s0) : sum_code_low(s0), c1 = which ? sum_code_high(s1) : sum_code_low(s1);
         const u32 c2 = which ? sum_code_high(s2) : sum_code_low(s2);
+        const u32 c0f = wrap_entry ? sum_code_high(8u) & (which ? 0xFu : 0u) : c0;
         uint8_t *v = base + which * (258 * 4);
-        v[w] = (uint8_t)(c0 | (c1 << 4));
+        v[w] = (uint8_t)(c0f | (c1 << 4));
         if (w < 511)
           v[512 + w] = (uint8_t)(c1 | (c2 << 4));
         if (w < 5)
@@ -1846,7 +1847,7 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
         const u32 *dd = d_of(cc), *ones = ones_of(cc);
         const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + kVec : &sh.e8[1][0][0][0];
         if (o)
-          mx_init_acc_odd(sh, ones, dd, dd + 514, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+          mx_init_acc_odd(ones, dd, dd + 514, lane, q0_tile, acc, prm.win_start, prm.win_stop);
         else
           mx_init_acc(ones, lane, q0_tile, acc, prm.win_start, prm.win_stop);
         mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
