@@ -686,7 +686,7 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, const u32 *d_
 //   * start values:  base - pop(W)   (mx_init_acc_odd);
 //   * - chip_p[1022 - q] beta_0 is entry 1022 of the offset-8 vectors' first period lowered by beta_0 = 16 - 2 pop(W) -- and
 //     pop(W) is that entry's own block sum: the entry is the constant -16 (mx_byte_wipe_codes): nothing to compute at all;
-//   * per pass one MFMA per tile and stream (mx_odd_tail_step): A column 0 of lane half 0 = -(2 c1022 - 1) / 2 against nibble
+//   * per pass one MFMA per tile and stream (mx_odd_tail_steps): A column 0 of lane half 0 = -(2 c1022 - 1) / 2 against nibble
 //     q - 1 of the pass's own vector (-2 (S & 3), then -(S >> 2) at 2^3), and in the high pass column 0 of lane half 1 = c1022
 //     against -2 at 2^3; both B entries zero for q = 0.
 template <int NT>
@@ -707,29 +707,42 @@ __device__ __forceinline__ void mx_init_acc_odd(const u32 *ones, const u32 *d_i,
     }
   }
 }
+// (both passes' extra steps in one go, BEFORE the passes: their operands come from LDS under the start values' moves)
 template <int NT>
-__device__ __forceinline__ void mx_odd_tail_step(const MxShared &sh, const u32 *vec, bool high, int lane, int q0_tile,
-                                                 v16f (&acc)[2][NT], u32 scale_b)
+__device__ __forceinline__ void mx_odd_tail_operands(const u32 *v_low, const u32 *v_high, int lane, int q0_tile, u32 (&b_low)[2][NT],
+                                                     u32 (&b_high)[2][NT])
 {
   const int n = lane & 31, h = lane >> 5;
-  const u32 c22 = (sh.chip_t[1022 + 1] >> n) & 1u;   // A row n = PRN n of the cluster
-  const u32 a0 = h == 0 ? (c22 ? 0x9u : 0x1u) : (high ? c22 << 1 : 0u);   // FP4: -0.5 / +0.5; 1.0
-  const v4i a = v4i{(int)a0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     const int q = 32 * (q0_tile + 2 * j) + n;
     const int e = q > 0 ? q - 1 : 0;
-    // entry q - 1 of the vector (copy 0, dword e / 8) moved to nibble 0; what is left above it meets zero columns of A
-    u32 bi = vec[e >> 3] >> (4 * (e & 7)), bq = vec[8 * kCopyDwords + (e >> 3)] >> (4 * (e & 7));
-    if (h)
-      bi = bq = high ? 0xCu : 0u;   // FP4 -2
-    if (q == 0)
-      bi = bq = 0;
-    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a), widen(v4i{(int)bi, 0, 0, 0}), acc[0][j], 4, 4, 0, kScaleA, 0,
-                                                                 scale_b);
-    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a), widen(v4i{(int)bq, 0, 0, 0}), acc[1][j], 4, 4, 0, kScaleA, 0,
-                                                                 scale_b);
+    // entry q - 1 of a vector (copy 0, dword e / 8) moved to nibble 0; what is left above it meets zero columns of A
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const u32 lo = v_low[s * 8 * kCopyDwords + (e >> 3)] >> (4 * (e & 7)), hi = v_high[s * 8 * kCopyDwords + (e >> 3)] >> (4 * (e & 7));
+      b_low[s][j] = h || q == 0 ? 0u : lo;
+      b_high[s][j] = q == 0 ? 0u : h ? 0xCu /* FP4 -2 */ : hi;
+    }
   }
+}
+template <int NT>
+__device__ __forceinline__ void mx_odd_tail_steps(const MxShared &sh, int lane, const u32 (&b_low)[2][NT], const u32 (&b_high)[2][NT],
+                                                  v16f (&acc)[2][NT])
+{
+  const int n = lane & 31, h = lane >> 5;
+  const u32 c22 = (sh.chip_t[1022 + 1] >> n) & 1u;   // A row n = PRN n of the cluster
+  const v4i a_low = v4i{(int)(h ? 0u : c22 ? 0x9u : 0x1u), 0, 0, 0};             // FP4 -0.5 / +0.5
+  const v4i a_high = v4i{(int)(h ? c22 << 1 : c22 ? 0x9u : 0x1u), 0, 0, 0};      // lane half 1: 1.0 where chip 1022 is set
+#pragma unroll
+  for (int j = 0; j < NT; j++)
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      acc[s][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_low), widen(v4i{(int)b_low[s][j], 0, 0, 0}), acc[s][j], 4, 4, 0,
+                                                                  kScaleA, 0, kScaleOne);
+      acc[s][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a_high), widen(v4i{(int)b_high[s][j], 0, 0, 0}), acc[s][j], 4, 4,
+                                                                  0, kScaleA, 0, kScaleEight);
+    }
 }
 
 // The general form of the above for a workgroup that STARTS at sample offset t0s = 8 half + b (mx_vector_build_direct gave
@@ -1846,16 +1859,16 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
       if ((x & 1) == 0) {
         const u32 *dd = d_of(cc), *ones = ones_of(cc);
         const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + kVec : &sh.e8[1][0][0][0];
-        if (o)
+        if (o) {
+          u32 b_low[2][kMxTiles], b_high[2][kMxTiles];
+          mx_odd_tail_operands(va, vb, lane, q0_tile, b_low, b_high);
           mx_init_acc_odd(ones, dd, dd + 514, lane, q0_tile, acc, prm.win_start, prm.win_stop);
-        else
+          mx_odd_tail_steps(sh, lane, b_low, b_high, acc);
+        } else {
           mx_init_acc(ones, lane, q0_tile, acc, prm.win_start, prm.win_stop);
+        }
         mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
-        if (o)
-          mx_odd_tail_step(sh, va, false, lane, q0_tile, acc, kScaleOne);
         mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
-        if (o)
-          mx_odd_tail_step(sh, vb, true, lane, q0_tile, acc, kScaleEight);
       } else {
         mx_epilogue_single(sh, lane, kq, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
       }
