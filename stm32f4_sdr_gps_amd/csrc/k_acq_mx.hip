@@ -1614,18 +1614,35 @@ __device__ __forceinline__ void mx_block_commit(MxShared &sh, const MxBlockRegs 
 __device__ __forceinline__ u32 sum_code_low(u32 s) { return (0xFEC0u >> ((s << 2) & 0xCu)) & 0xFu; }
 __device__ __forceinline__ u32 sum_code_high(u32 s) { return (0xEDCA0u >> (s & 0x1Cu)) & 0xFu; }
 
+// Table for the wipe-off piece (in the recurrence's lookup tables' LDS, which this form does not use): two block sums
+// (a | b << 5, each 0 .. 16) -> the byte of their low codes and, above it, the byte of their high codes
+__device__ __forceinline__ void mx_byte_fill_code_table(MxShared &sh, int tid)
+{
+  uint16_t *lut = reinterpret_cast<uint16_t *>(sh.t_lut);
+  static_assert(sizeof(sh.t_lut) >= 1024 * sizeof(uint16_t), "code table fits");
+  for (int i = tid; i < 1024; i += kMxThreads) {
+    const u32 sa = (u32)i & 31u, sb = (u32)i >> 5;
+    lut[i] = (uint16_t)(sum_code_low(sa) | (sum_code_low(sb) << 4) | (sum_code_high(sa) << 8) | (sum_code_high(sb) << 12));
+  }
+}
+
 // Wipe-off of the block in sh.x -> d[2][514] (word 511 = the wrap-around copy), pop(D) -> ones (zeroed beforehand), and copy 0
 // of the four vectors of each stream -- entry k = the FP4 code of a part of the block sum S_t0[k mod 1023], k < 2056 -- as bytes
 // of two entries: thread w has word w and wipes word w + 1 a second time (no barrier between the stream and its sums), i.e.
 // sums 2 w, 2 w + 1, 2 w + 2 of either sample offset: byte w of the first period, byte 512 + w of the second (which starts at
-// the odd entry 1023), and bytes 0..4 again as 1023..1027 (entries from 2046).  Entry 1023 = entry 0.
+// the odd entry 1023), and bytes 0..4 again as 1023..1027 (entries from 2046).  Entry 1023 = entry 0.  The four bytes of a
+// thread (low / high vector, first / second period) are transposed over its quad, so that each lane writes ONE dword.
 __device__ __forceinline__ void mx_byte_wipe_codes(const MxShared &sh, u32 *d, u32 *ones, u32 *base0, u32 *base8, u32 step_word,
                                                    int tid, int lane)
 {
   const u32 *x32 = reinterpret_cast<const u32 *>(sh.x);
-  const int w = tid;
+  const uint16_t *lut = reinterpret_cast<const uint16_t *>(sh.t_lut);
+  const int w = tid, k = tid & 3;
   const u32 x_first = x32[0], x_cur = x32[w], x_next = x32[w < 511 ? w + 1 : 0];
   const u32 quad_cur = (step_word * (u32)w) >> 30, quad_next = (step_word * (u32)(w + 1)) >> 30;
+  const u32 sel = (u32)k * 0x0101u + 0x0400u;   // v_perm_b32: byte k of the second source, byte k of the first
+  // lane k of a quad writes item k: low / high vector (k & 1), first / second period (k >> 1), dword w / 4 of it
+  const int item_dword = (k & 1) * 258 + (k >> 1) * 128 + (w >> 2);
   u32 cnt = 0;   // both streams' counts in one register (each below 2^16 per wave)
 #pragma unroll
   for (int s = 0; s < 2; s++) {
@@ -1638,26 +1655,31 @@ __device__ __forceinline__ void mx_byte_wipe_codes(const MxShared &sh, u32 *d, u
     const u32 x8 = __builtin_amdgcn_alignbit(nxt, cur, 8u);
 #pragma unroll
     for (int o = 0; o < 2; o++) {
-      const u32 s0 = pop16(o ? x8 : cur), s2 = pop16(o ? nxt >> 8 : nxt);
-      u32 s1 = (u32)__popc((o ? x8 : cur) >> 16);
-      if (o && w == 511)
+      u32 s0 = pop16(o ? x8 : cur), s1 = (u32)__popc((o ? x8 : cur) >> 16);
+      const u32 s2 = pop16(o ? nxt >> 8 : nxt);
+      if (o && w == 511) {
         s1 = pop16(first >> 8);   // entry 1023 = entry 0 (offset 0: the wrap word's upper half already is D[0, 16))
-      // Offset 8, entry 1022 of the FIRST period (the only one chip 1022 - q ever meets): the odd byte offsets skip the replica
-      // word at the wrap (quirk Q3) -- - chip[1022 - q] beta_0 with beta_0 = 16 - 2 pop(W), and pop(W) IS this entry's block sum
-      // S_8[1022] = pop(D[0, 8)): entry -2 S - beta_0 = -16 whatever the data, i.e. "S = 8".
-      const bool wrap_entry = o && w == 511;
-      uint8_t *base = reinterpret_cast<uint8_t *>(o ? base8 : base0) + s * (2 * 258 * 4);   // [stream][low / high][258 dwords]
-#pragma unroll
-      for (int which = 0; which < 2; which++) {
-        const u32 c0 = which ? sum_code_high(s0) : sum_code_low(s0), c1 = which ? sum_code_high(s1) : sum_code_low(s1);
-        const u32 c2 = which ? sum_code_high(s2) : sum_code_low(s2);
-        const u32 c0f = wrap_entry ? sum_code_high(8u) & (which ? 0xFu : 0u) : c0;
-        uint8_t *v = base + which * (258 * 4);
-        v[w] = (uint8_t)(c0f | (c1 << 4));
-        if (w < 511)
-          v[512 + w] = (uint8_t)(c1 | (c2 << 4));
-        if (w < 5)
-          v[1023 + w] = (uint8_t)(c0 | (c1 << 4));
+        // Offset 8, entry 1022 of the FIRST period (the only one chip 1022 - q ever meets): the odd byte offsets skip the
+        // replica word at the wrap (quirk Q3) -- - chip[1022 - q] beta_0 with beta_0 = 16 - 2 pop(W), and pop(W) IS this
+        // entry's block sum S_8[1022] = pop(D[0, 8)): entry -2 S - beta_0 = -16 whatever the data, i.e. "S = 8".
+        s0 = 8;
+      }
+      // bytes: [0] low vector, first period; [1] high, first; [2] low, second period; [3] high, second
+      const u32 pk = (u32)lut[s0 | (s1 << 5)] | ((u32)lut[s1 | (s2 << 5)] << 16);
+      u32 *base = (o ? base8 : base0) + s * (2 * 258);   // [stream][low / high][258 dwords]
+      const u32 p0 = (u32)__builtin_amdgcn_mov_dpp((int)pk, 0x00, 0xF, 0xF, true), p1 = (u32)__builtin_amdgcn_mov_dpp((int)pk, 0x55, 0xF, 0xF, true);
+      const u32 p2 = (u32)__builtin_amdgcn_mov_dpp((int)pk, 0xAA, 0xF, 0xF, true), p3 = (u32)__builtin_amdgcn_mov_dpp((int)pk, 0xFF, 0xF, 0xF, true);
+      const u32 out = (__builtin_amdgcn_perm(p1, p0, sel) & 0xFFFFu) | (__builtin_amdgcn_perm(p3, p2, sel) << 16);
+      if (w < 508 || k < 2)
+        base[item_dword] = out;
+      uint8_t *bytes = reinterpret_cast<uint8_t *>(base);
+      if (w >= 508 && w < 511) {   // the last dword of the second period also holds byte 1023, which is entry 2046's
+        bytes[512 + w] = (uint8_t)(pk >> 16);
+        bytes[258 * 4 + 512 + w] = (uint8_t)(pk >> 24);
+      }
+      if (w < 5) {
+        bytes[1023 + w] = (uint8_t)pk;
+        bytes[258 * 4 + 1023 + w] = (uint8_t)(pk >> 8);
       }
     }
   }
@@ -1734,10 +1756,38 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   constexpr int kVec = 2 * 8 * kCopyDwords, kSlotsEven = 0, kSlotsOdd = 6;
   static_assert(2 * kVec * sizeof(u32) <= 5 * sizeof(sh.part[0]), "two vectors below result slots 6");
 
-  auto decode = [&](int i, int &search, int &dopp, u32 &mask) {
-    const int sd = (first + i * stride) / n_sets;
-    dopp = sd % prm.n_dopp;
-    search = sd / prm.n_dopp;
+  // (search, Doppler bin) of this workgroup's clusters c - 1 .. c + 2 around the cluster c the pieces are at: moved on by
+  // additions, one division when the workgroup starts (a cluster's pieces need three decodes; divisions cost them a third)
+  const int sd_step = stride / n_sets, search_step = sd_step / prm.n_dopp, dopp_step = sd_step % prm.n_dopp;
+  int w_sd[4], w_search[4], w_dopp[4], w_at = 0;   // [k]: cluster w_at - 1 + k
+  w_sd[1] = first / n_sets;
+  w_search[1] = w_sd[1] / prm.n_dopp;
+  w_dopp[1] = w_sd[1] % prm.n_dopp;
+  w_sd[0] = w_sd[1], w_search[0] = w_search[1], w_dopp[0] = w_dopp[1];
+#pragma unroll
+  for (int k = 2; k < 4; k++) {
+    w_sd[k] = w_sd[k - 1] + sd_step;
+    w_dopp[k] = w_dopp[k - 1] + dopp_step;
+    w_search[k] = w_search[k - 1] + search_step + (w_dopp[k] >= prm.n_dopp ? 1 : 0);
+    w_dopp[k] -= w_dopp[k] >= prm.n_dopp ? prm.n_dopp : 0;
+  }
+  auto window_to = [&](int c) {   // (at most one step per call)
+    if (w_at < c) {
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        w_sd[k] = w_sd[k + 1], w_search[k] = w_search[k + 1], w_dopp[k] = w_dopp[k + 1];
+      w_sd[3] = w_sd[2] + sd_step;
+      w_dopp[3] = w_dopp[2] + dopp_step;
+      w_search[3] = w_search[2] + search_step + (w_dopp[3] >= prm.n_dopp ? 1 : 0);
+      w_dopp[3] -= w_dopp[3] >= prm.n_dopp ? prm.n_dopp : 0;
+      w_at++;
+    }
+  };
+  auto decode = [&](int i, int &search, int &dopp, u32 &mask) {   // i in w_at - 1 .. w_at + 2
+    const int k = i - w_at + 1;
+    const int sd = k == 0 ? w_sd[0] : k == 1 ? w_sd[1] : k == 2 ? w_sd[2] : w_sd[3];
+    search = k == 0 ? w_search[0] : k == 1 ? w_search[1] : k == 2 ? w_search[2] : w_search[3];
+    dopp = k == 0 ? w_dopp[0] : k == 1 ? w_dopp[1] : k == 2 ? w_dopp[2] : w_dopp[3];
     mask = 0;
 #pragma unroll
     for (int g = 0; g < 4; g++) {
@@ -1777,6 +1827,7 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     constexpr int kSlotVecs = (int)(sizeof(sh.part[0]) / sizeof(uint4));
     for (int i = tid; i < 2 * kSlotVecs; i += kMxThreads)
       reinterpret_cast<uint4 *>(&sh.part[i / kSlotVecs ? kSlotsOdd : kSlotsEven][0][0][0])[i % kSlotVecs] = make_uint4(0, 0, 0, 0);
+    mx_byte_fill_code_table(sh, tid);
     if (tid < 6)
       ones3[tid] = 0;
     if (tid < 4) {   // the zero pad behind the wrap-around word, both copies
@@ -1810,35 +1861,47 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   unsigned long long *tl = blockIdx.x == 0 && lane == 0 && (wave & 3) == 0
                                ? reinterpret_cast<unsigned long long *>(peaks + (size_t)prm.n_clusters * 32) + role * 2048 : nullptr;
   int tli = 0;
-#define MX_TL() do { if (tl && tli < 2048) tl[tli++] = __builtin_readcyclecounter(); } while (0)
+  int tli2 = 1024;
+#define MX_TL() do { if (tl && tli < 1024) tl[tli++] = __builtin_readcyclecounter(); } while (0)
+#define MX_TL2() do { if (tl && tli2 < 2048) tl[tli2++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define MX_TL() do { } while (0)
+#define MX_TL2() do { } while (0)
 #endif
   // the pieces behind the barrier of even half stage hs_even, thread t's share
   auto piece = [&](int hs_even, int t) {
     asm volatile("" : "+v"(t));   // (per-thread addresses of these pieces are recomputed, not kept across the stages)
     const int c = hs_even >> 2;
+    window_to(c);
     if ((hs_even & 2) == 0) {
+      MX_TL2();
       if (c < n_my)
         mx_byte_vector_pair(base8_of(c), e8x, e8x + kVec, t);
+      MX_TL2();
       if (c + 1 < n_my)
         mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step_of(c + 1), t, t & 63);
+      MX_TL2();
       if (c + 2 < n_my)
         next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
+      MX_TL2();
     } else {
+      MX_TL2();
       if (c + 1 < n_my)
         mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+      MX_TL2();
       if (c + 2 < n_my) {
         mx_block_commit(sh, next_block, prm.if_format, t);
         if (t < 2)
           ones_of(c + 2)[t] = 0;
       }
+      MX_TL2();
       if (c >= 1) {
         int search, dopp;
         u32 mask;
         decode(c - 1, search, dopp, mask);
         mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
       }
+      MX_TL2();
     }
   };
 #pragma unroll 1
