@@ -152,7 +152,6 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     const int v = std::atoi(sp);
     ctx->split_force = v == 8 ? 8 : v == 4 ? 4 : 2;
   }
-  ctx->byte_legacy = std::getenv("GPSX_ACQ_BYTE_LEGACY") != nullptr;
   if (const char *w = std::getenv("GPSX_TRACK_WAVE_FROM"))
     ctx->track_wave_from = std::atoi(w) > 0 ? std::atoi(w) : 1;
   if (const char *m = std::getenv("GPSX_ACQ_MS_MODE"))
@@ -536,7 +535,6 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   }
   AcqParams prm{};
   prm.split_segs = ctx->split_force;   // 0: launch_acq_mx picks by launch size
-  prm.byte_legacy = ctx->byte_legacy;
   prm.n_ms = g->n_ms;
   prm.search_stride_blocks = g->search_stride_blocks;
   prm.n_prn = g->n_prn;

@@ -58,7 +58,6 @@ struct gpsx_ctx {
   int track_wave_from = 1;           // $GPSX_TRACK_WAVE_FROM: channels from which k_track_epl_wave serves the step (default: always;
                                      // a large value selects the workgroup-per-channel kernel: tests, A/B)
   bool in_chunk_callback = false;    // set around the on_chunk calls of gpsx_track_epl_batch_chunked: entry points refuse re-entry
-  bool byte_legacy = false;          // $GPSX_ACQ_BYTE_LEGACY: byte-phase grids one cluster at a time (k_acq_mx<4>) instead of pipelined
   int split_force = 0;               // $GPSX_ACQ_SPLIT: workgroups per cluster of the split form (2, 4, 8; 0 = by launch size)
   bool no_split = false;             // $GPSX_ACQ_NO_SPLIT: small single-block fine grids stay one workgroup per cluster (tests, A/B)
   int ms_mode = 0;                   // $GPSX_ACQ_MS_MODE = walk | blocks: force one multi-block form (tests, A/B); 0 = by size

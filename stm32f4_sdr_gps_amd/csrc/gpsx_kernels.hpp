@@ -48,7 +48,6 @@ struct AcqParams {
   // set by launch_acq_mx for its own forms:
   int32_t split_segs;       //   k_acq_mx<5>: workgroups per cluster (2, 4 or 8)
   int32_t n_clusters;       //   k_acq_mx<4>: clusters of the launch (one persistent workgroup per CU walks them)
-  int32_t byte_legacy;      //   byte-phase grid: 1 = the one-cluster-at-a-time form k_acq_mx<4> (A/B)
   uint64_t n_planes;        //   k_acq_mx<5>: entries per result plane (packed keys [0, n), sums [n, 2 n) behind `energy`)
   int32_t experiment;       // ablations of k_acq_mx for timing (results are then wrong); always 0 unless the library was built
                             // with -DGPSX_MX_ABLATIONS, which alone makes gpsx_api.hip read $GPSX_MX_EXPERIMENT

@@ -42,8 +42,8 @@
 //
 // Forms (k_acq_mx<MODE>): 0 single block, one workgroup per cluster (the headline sweep); 3 / 1 a workgroup walks the blocks
 // of its search, running sums as 16- / 24-bit records through HBM scratch; 2 a workgroup per (cluster, block), magnitudes out
-// for k_acq_vals_search; 4 the byte-phase grid (sample offsets 0 and 8, each started directly from its own block sums,
-// persistent workgroups, stages of two q-tiles); 5 small launches: 2 / 4 / 8 workgroups per cluster, each started directly
+// for k_acq_vals_search; 4 the byte-phase grid (sample offsets 0 and 8, each started directly from its own block sums; one
+// persistent workgroup per CU runs its clusters as ONE software pipeline: mx_byte_pipe); 5 small launches: 2 / 4 / 8 workgroups per cluster, each started directly
 // at its own sample offset (mx_direct_terms: every quirk term as a start value), results merged through global planes.
 #include <cstdlib>
 
@@ -122,8 +122,6 @@ __device__ __forceinline__ u32 plane_bits9(const u32 *pl, int pos)
 }
 
 // ---- per block: capture -> LDS, wipe-off, polyphase planes -------------------------------------------------------------
-// PLANES = false (byte-phase grid): the polyphase planes are what the recurrence vectors are cut from; a form that starts
-// every offset from its block sums does not need them
 // (in two parts: the block's load goes out together with the cluster's tables -- one global-memory latency, not two)
 __device__ __forceinline__ void mx_load_block(MxShared &sh, const uint8_t *blk, int if_format, int tid)
 {
@@ -132,7 +130,6 @@ __device__ __forceinline__ void mx_load_block(MxShared &sh, const uint8_t *blk, 
   if (tid < 2)
     sh.ones[tid] = 0;
 }
-template <bool PLANES>
 __device__ void mx_wipe_block(MxShared &sh, u32 step_word, int tid, int lane)
 {
   {
@@ -161,8 +158,6 @@ __device__ void mx_wipe_block(MxShared &sh, u32 step_word, int tid, int lane)
   if (tid < 2)
     sh.d[tid][511] = sh.d[tid][0] << 16;   // samples 16352..16367 are zero, then the stream wraps to sample 0
   __syncthreads();
-  if constexpr (!PLANES)
-    return;
   // plane[iq][t0] bit i = D(16 (i mod 1023) + t0), i < 2112.  First period: word w of offset t0 takes bit t0 and bit 16 + t0
   // of the stream words 16 w .. 16 w + 15 (bit 1023 = D(16368 + t0) is the wrap-around copy in word 511: D(t0), as it has
   // to be); the 16 threads of a word read the same 16 addresses (LDS broadcast).
@@ -385,52 +380,6 @@ __device__ __forceinline__ void mx_vector_build_direct(MxShared &sh, int which, 
     dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(w2[1], w2[0], 4u * (u32)c) : w2[0];
 }
 
-// The four vectors of the byte-phase form (sample offsets 0 and 8, low and high part each) in two phases: the block sums
-// S_t0[k] = pop(D[16 k + t0, +16)) once, as bytes (in the polyphase planes' LDS, which this form does not use), then thread
-// (stream, j) looks up its sixteen sums per offset and writes dword j of the eight shifted copies of all four vectors: a
-// third of the instructions of four mx_vector_build_direct calls (which recount every sum for each vector).
-//   vectors: sh.e8[0] / sh.e8[1] = offset 0 low / high, e8x / e8x + one vector = offset 8 low / high
-__device__ __forceinline__ void mx_build_byte_vectors(MxShared &sh, u32 *e8x, int tid)
-{
-  uint8_t *sums = reinterpret_cast<uint8_t *>(&sh.plane[0][0][0]);   // [stream][offset 0 / 8][1024]
-  static_assert(sizeof(sh.plane) >= 2 * 2 * 1024, "block sums fit the planes");
-  for (int m = tid; m < 2 * 512; m += kMxThreads) {
-    const int iq = m >> 9, w = m & 511;
-    const u32 x0 = sh.d[iq][w], x8 = __builtin_amdgcn_alignbit(sh.d[iq][w + 1], x0, 8u);
-    // (word 511: its low half = the sixteen never-mixed samples, then the stream wraps; sums 1023 do not exist and are not read)
-    reinterpret_cast<uint16_t *>(sums + (2 * iq) * 1024)[w] = (uint16_t)(pop16(x0) | ((u32)__popc(x0 >> 16) << 8));
-    reinterpret_cast<uint16_t *>(sums + (2 * iq + 1) * 1024)[w] = (uint16_t)(pop16(x8) | ((u32)__popc(x8 >> 16) << 8));
-  }
-  __syncthreads();
-  const int iq = tid >> 8, j = tid & 255;
-#pragma unroll
-  for (int o = 0; o < 2; o++) {
-    const uint8_t *sv = sums + (2 * iq + o) * 1024;
-    u32 lo[2] = {0, 0}, hi[2] = {0, 0};   // [which]: dwords j and j + 1 of copy 0
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-      const u32 sum = sv[wrap1023(8 * j + e)];
-      const u32 c0 = (0xFEC0u >> (4u * (sum & 3u))) & 0xFu;      // -2 (S & 3) = 0, -2, -4, -6 -> codes 0, C, E, F
-      const u32 c1 = (0xEDCA0u >> (4u * (sum >> 2))) & 0xFu;    // -(S >> 2) = 0 .. -4 -> codes 0, A, C, D, E
-      if (e < 8) {
-        lo[0] |= c0 << (4 * e);
-        lo[1] |= c1 << (4 * e);
-      } else {
-        hi[0] |= c0 << (4 * (e - 8));
-        hi[1] |= c1 << (4 * (e - 8));
-      }
-    }
-#pragma unroll
-    for (int which = 0; which < 2; which++) {
-      u32 *base = o ? e8x + which * (2 * 8 * kCopyDwords) : &sh.e8[which][0][0][0];
-      u32 *dst = base + (iq * 8) * kCopyDwords + j;
-#pragma unroll
-      for (int c = 0; c < 8; c++)
-        dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi[which], lo[which], 4u * (u32)c) : lo[which];
-    }
-  }
-}
-
 // One anti-diagonal of a pass (fragment Q0 + 2 S): request the fragments of the next one, then the MFMAs of this one.
 // The sched_group_barriers pin that order -- the DS reads first, (8 MFMAs = 260 cycles ahead of their use) -- which the
 // scheduler, short of registers, would otherwise turn into "requested one MFMA before the wait": the LDS is kept busy by
@@ -630,14 +579,12 @@ __device__ __forceinline__ void mx_init_acc(const u32 *ones, int lane, int q0_ti
 // A_b = 2 pop(byte_o & low_b) - b (quirk Q5); W = data bytes (2045, 0), the word at the wrap; P = data bytes (o - 2, o - 1),
 // T = [q > 0]: the two replica words odd offsets skip (quirk Q3); alpha_b = b, beta_b = 16 - 2 pop(W) - b because the low
 // byte of W (data byte 2045, never mixed) is zero.  At b = 0: A = 0, alpha = 0.
-// DIRECT: the accumulators were started afresh for sample offset 8 (mx_vector_build_direct) -- they never held A_7 of the even
-// offsets, so only the odd offset's own terms are put in.
-// (d_i / d_q: the block's wiped streams -- sh.d[0] / sh.d[1], or the other block's pair in the pipelined byte-phase form)
-template <bool DIRECT, int NT>
-__device__ __forceinline__ void mx_half_switch(const MxShared &sh, const u32 *d_i, const u32 *d_q, int lane, int q0_tile,
-                                               v16f (&acc)[2][NT], int win_start, int win_stop)
+template <int NT>
+__device__ __forceinline__ void mx_half_switch(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][NT], int win_start,
+                                               int win_stop)
 {
   const int n = lane & 31, h = lane >> 5;
+  const u32 *d_i = sh.d[0], *d_q = sh.d[1];
   const u32 wrap_i = (d_i[0] & 0xFFu) << 8, wrap_q = (d_q[0] & 0xFFu) << 8;
   const float beta0_i = (float)(16 - 2 * (int)__popc(wrap_i)) * kAccScale, beta0_q = (float)(16 - 2 * (int)__popc(wrap_q)) * kAccScale;
   const int popw_i = (int)__popc(wrap_i), popw_q = (int)__popc(wrap_q);
@@ -650,8 +597,8 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, const u32 *d_
     const bool in0 = exists && 2 * q >= win_start && 2 * q < win_stop;
     const bool in1 = exists && 2 * q + 1 >= win_start && 2 * q + 1 < win_stop;
     // A_7 of the even offset goes, A_0 = 0 of the odd one comes
-    int fa_i = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(d_i, 2 * qc) & 0x7Fu) - 7);
-    int fa_q = DIRECT ? 0 : -(2 * (int)__popc(lds_byte(d_q, 2 * qc) & 0x7Fu) - 7);
+    int fa_i = -(2 * (int)__popc(lds_byte(d_i, 2 * qc) & 0x7Fu) - 7);
+    int fa_q = -(2 * (int)__popc(lds_byte(d_q, 2 * qc) & 0x7Fu) - 7);
     int fk_i = -popw_i, fk_q = -popw_q;
     if (q > 0 && exists) {
       const u32 prev_i = lds_byte(d_i, 2 * qc - 1) | (lds_byte(d_i, 2 * qc) << 8);
@@ -679,7 +626,8 @@ __device__ __forceinline__ void mx_half_switch(const MxShared &sh, const u32 *d_
 }
 
 // ---- sample offset 8 started directly, with the odd byte offset's terms in the start values and in ONE extra K step per pass -----
-// (the pipelined byte-phase form; mx_half_switch<DIRECT> is the same sum patched in by the vector ALU after the passes.)
+// (the byte-phase form, mx_byte_pipe; the formula is the one in front of mx_half_switch at b = 0, without the A_7 that a walk
+//  from the even offsets would have left in the accumulators.)
 //   extra(q, p) = - pop(W) - chip_p[1022 - q] beta_0 + T(q) [ (2 c1022_p - 1) S_8[q - 1] - 16 c1022_p ]
 // because P = data bytes (2 q - 1, 2 q) IS the block D[16 (q - 1) + 8, +16) whose popcount the offset-8 vectors already carry
 // as entry q - 1: the tail word acts as one more chip, "chip -1" = chip 1022 in +-1 form.  So
@@ -1216,7 +1164,7 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
 
 
 
-constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5, kMxBytePipe = 6;   // k_acq_mx's MODE
+constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5;   // k_acq_mx's MODE
 
 }  // namespace
 
@@ -1271,17 +1219,12 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
   // 0..7 and 8..15, the second one started directly at offset 8 (as the byte-phase form does); their search results meet in
   // two global u32 planes (`energy` = packed keys, behind them the sums: atomicMax / atomicAdd) that k_acq_finalize converts
   constexpr bool SPLIT = MODE == kMxSplit;
-  constexpr bool BYTE = MODE == kMxByte;   // single block, byte-phase grid (its own instantiation: branches around the
-                                           // accumulator arrays in the fine grid's loop cost that form its registers)
   typedef SumRecT<S16> SumRec;
   if constexpr (MODE == kMxWalk) {
     if (flags && flags[wg] == 0)   // (uniform: the 16-bit run of this cluster was exact)
       return;
   }
-  int tid_raw = threadIdx.x;
-  if constexpr (MODE == kMxByte)
-    asm volatile("" : "+v"(tid_raw));   // (persistent form: per-thread arithmetic is redone per cluster, not kept across the walk)
-  const int tid = tid_raw;
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform values in SGPRs)
 #ifdef GPSX_MX_ABLATIONS
   const int ex = prm.experiment;
@@ -1327,11 +1270,10 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     const u32 *src_t = mx_t + (size_t)set * 1032;
     for (int i = tid; i < 1032; i += kMxThreads)
       sh.chip_t[i] = src_t[i];
-    if constexpr (!BYTE)
-      mx_fill_tables(sh, tid);
+    mx_fill_tables(sh, tid);
     tables_set = set;
   }
-  for (int i = tid; i < (BYTE ? 1 : 8) * 32 * 2 * 32 / 4; i += kMxThreads)   // (BYTE: bit shift 0 only, the rest holds vectors)
+  for (int i = tid; i < 8 * 32 * 2 * 32 / 4; i += kMxThreads)
     reinterpret_cast<uint4 *>(&sh.part[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
   const uint8_t *block0 = if_blocks + (size_t)(search * prm.search_stride_blocks + (STORE ? wg % prm.n_ms : 0)) * block_bytes;
@@ -1351,9 +1293,6 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
   const u32 *zero_recs = MULTI ? flags - kMxZeroRecBytes / sizeof(u32) : nullptr;   // (the launcher put them in front of the flags)
   u32 witness = 0;   // S16: OR of every sum this lane stored
   const int n_ms = MULTI ? prm.n_ms : 1;
-  // Byte-phase grids (the reference's own 2046-phase search: bit shift 0 only) are sample offsets 0 and 8 of the fine grid;
-  // MODE kMxByte starts each from its own block sums: four passes, two epilogues (round 2 walked ten of the seventeen passes
-  // to get from offset 0 to offset 8).
   // SPLIT: two direct passes at sample offset t0s, then 16 / n_seg - 1 steps of the walk (local pass lp >= 2 is pass t0s + lp)
   const int t0s = SPLIT ? seg * (16 / n_seg) : 0;
   const int n_pass = SPLIT ? 16 / n_seg + 1 : kPasses;
@@ -1371,45 +1310,8 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       mx_load_block(sh, block0 + (size_t)ms * block_bytes, prm.if_format, tid_p);
       __syncthreads();
     }
-    mx_wipe_block<!BYTE>(sh, step_word, tid_p, lane_p);
-    if constexpr (BYTE) {
-      // Byte-phase grid: sample offsets 0 and 8, each from its own block sums -- all four vectors are built here (the third
-      // and fourth in the search-result slots of bit shifts 1..7, which this form does not have), and then every wave runs
-      // its six stages with no barrier at all: waves 4..7 start one pass late, so that on every SIMD one wave's epilogue runs
-      // under the other's matrix passes.
-      u32 *e8x = &sh.part[1][0][0][0];   // 7 x 8 KB free; two vectors take 2 x 16.25 KB
-      static_assert(sizeof(sh.part) - sizeof(sh.part[0]) >= 2 * 2 * 8 * kCopyDwords * sizeof(u32), "room for two vectors");
-      mx_build_byte_vectors(sh, e8x, tid);
-      __syncthreads();
-      // Stages of (tile pair, sample offset), four per wave: two passes on two q-tiles (128 MFMAs), the odd offset's terms, one
-      // epilogue (32 hypotheses per lane).  The two waves of a SIMD are held in antiphase by one barrier per stage -- waves
-      // 0..3: passes, then epilogue; waves 4..7: the previous stage's epilogue, then passes -- as in the fine grid's loop.
-      // Left to themselves (no barrier, a head start for one role) they fall into lockstep, which is stable: a wave in its
-      // epilogue next to the other's MFMAs issues at 2/3 of its rate until the other catches up, and from then on both want
-      // the matrix pipe together and the vector ALU together -- measured: passes and epilogues simply added up (0.88 ms).
-      v16f acc[2][2];
-#pragma unroll 1
-      for (int hs = 0; hs <= 8; hs++) {
-        if ((hs & 1) == 0)
-          __syncthreads();
-        const int x = hs - role;
-        if (x < 0 || x >= 8)
-          continue;
-        const int item = x >> 1, o = item >> 1, q0t = q0_tile + 4 * (item & 1);   // sample offset 8 o, q-tiles q0t and q0t + 2
-        if ((x & 1) == 0) {
-          const u32 *va = o ? e8x : &sh.e8[0][0][0][0], *vb = o ? e8x + 2 * 8 * kCopyDwords : &sh.e8[1][0][0][0];
-          mx_init_acc(sh.ones, lane, q0t, acc, prm.win_start, prm.win_stop);
-          mx_pass<true>(sh, 0, lane, q0t, acc, kScaleOne, a_corr, false, va);
-          mx_pass<true>(sh, 1, lane, q0t, acc, kScaleEight, a_corr, false, vb);
-          if (o)
-            mx_half_switch<true>(sh, sh.d[0], sh.d[1], lane, q0t, acc, prm.win_start, prm.win_stop);
-        } else {
-          const u32 kq2[2] = {(u32)(2047 - 2 * (32 * q0t + (lane & 31))), (u32)(2047 - 2 * (32 * (q0t + 2) + (lane & 31)))};
-          mx_epilogue_single(sh, lane, kq2, 8 * o, acc);
-        }
-      }
-      continue;
-    } else if (SPLIT && seg) {
+    mx_wipe_block(sh, step_word, tid_p, lane_p);
+    if (SPLIT && seg) {
       // not the first run: the first two vectors from the block sums of sample offset t0s (the planes' barrier is the loop's first)
       mx_vector_build_direct(sh, 0, t0s, &sh.e8[0][0][0][0], tid);
       mx_vector_build_direct(sh, 1, t0s, &sh.e8[1][0][0][0], tid);
@@ -1492,7 +1394,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
           }
         } else {
           if (p == 9)
-            mx_half_switch<false>(sh, sh.d[0], sh.d[1], lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
+            mx_half_switch(sh, lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
         }
       }
       if (STORE) {
@@ -1572,7 +1474,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
   }
 }
 
-// ---- the byte-phase grid as ONE software pipeline over the clusters of a persistent workgroup (k_acq_mx<6>) -----------------
+// ---- the byte-phase grid as ONE software pipeline over the clusters of a persistent workgroup (k_acq_mx<4>) -----------------
 // Per cluster and wave two stages -- sample offset 0, sample offset 8, each started from its own block sums: start values, two
 // passes on the wave's four q-tiles, an epilogue of 64 hypotheses per lane -- the two waves of a SIMD half a stage apart, one
 // barrier per stage.  The clusters follow each other WITHOUT a fill and a drain half stage and without a preamble between them:
@@ -1715,12 +1617,18 @@ __device__ __forceinline__ void mx_byte_fold(MxShared &sh, int slots, u32 group_
   const uint4 v = *row;
   *row = make_uint4(0, 0, 0, 0);
   u32 k = max(max(v.x, v.y), max(v.z, v.w)), t = v.x + v.y + v.z + v.w;
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    const u32 ko = (u32)__shfl_xor((int)k, m, 64), to = (u32)__shfl_xor((int)t, m, 64);
-    k = ko > k ? ko : k;
-    t += to;
+  // the eight lanes of a PRN: neighbours, pairs (quad permutes), then the other half of the eight (mirrored: all four alike by then)
+#define MX_FOLD8(ctrl)                                                                          \
+  {                                                                                             \
+    const u32 ko = (u32)__builtin_amdgcn_mov_dpp((int)k, ctrl, 0xF, 0xF, true);                 \
+    const u32 to = (u32)__builtin_amdgcn_mov_dpp((int)t, ctrl, 0xF, 0xF, true);                 \
+    k = ko > k ? ko : k;                                                                        \
+    t += to;                                                                                    \
   }
+  MX_FOLD8(0xB1)    // quad_perm [1, 0, 3, 2]
+  MX_FOLD8(0x4E)    // quad_perm [2, 3, 0, 1]
+  MX_FOLD8(0x141)   // row_half_mirror
+#undef MX_FOLD8
   const int slot = 32 * set + p;
   if (part == 0 && ((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn) {
     const size_t idx = ((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits;
@@ -1802,11 +1710,18 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     decode(i, search, dopp, mask);
     return if_blocks + (size_t)(search * prm.search_stride_blocks) * block_bytes;
   };
+  // the carrier's step per 32-sample word for the first 256 Doppler bins (one correctly rounded division each: once per
+  // workgroup instead of once per cluster, where everything in the wipe-off piece waits for it); behind the code table
+  u32 *step_tab = sh.t_lut + 512;
+  static_assert(sizeof(sh.t_lut) >= (512 + 256) * sizeof(u32), "step table fits");
+  auto step_of_bin = [&](int dopp) {
+    return nco_step_per_word((float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz));   // PM/GPS/acquisition.c:285-289
+  };
   auto step_of = [&](int i) {
     int search, dopp;
     u32 mask;
     decode(i, search, dopp, mask);
-    return nco_step_per_word((float)(prm.if_hz + prm.dopp_min_hz + dopp * prm.dopp_step_hz));   // PM/GPS/acquisition.c:285-289
+    return dopp < 256 ? step_tab[dopp] : step_of_bin(dopp);
   };
   auto d_of = [&](int i) { return i & 1 ? d_alt : &sh.d[0][0]; };
   auto ones_of = [&](int i) { return ones3 + 2 * (i % 3); };
@@ -1828,6 +1743,8 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     for (int i = tid; i < 2 * kSlotVecs; i += kMxThreads)
       reinterpret_cast<uint4 *>(&sh.part[i / kSlotVecs ? kSlotsOdd : kSlotsEven][0][0][0])[i % kSlotVecs] = make_uint4(0, 0, 0, 0);
     mx_byte_fill_code_table(sh, tid);
+    if (tid < 256 && tid < prm.n_dopp)
+      step_tab[tid] = step_of_bin(tid);
     if (tid < 6)
       ones3[tid] = 0;
     if (tid < 4) {   // the zero pad behind the wrap-around word, both copies
@@ -1873,35 +1790,49 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     asm volatile("" : "+v"(t));   // (per-thread addresses of these pieces are recomputed, not kept across the stages)
     const int c = hs_even >> 2;
     window_to(c);
+    const bool steady = c >= 1 && c + 2 < n_my;   // every piece exists: one straight run, their LDS round trips overlap
+#ifdef GPSX_MX_NO_PIECES   // (timing ablation: results are then wrong)
+    if (steady)
+      return;
+#endif
     if ((hs_even & 2) == 0) {
-      MX_TL2();
-      if (c < n_my)
+      if (steady) {
+        const u32 step = step_of(c + 1);
+        const uint8_t *blk = block_of(c + 2);
+        next_block = mx_block_request(blk, prm.if_format, t);
         mx_byte_vector_pair(base8_of(c), e8x, e8x + kVec, t);
-      MX_TL2();
-      if (c + 1 < n_my)
-        mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step_of(c + 1), t, t & 63);
-      MX_TL2();
-      if (c + 2 < n_my)
-        next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
-      MX_TL2();
+        mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step, t, t & 63);
+      } else {
+        if (c < n_my)
+          mx_byte_vector_pair(base8_of(c), e8x, e8x + kVec, t);
+        if (c + 1 < n_my)
+          mx_byte_wipe_codes(sh, d_of(c + 1), ones_of(c + 1), base0, base8_of(c + 1), step_of(c + 1), t, t & 63);
+        if (c + 2 < n_my)
+          next_block = mx_block_request(block_of(c + 2), prm.if_format, t);
+      }
     } else {
-      MX_TL2();
-      if (c + 1 < n_my)
-        mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
-      MX_TL2();
-      if (c + 2 < n_my) {
+      int search, dopp;
+      u32 mask;
+      if (steady) {
+        decode(c - 1, search, dopp, mask);
         mx_block_commit(sh, next_block, prm.if_format, t);
         if (t < 2)
           ones_of(c + 2)[t] = 0;
-      }
-      MX_TL2();
-      if (c >= 1) {
-        int search, dopp;
-        u32 mask;
-        decode(c - 1, search, dopp, mask);
         mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
+        mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+      } else {
+        if (c + 1 < n_my)
+          mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], t);
+        if (c + 2 < n_my) {
+          mx_block_commit(sh, next_block, prm.if_format, t);
+          if (t < 2)
+            ones_of(c + 2)[t] = 0;
+        }
+        if (c >= 1) {
+          decode(c - 1, search, dopp, mask);
+          mx_byte_fold(sh, (c - 1) & 1 ? kSlotsOdd : kSlotsEven, mask, set, search, dopp, prm, peaks, t);
+        }
       }
-      MX_TL2();
     }
   };
 #pragma unroll 1
@@ -1955,17 +1886,11 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mx(const AcqParams prm, i
                                                           u32 *__restrict__ flags)
 {
   __shared__ MxShared sh;
-  int tables_set = -1;
-  if constexpr (MODE == kMxBytePipe) {
+  if constexpr (MODE == kMxByte) {
+    // persistent: one workgroup per CU walks its clusters as one software pipeline
     mx_byte_pipe(sh, prm, cluster_lo, if_blocks, mx_a, mx_t, peaks);
-  } else if constexpr (MODE == kMxByte) {
-    // persistent: one workgroup per CU walks the clusters -- no dispatch gap between them, the PRN set's tables loaded once
-#pragma unroll 1
-    for (int wg = (int)blockIdx.x; wg < prm.n_clusters; wg += (int)gridDim.x) {
-      mx_unit<MODE>(sh, prm, wg, tables_set, cluster_lo, if_blocks, mx_a, mx_t, peaks, energy, flags);
-      __syncthreads();   // the fold's readers are done before the next cluster's preamble writes
-    }
   } else {
+    int tables_set = -1;
     mx_unit<MODE>(sh, prm, (int)blockIdx.x, tables_set, cluster_lo, if_blocks, mx_a, mx_t, peaks, energy, flags);
   }
 }
@@ -2018,17 +1943,11 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   if (prm.n_bits == 1) {   // byte-phase grid: sample offsets 0 and 8, each started from its own block sums
     AcqParams bp = prm;
     bp.n_clusters = c_hi - c_lo;
-    if (!prm.byte_legacy) {
-      // one software pipeline per persistent workgroup; a workgroup keeps ONE PRN set's tables: the grid is a multiple of n_sets
-      const int n_sets = (prm.n_groups + 3) / 4;
-      const int grid = bp.n_clusters < n_cus ? bp.n_clusters : n_cus - n_cus % n_sets;
-      hipLaunchKernelGGL(k_acq_mx<kMxBytePipe>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t,
-                         d_peaks, (u32 *)nullptr, (u32 *)nullptr);
-      return "k_acq_mx<6>";
-    }
-    const int grid = c_hi - c_lo < n_cus ? c_hi - c_lo : n_cus;
-    hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t,
-                       d_peaks, (u32 *)nullptr, (u32 *)nullptr);
+    // one software pipeline per persistent workgroup; a workgroup keeps ONE PRN set's tables: the grid is a multiple of n_sets
+    const int n_sets = (prm.n_groups + 3) / 4;
+    const int grid = bp.n_clusters < n_cus ? bp.n_clusters : n_cus - n_cus % n_sets;
+    hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
+                       (u32 *)nullptr, (u32 *)nullptr);
     return "k_acq_mx<4>";
   }
   if (d_planes && 2 * (c_hi - c_lo) <= n_cus) {

@@ -301,7 +301,7 @@ def test_acq_grid_reference_native_grid_29_bins_byte_phases(eng, oracle, stream)
     from stm32f4_sdr_gps_amd.capi import PHASES_BYTE
     prns = np.arange(1, 33, dtype=np.uint8)
     peaks, _ = eng.acq_grid(stream[4:6], prns, n_search=2, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=PHASES_BYTE)
-    assert eng.lib.gpsx_last_kernel(eng.h) in (b"k_acq_mx<4>", b"k_acq_mx<6>")
+    assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<4>"
     for s_ in range(2):
         want = oracle.acq_grid(stream[4 + s_:5 + s_], 1, prns, -7000, 500, 29, 1, n_threads=ORC_THREADS)
         for f in ("max_val", "phase", "sum", "avr"):
@@ -309,7 +309,7 @@ def test_acq_grid_reference_native_grid_29_bins_byte_phases(eng, oracle, stream)
     prns5 = np.array([5, 14, 20, 30, 1, 33, 210], np.uint8)
     for win in ((0, 1), (1, 2), (1, 2046), (0, 2045), (777, 778), (778, 779), (100, 1901), (2045, 2046), (3, 3)):
         peaks, _ = eng.acq_grid(stream[2:3], prns5, dopp_min_hz=-1000, dopp_step_hz=1000, n_dopp=3, phase_mode=PHASES_BYTE, win=win)
-        assert eng.lib.gpsx_last_kernel(eng.h) in (b"k_acq_mx<4>", b"k_acq_mx<6>")
+        assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<4>"
         for p, prn in enumerate(prns5):
             for d in range(3):
                 pk, _, _ = oracle.search_job(stream[2:3], 1, oracle.ca_code(int(prn)), float(IF_HZ - 1000 + 1000 * d), 0, win[0], win[1])
@@ -335,12 +335,50 @@ def test_byte_phase_grid_persistent_workgroups_two_prn_sets_and_two_bit_if(oracl
     try:
         e.set_if_format(capi.IF_2BIT_SM)
         pk, keys = e.acq_grid(two, prns, **kw)
-        assert e.lib.gpsx_last_kernel(e.h) in (b"k_acq_mx<4>", b"k_acq_mx<6>")
+        assert e.lib.gpsx_last_kernel(e.h) == b"k_acq_mx<4>"
         want_pk, want_keys = ref.acq_grid(one, prns, **kw)
         assert ref.lib.gpsx_last_kernel(ref.h).startswith(b"k_acq<8,false,dot8>")
         assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys)
         for s_, p, d in ((0, 4, 15), (5, 29, 18), (3, 33, 8), (2, 39, 0), (1, 0, 28)):
             o, _, _ = oracle.search_job(one[s_:s_ + 1], 1, oracle.ca_code(int(prns[p])), float(IF_HZ - 7000 + 500 * d), 0)
+            assert _peak_tuple(pk[s_, p, d, 0]) == (o["max_val"], o["phase"], o["sum"], o["avr"]), (s_, p, d)
+    finally:
+        e.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("n_search,win,shard", [(64, None, None), (37, (5, 2001), (1, 3)), (9, (1, 2), None), (18, None, None)])
+def test_byte_phase_grid_pipeline_depths(oracle, monkeypatch, n_search, win, shard):
+    """k_acq_mx<4> is one software pipeline per persistent workgroup: what cluster c + 1 and c + 2 need (block, wipe-off, block
+    sums' codes, vectors) is made behind cluster c's stage barriers, results are written two stages late.  Launches whose
+    workgroups walk 1, 2 (18 captures x 29 bins = 522 clusters on 256 CUs: two or three), 4-5 and 7-8 clusters -- the fill, the
+    short paths with missing pieces and the steady state -- with and without a search window, every triplet and key against
+    the direct 4-bit-dot-product kernel (GPSX_ACQ_ALGO=dot8, itself checked against the oracle), a sample against the oracle."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    blocks = synth.cold_start_block(n_search, seed=31 + n_search, amp_scale=0.3)
+    prns = np.arange(1, 33, dtype=np.uint8)
+    kw = dict(n_search=n_search, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=capi.PHASES_BYTE)
+    if win:
+        kw["win"] = win
+    if shard:   # (the middle third of the sharding units: the run starts and ends inside clusters)
+        kw["shard"] = shard
+    e = capi.Engine(0)
+    monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
+    ref = capi.Engine(0)
+    monkeypatch.delenv("GPSX_ACQ_ALGO")
+    try:
+        pk, keys = e.acq_grid(blocks, prns, **kw)
+        assert e.lib.gpsx_last_kernel(e.h) == b"k_acq_mx<4>"
+        want_pk, want_keys = ref.acq_grid(blocks, prns, **kw)
+        assert ref.lib.gpsx_last_kernel(ref.h).startswith(b"k_acq<8,false,dot8>")
+        assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys)
+        w0, w1 = win if win else (0, 2046)
+        rng = np.random.default_rng(n_search)
+        owned = np.argwhere(keys != 0) if shard else None
+        for _ in range(6):
+            s_, p, d = (int(v) for v in owned[rng.integers(len(owned))]) if shard else \
+                (int(rng.integers(n_search)), int(rng.integers(32)), int(rng.integers(29)))
+            o, _, _ = oracle.search_job(blocks[s_:s_ + 1], 1, oracle.ca_code(int(prns[p])), float(IF_HZ - 7000 + 500 * d), 0, w0, w1)
             assert _peak_tuple(pk[s_, p, d, 0]) == (o["max_val"], o["phase"], o["sum"], o["avr"]), (s_, p, d)
     finally:
         e.close()

@@ -34,8 +34,8 @@ tl = out[n_pk * 16:].view(np.uint64).reshape(2, 2048).astype(np.int64)
 for role in range(2):
     t = tl[role]
     t2 = t[1024:]
-    t2 = t2[:int(np.flatnonzero(t2)[-1]) + 1]
-    if len(t2) >= 16:   # four stamps per piece, alternating start-of-offset-0-stage / start-of-offset-8-stage pieces
+    t2 = t2[:int(np.flatnonzero(t2)[-1]) + 1] if t2.any() else t2[:0]
+    if np.count_nonzero(t2) >= 16:   # four stamps per piece, alternating start-of-offset-0-stage / start-of-offset-8-stage pieces
         q = t2[:len(t2) // 8 * 8].reshape(-1, 8)[2:-2]
         print("  pieces of the offset-0 stage: vectors %5.0f  wipe-off / codes %5.0f  request %5.0f" % tuple(np.diff(q[:, :4], axis=1).mean(axis=0)))
         print("  pieces of the offset-8 stage: vectors %5.0f  commit %5.0f  fold %5.0f" % tuple(np.diff(q[:, 4:], axis=1).mean(axis=0)))
