@@ -86,8 +86,6 @@ struct MxShared {
   u32 ones[2];                           // pop(D) per stream
   u32 t_lut[768];                        // [0, 512): 9 adjacent bits -> FP4 codes of -2 (bit k+1 - bit k), k = 0..7;
                                          // [512, 768): 8 bits -> FP4 codes of 2 bit - 1 (mx_fill_tables)
-  u32 bbase[3][2][2][258];               // pipelined byte-phase form: copy 0 of the vectors as the wipe-off piece leaves them --
-                                         // [offset 0 | offset 8 of even / odd clusters][stream][low / high][dword]
   alignas(16) u32 part[8][32][2][32];              // (packed best key, sum) per bit shift, PRN and lane of the wave half that holds the
                                          // PRN: every lane folds its own results in with LDS atomics (no return value, no
                                          // conflicts), the 32 lanes meet once, when the workgroup writes its triplets
@@ -1329,6 +1327,15 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
       mx_vector_phase2(sh, 1, tid_p, kMxThreads);
     }
 
+#ifdef GPSX_MX_TIMELINE   // (tools/experiments/single_timeline.py: cycle stamps of workgroup 1000's waves 0 and 4 behind the peaks)
+    unsigned long long *tl1 = MODE == kMxSingle && blockIdx.x == 1000 && lane == 0 && (wave & 3) == 0
+                                  ? reinterpret_cast<unsigned long long *>(peaks + (size_t)gridDim.x * 256) + role * 512 : nullptr;
+    int tl1i = 0;
+#define MX_TL1() do { if (tl1 && tl1i < 512) tl1[tl1i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define MX_TL1() do { } while (0)
+#endif
+    MX_TL1();
     v16f acc[2][kMxTiles];
     mx_init_acc(sh.ones, lane_p, q0_tile, acc, prm.win_start, prm.win_stop);
     if ((ex & 2) || ((ex & 32) && role)) {   // (timing ablation without MFMAs: noise-sized counts, so that the epilogue takes its usual path)
@@ -1346,8 +1353,10 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     // into the buffer that both roles read during step p - 1.
 #pragma unroll 1
     for (int hs = (ex & 256) ? 2 * n_pass + 1 : 0; hs <= 2 * n_pass; hs++) {   // (timing ablation 256: no steps at all)
+      MX_TL1();
       if ((hs & 1) == 0)
         __syncthreads();
+      MX_TL1();
       // The vector of the next step: built behind the barrier by everybody (single-block forms), or behind this step's epilogue
       // by the role that just finished one (walk forms: each role's threads own one stream of the vector -- threads 0..255 =
       // waves 0..3 = I, 256..511 = Q --, the buffer it goes into was last read in the previous step, and the barrier that opens
@@ -1368,6 +1377,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
           mx_vector_build(sh, pbase + p_vec, tid_v);
         }
       }
+      MX_TL1();
       int lane_s = lane;         // (walk forms: opaque per half step, see tid_p -- record addresses are recomputed, not spilled)
       if constexpr (MULTI)
         asm volatile("" : "+v"(lane_s));
@@ -1397,6 +1407,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
             mx_half_switch(sh, lane_s, q0_tile, acc, prm.win_start, prm.win_stop);
         }
       }
+      MX_TL1();
       if (STORE) {
         if (active && (x & 1) && p >= 1) {
           uint16_t *plane0 = reinterpret_cast<uint16_t *>(energy) +
@@ -1656,13 +1667,15 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   const int set = first % n_sets;                        // (the launcher's grid is a multiple of n_sets: one PRN set per workgroup)
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
 
-  // LDS this form has to itself: the polyphase planes (second copy of d, three of ones), result slots 1..5 (the offset-8
-  // vectors) and 6 (odd clusters' results)
+  // LDS this form has to itself: the polyphase planes (second copy of d, three of ones), the lookup tables (code table, step
+  // table), and of the result slots of bit shifts 1..7: the offset-8 vectors, behind them copy 0 of the vectors as the wipe-off
+  // piece leaves them ([offset 0 | offset 8 of even / odd clusters][stream][low / high][258 dwords]), slot 7 = odd clusters' results
   u32 *d_alt = &sh.plane[0][0][0], *ones3 = d_alt + 2 * 514;   // ones3[3][2]
   static_assert(sizeof(sh.plane) >= (2 * 514 + 6) * sizeof(u32), "overlays fit");
   u32 *e8x = &sh.part[1][0][0][0];
-  constexpr int kVec = 2 * 8 * kCopyDwords, kSlotsEven = 0, kSlotsOdd = 6;
-  static_assert(2 * kVec * sizeof(u32) <= 5 * sizeof(sh.part[0]), "two vectors below result slots 6");
+  constexpr int kVec = 2 * 8 * kCopyDwords, kBase = 2 * 2 * 258, kSlotsEven = 0, kSlotsOdd = 7;
+  u32 *bbase = e8x + 2 * kVec;
+  static_assert((2 * kVec + 3 * kBase) * sizeof(u32) <= 6 * sizeof(sh.part[0]), "two vectors and three sets of their copy 0 below result slots 7");
 
   // (search, Doppler bin) of this workgroup's clusters c - 1 .. c + 2 around the cluster c the pieces are at: moved on by
   // additions, one division when the workgroup starts (a cluster's pieces need three decodes; divisions cost them a third)
@@ -1725,8 +1738,8 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   };
   auto d_of = [&](int i) { return i & 1 ? d_alt : &sh.d[0][0]; };
   auto ones_of = [&](int i) { return ones3 + 2 * (i % 3); };
-  u32 *base0 = &sh.bbase[0][0][0][0];
-  auto base8_of = [&](int i) { return &sh.bbase[1 + (i & 1)][0][0][0]; };
+  u32 *base0 = bbase;
+  auto base8_of = [&](int i) { return bbase + (1 + (i & 1)) * kBase; };
 
   // ---- fill: tables of the PRN set, cluster 0 up to its offset-0 vectors, cluster 1's block in LDS ------------------------------
   {
