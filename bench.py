@@ -324,6 +324,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true",
                     help="skip the pcie_inclusive leg (profiling runs: its two concurrent contexts stretch the kernel durations "
                          "a kernel trace averages)")
+    ap.add_argument("--no-native", action="store_true", help="skip the reference-native (byte-phase) grid leg")
     ap.add_argument("--no-tracking", action="store_true",
                     help="skip the secondary metric (real-time tracking channels: E/P/L steps of growing channel counts)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -445,11 +446,46 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         gpu_ms = eng.elapsed_ms(ev0, ev1)
+        headline_kernel = eng.lib.gpsx_last_kernel(eng.h).decode()   # (before the secondary legs launch theirs)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
+
+    # The reference's OWN search grid on the same captures (SURVEY.md 8(d) "also report"): 32 PRN x 29 Doppler bins (+-7 kHz at
+    # 500 Hz, PM/GPS/acquisition.c:285-289) x 2046 byte-granular code phases, replica bit shift 0 -- k_acq_mx<4>.
+    native = None
+    if world == 1 and n_ms == 1 and not args.no_native:
+        try:
+            gn = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=-7000, dopp_step_hz=500,
+                               n_dopp=29, phase_mode=capi.PHASES_BYTE)
+            with torch.cuda.stream(stream):
+                def native_step():
+                    rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(gn), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
+                                                   key_bufs[0].data_ptr(), None, None, None)
+                    if rc != 0:
+                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
+                for _ in range(3):
+                    native_step()
+                torch.cuda.synchronize()
+                n0, n1 = eng.event(), eng.event()
+                eng.record(n0)
+                for _ in range(20):
+                    native_step()
+                eng.record(n1)
+                torch.cuda.synchronize()
+                n_ms_launch = eng.elapsed_ms(n0, n1) / 20
+            n_hyp = n_search * N_PRN * 29 * 2046
+            n_flops = 4 * 2 * 2.0 * 32 * 1024 * 1024 * n_search * 29   # four FP4 GEMM passes x 2 streams per (capture, bin)
+            native = {"workload": "32 PRN x 29 Doppler x 2046 byte phases per capture, %d captures per launch" % n_search,
+                      "value": n_hyp / (n_ms_launch * 1e-3), "unit": "hypotheses/s", "ms_per_launch": n_ms_launch,
+                      "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
+                      "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 10000.0,
+                                   "achieved": n_flops / (n_ms_launch * 1e-3) / 1e12, "frac": n_flops / (n_ms_launch * 1e-3) / 1e16}}
+        except Exception as exc:   # a secondary leg must not take the headline line with it
+            native = {"error": repr(exc)}
+            print(f"bench.py: native-grid leg failed: {exc!r}", file=sys.stderr, flush=True)
 
     # PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
     # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
@@ -590,7 +626,7 @@ def main():
         value = total_hyp / elapsed_s
         launch_ms = gpu_ms / args.steps                   # HIP events on the engine's stream around the K launches
         hyp_per_launch = args.searches * n_ms * HYP_PER_SEARCH   # per GPU
-        kernel = eng.lib.gpsx_last_kernel(eng.h).decode()
+        kernel = headline_kernel
         # counters of this kernel and launch shape, from the committed rocprofv3 PMC summaries (tools/summarize_profile.py)
         counters = None
         kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
@@ -739,6 +775,8 @@ def main():
             line["single_search"] = single
         if local_ref is not None:
             line["per_gpu_unsharded"] = local_ref
+        if native is not None:
+            line["native_grid"] = native
         if tracking is not None:
             line["tracking"] = tracking
         if not args.no_cpu_baseline and world == 1:

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/pmc_quick
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # ($PMC_CMD: another command than the bench, e.g. PMC_CMD="python $REPO/tools/bench_native_grid.py --steps 3 --warmup 1")
-CMD=${PMC_CMD:-"python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-pcie $*"}
+CMD=${PMC_CMD:-"python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-pcie --no-native $*"}
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/a -o pmc -- $CMD > $OUT/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INST_CYCLES_SALU --output-format csv -d $OUT/b -o pmc -- $CMD > $OUT/b.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F8 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/c -o pmc -- $CMD > $OUT/c.log 2>&1

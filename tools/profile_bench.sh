@@ -8,9 +8,9 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 EXTRA=${BENCH_ARGS:-}   # e.g. BENCH_ARGS="--n-ms 10" for the non-coherent configuration
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-tracking --no-pcie $EXTRA"
+BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-tracking --no-pcie --no-native $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-SMALL="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-pcie $EXTRA"
+SMALL="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-pcie --no-native $EXTRA"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $SMALL > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $SMALL > $OUT/pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq -o pmc -- $SMALL > $OUT/pmc_sq.log 2>&1
