@@ -412,8 +412,43 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
     mx_pass_step<S + 1, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
 }
 
-// AHEAD = false (the walk form, whose prefetched sums leave no registers for a second set of fragments): every fragment is
-// requested where the compiler sees fit before its use
+// The same without a second set of fragment registers (the walk forms, whose prefetched sums leave none): the I fragment of the
+// next anti-diagonal is requested INTO the registers of this one's as soon as its MFMAs have been issued, under the Q stream's
+// MFMAs, the Q fragment under the next step's I MFMAs -- four MFMAs (130 cycles) of cover each instead of eight; the A fragment
+// (registers of its own) a whole step ahead.
+template <int S, int NT>
+__device__ __forceinline__ void mx_pass_step_inplace(lds_cu32 *wi, lds_cu32 *wq, const v4i *ca, v4i (&a)[16], v4i &fi, v4i &fq,
+                                                     v16f (&acc)[2][NT], u32 scale_b)
+{
+  constexpr int kSteps = 16 + NT - 1;
+  constexpr bool more = S + 1 < kSteps;
+  if constexpr (more && S + 1 < 16)
+    a[S + 1] = ca[(S + 1) * 64];                           // chips_a[S + 1][h][n]
+  constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < NT - 1 ? S : NT - 1;
+#pragma unroll
+  for (int j = j_lo; j <= j_hi; j++)
+    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
+  if constexpr (more)
+    fi = lds_frag(wi, 8 * (S + 1));
+#pragma unroll
+  for (int j = j_lo; j <= j_hi; j++)
+    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fq), acc[1][j], 4, 4, 0, kScaleA, 0, scale_b);
+  if constexpr (more)
+    fq = lds_frag(wq, 8 * (S + 1));
+  if constexpr (more) {
+    if constexpr (S + 1 < 16)
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read: the A fragment
+    __builtin_amdgcn_sched_group_barrier(0x008, j_hi - j_lo + 1, 0);     // MFMAs, I
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                   // DS reads: the next I fragment
+    __builtin_amdgcn_sched_group_barrier(0x008, j_hi - j_lo + 1, 0);     // MFMAs, Q
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                   // DS reads: the next Q fragment
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (more)
+    mx_pass_step_inplace<S + 1, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
+}
+
+// AHEAD = false (the walk forms): mx_pass_step_inplace
 // NT = q-tiles of this call (q0_tile + 2 j, j < NT): four everywhere but in the byte-phase form, which works in tile pairs
 template <bool AHEAD, int NT>
 __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][NT],
@@ -431,20 +466,9 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
     a[0] = ca[0];
     mx_pass_step<0, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
   } else {
-#pragma unroll
-    for (int s = 0; s < 16 + NT - 1; s++) {
-      if (s < 16)
-        a[s] = ca[s * 64];                                   // chips_a[s][h][n]
-      const v4i fi = lds_frag(wi, 8 * s), fq = lds_frag(wq, 8 * s);   // fragment Q0 + 2 s
-#pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const int kappa = s - j;
-        if (kappa < 0 || kappa >= 16)
-          continue;
-        acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
-        acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[kappa]), widen(fq), acc[1][j], 4, 4, 0, kScaleA, 0, scale_b);
-      }
-    }
+    v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
+    a[0] = ca[0];
+    mx_pass_step_inplace<0, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
   }
   if (with_corr) {   // wave-uniform
     // the extra K step: only column 0 of each lane half of A is set (chip 1022 / chip 1021 of the PRN), so only the first
@@ -1328,7 +1352,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     }
 
 #ifdef GPSX_MX_TIMELINE   // (tools/experiments/single_timeline.py: cycle stamps of workgroup 1000's waves 0 and 4 behind the peaks)
-    unsigned long long *tl1 = MODE == kMxSingle && blockIdx.x == 1000 && lane == 0 && (wave & 3) == 0
+    unsigned long long *tl1 = (MODE == kMxSingle || (MODE == kMxWalk16 && ms == 5)) && blockIdx.x == 1000 && lane == 0 && (wave & 3) == 0
                                   ? reinterpret_cast<unsigned long long *>(peaks + (size_t)gridDim.x * 256) + role * 512 : nullptr;
     int tl1i = 0;
 #define MX_TL1() do { if (tl1 && tl1i < 512) tl1[tl1i++] = __builtin_readcyclecounter(); } while (0)

@@ -15,9 +15,10 @@ from stm32f4_sdr_gps_amd import capi, synth   # noqa: E402
 capi.LIB_PATH = os.path.join(ROOT, "stm32f4_sdr_gps_amd/lib/libgpsx_b.so")
 eng = capi.Engine(0)
 searches, n_prn, n_dopp = 256, 32, 21
-blocks = synth.cold_start_block(searches, seed=11, amp_scale=0.25)
+n_ms = int(sys.argv[1]) if len(sys.argv) > 1 else 1   # 10: the walk form k_acq_mx<3>, block 5 of workgroup 1000
+blocks = synth.cold_start_block(searches * n_ms, seed=11, amp_scale=0.25)
 prns = np.arange(1, n_prn + 1, dtype=np.uint8)
-g = eng.grid_desc(prns, n_search=searches, n_ms=1, search_stride_blocks=1, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=n_dopp,
+g = eng.grid_desc(prns, n_search=searches, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=n_dopp,
                   phase_mode=capi.PHASES_FINE)
 n_pk = searches * n_prn * n_dopp * 8
 d_if = eng.malloc(blocks.size + 2)
@@ -25,7 +26,7 @@ eng.h2d(d_if, np.concatenate([blocks.reshape(-1), np.zeros(2, np.uint8)]))
 d_peaks = eng.malloc(n_pk * 16 + 2 * 512 * 8)
 d_keys = eng.malloc(searches * n_prn * n_dopp * 8)
 for _ in range(3):
-    eng._chk(eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), C.c_void_p(d_if), searches, C.c_void_p(d_peaks), C.c_void_p(d_keys),
+    eng._chk(eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), C.c_void_p(d_if), searches * n_ms, C.c_void_p(d_peaks), C.c_void_p(d_keys),
                                        None, None, None), "grid")
 eng.synchronize()
 print(eng.lib.gpsx_last_kernel(eng.h))
