@@ -14,6 +14,7 @@ cp gpurun_out/${T}_tracking_latency.json profiles/${T}_tracking_latency.json
 [ -d gpurun_out/prof_${T}_track_loop ] && python tools/summarize_track_profile.py ${T}_track_loop 212992 k_track_loop 20 > /dev/null
 [ -s gpurun_out/${T}_track_loop_kernel_us.json ] && cp gpurun_out/${T}_track_loop_kernel_us.json profiles/${T}_track_loop_kernel_us.json
 [ -s gpurun_out/prof_${T}_native/trace/trace_kernel_stats.csv ] && cp gpurun_out/prof_${T}_native/trace/trace_kernel_stats.csv profiles/${T}_native_grid_kernel_stats.csv
+[ -s gpurun_out/${T}_native_pmc_summary.json ] && cp gpurun_out/${T}_native_pmc_summary.json profiles/${T}_native_grid_pmc_summary.json
 [ -s gpurun_out/${T}_gputests.log ] && cp gpurun_out/${T}_gputests.log profiles/${T}_gputests.log
 if [ -f gpurun_out/${T}_sweep.txt ]; then
 python - "$T" <<'PY'

@@ -34,6 +34,7 @@ python tools/bench_tracking.py > gpurun_out/${T}_tracking_latency.json 2>/dev/nu
   for n in 1 4 16; do for a in mx poly; do GPSX_ACQ_ALGO=$a python tools/bench_grid_kernel.py $n 10 5 2>/dev/null | tail -1; done; done ) > gpurun_out/${T}_sweep.txt 2>&1
 python tools/bench_native_grid.py 2>/dev/null | tail -1 > gpurun_out/${T}_native.json
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${T}_native/trace -o trace -- python $GRAFT_REPO_ROOT/tools/bench_native_grid.py > $GRAFT_REPO_ROOT/gpurun_out/${T}_native_prof.log 2>&1 )
+PMC_JSON=$GRAFT_REPO_ROOT/gpurun_out/${T}_native_pmc_summary.json PMC_CMD="python $GRAFT_REPO_ROOT/tools/bench_native_grid.py --steps 3 --warmup 1" bash tools/pmc_quick.sh "k_acq_mx<4>" > gpurun_out/${T}_native_pmc.log 2>&1
 python tools/pcie_probe.py > gpurun_out/${T}_pcie_probe.txt 2>&1
 python - "$T" <<'PY'
 import json, sys
