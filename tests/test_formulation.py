@@ -85,3 +85,44 @@ def test_sad_formulation_codes_with_both_end_chips(oracle):
             want = np.array([oracle.mult_and_summ(di, dq, rep, o) for o in range(2046)], np.int64)
             assert np.array_equal(model_counts(di, chips, b), want[:, 0])
             assert np.array_equal(model_counts(dq, chips, b), want[:, 1])
+
+
+def mx_byte_phase_counts(d_words, chips):
+    """The byte-phase grid (replica bit shift 0) as k_acq_mx<4> forms it on the matrix cores (csrc/k_acq_mx.hip, mx_byte_pipe):
+    both sample offsets started directly from their block sums S_t0[k] = pop(D[16 k + t0, +16)), as ONE Toeplitz product each,
+        even o = 2 q:      cnt - 8184 = pop(D) + 8 + sum_c chip[c] (-2 S_0[(q + c) mod 1023])
+        odd  o = 2 q + 1:  cnt - 8184 = pop(D) + 8 - pop(W) + sum_c chip[c] (-2 E[q + c]) + [q > 0] (sgn S_8[q - 1] - 16 chip[1022])
+    with E[i] = S_8[i mod 1023] except E[1022] = 8 (first period only: the wrap word's term -chip[1022 - q] (16 - 2 pop(W)) is that
+    entry lowered by 16 - 2 pop(W), and pop(W) = pop(D[0, 8)) IS S_8[1022]), sgn = 2 chip[1022] - 1 (the tail word P = D[16 (q - 1)
+    + 8, +16) acts as one more chip, "chip -1" = chip 1022) -- no per-hypothesis correction left for the vector ALU."""
+    D = _bits(d_words)                                # 16368 samples, the last 16 (word 1022) zero
+    Dd = np.concatenate([D, D])
+    chips = chips.astype(np.int64)
+    ones = int(D.sum())
+    S0 = np.array([Dd[16 * k:16 * k + 16].sum() for k in range(1023)])
+    S8 = np.array([Dd[16 * k + 8:16 * k + 24].sum() for k in range(1023)])
+    popw = int(D[:8].sum())
+    assert S8[1022] == popw
+    E0 = np.concatenate([S0, S0])
+    E8 = np.concatenate([S8, S8])
+    E8[1022] = 8
+    sgn = 2 * int(chips[1022]) - 1
+    cnt = np.zeros(2046, np.int64)
+    for q in range(1023):
+        cnt[2 * q] = 8184 + ones + 8 - 2 * int((chips * E0[q:q + 1023]).sum())
+        odd = ones + 8 - popw - 2 * int((chips * E8[q:q + 1023]).sum())
+        if q > 0:
+            odd += sgn * int(S8[q - 1]) - 16 * int(chips[1022])
+        cnt[2 * q + 1] = 8184 + odd
+    return cnt
+
+
+def test_matrix_core_byte_phase_formulation_equals_oracle(oracle):
+    g = load("f4_corr.npz")
+    for prn, dopp, blk_i in ((2, -2500, 2), (4, 1300, 0), (6, 4975, 1), (16, -6800, 3), (31, 0, 2)):   # the four (c1021, c1022) pairs
+        chips = oracle.ca_code(prn)
+        di, dq, _ = oracle.wipeoff(g["stream"][blk_i], float(IF_HZ + dopp))
+        rep = oracle.replica(chips, 0)
+        want = np.array([oracle.mult_and_summ(di, dq, rep, o) for o in range(2046)], np.int64)
+        assert np.array_equal(mx_byte_phase_counts(di, chips), want[:, 0]), (prn, "I")
+        assert np.array_equal(mx_byte_phase_counts(dq, chips), want[:, 1]), (prn, "Q")
