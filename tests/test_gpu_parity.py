@@ -347,12 +347,14 @@ def test_byte_phase_grid_persistent_workgroups_two_prn_sets_and_two_bit_if(oracl
         ref.close()
 
 
-@pytest.mark.parametrize("n_search,win,shard", [(64, None, None), (37, (5, 2001), (1, 3)), (9, (1, 2), None), (18, None, None)])
+@pytest.mark.parametrize("n_search,win,shard", [(64, None, None), (37, (5, 2001), (1, 3)), (9, (1, 2), None), (18, None, None),
+                                                 (256, None, None)])
 def test_byte_phase_grid_pipeline_depths(oracle, monkeypatch, n_search, win, shard):
     """k_acq_mx<4> is one software pipeline per persistent workgroup: what cluster c + 1 and c + 2 need (block, wipe-off, block
     sums' codes, vectors) is made behind cluster c's stage barriers, results are written two stages late.  Launches whose
     workgroups walk 1, 2 (18 captures x 29 bins = 522 clusters on 256 CUs: two or three), 4-5 and 7-8 clusters -- the fill, the
-    short paths with missing pieces and the steady state -- with and without a search window, every triplet and key against
+    short paths with missing pieces and the steady state, and the bench's own launch (256 captures: 29 clusters per
+    workgroup) -- with and without a search window, every triplet and key against
     the direct 4-bit-dot-product kernel (GPSX_ACQ_ALGO=dot8, itself checked against the oracle), a sample against the oracle."""
     from stm32f4_sdr_gps_amd import capi, synth
     blocks = synth.cold_start_block(n_search, seed=31 + n_search, amp_scale=0.3)
