@@ -604,11 +604,13 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
         else
           (void)hipGetLastError();   // (no memory for the planes: the unsplit form runs; the error must not stick to its launch)
       }
+      bool keys_done = false;
+      prm.keys = shard_count == 1 ? d_keys : nullptr;   // (a shard's foreign units must read as zero: k_acq_keys sees to that)
       ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
                                        ctx->d_grid_mx_t, d_peaks, ctx->d_energy, mx_blocks, gpsx_acq_peaks_count(g), d_planes,
-                                       ctx->prop.multiProcessorCount);
+                                       ctx->prop.multiProcessorCount, &keys_done);
       LAUNCHCHK(ctx, "k_acq_mx");
-      if (d_keys) {
+      if (d_keys && !keys_done) {
         launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,
                         (int)unit_hi);
         LAUNCHCHK(ctx, "k_acq_keys");

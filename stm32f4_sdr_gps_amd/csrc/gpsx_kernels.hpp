@@ -55,6 +55,7 @@ struct AcqParams {
   const AcqJobRec *jobs;
   // outputs (optional ones may be null)
   gpsx_peak_t *peaks;
+  int64_t *keys;            // k_acq_mx: packed keys written next to the triplets (unsharded launches; null: k_acq_keys follows)
   gpsx_peak_t *per_ms;
   uint32_t *energy;
   uint16_t *cnt;
@@ -110,7 +111,7 @@ void launch_acq_finalize_from(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sum
                               gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from);
 const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
                           const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks,
-                          uint32_t *d_planes, int n_cus);
+                          uint32_t *d_planes, int n_cus, bool *keys_done);
 void launch_acq_vals_search(hipStream_t s, const AcqParams &prm, const uint16_t *d_vals, gpsx_peak_t *d_peaks, size_t n_peaks);
 void launch_acq_finalize(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
                          gpsx_peak_t *d_peaks);

@@ -1186,6 +1186,25 @@ __device__ __forceinline__ void mx_epilogue_store(int lane, int q0_tile, int t0,
 
 
 
+// max of a 64-bit value over the eight adjacent lanes of a PRN's bit shifts (quad permutes, then the mirrored half)
+__device__ __forceinline__ unsigned long long mx_max8_u64(unsigned long long v)
+{
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+#define MX_MAX8(ctrl)                                                                           \
+  {                                                                                             \
+    const u32 lo2 = (u32)__builtin_amdgcn_mov_dpp((int)lo, ctrl, 0xF, 0xF, true);               \
+    const u32 hi2 = (u32)__builtin_amdgcn_mov_dpp((int)hi, ctrl, 0xF, 0xF, true);               \
+    const bool g = hi2 > hi || (hi2 == hi && lo2 > lo);                                         \
+    lo = g ? lo2 : lo;                                                                          \
+    hi = g ? hi2 : hi;                                                                          \
+  }
+  MX_MAX8(0xB1)    // quad_perm [1, 0, 3, 2]
+  MX_MAX8(0x4E)    // quad_perm [2, 3, 0, 1]
+  MX_MAX8(0x141)   // row_half_mirror
+#undef MX_MAX8
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 constexpr int kMxSingle = 0, kMxWalk = 1, kMxStore = 2, kMxWalk16 = 3, kMxByte = 4, kMxSplit = 5;   // k_acq_mx's MODE
 
 }  // namespace
@@ -1506,6 +1525,20 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         pk[1] = make_uint2(t, t / (2u * kChips));                          //              sum, avr
       }
     }
+    // the packed key of (search, PRN, Doppler) -- (energy << 14) | (16383 - fine phase) of the best bit shift, what k_acq_keys
+    // makes of the triplets -- while they are in registers (unsharded launches: prm.keys is null otherwise)
+    if constexpr (!SPLIT) {
+      if (prm.keys && which == 0) {   // (wave-uniform: waves 0..3; a PRN's eight bit shifts are eight adjacent lanes)
+        unsigned long long key = 0;
+        if (b < prm.n_bits) {
+          const u32 max_val = k >> 11, phase = max_val ? 2047u - (k & 2047u) : 0u;
+          key = ((unsigned long long)max_val << 14) | (unsigned long long)(16383u - (8u * phase + (u32)b));
+        }
+        key = mx_max8_u64(key);
+        if (b == 0 && ((group_mask >> (p >> 3)) & 1u) && slot < prm.n_prn)
+          prm.keys[(size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp] = (int64_t)key;
+      }
+    }
   }
 }
 
@@ -1669,8 +1702,10 @@ __device__ __forceinline__ void mx_byte_fold(MxShared &sh, int slots, u32 group_
     const size_t idx = ((size_t)(search * prm.n_prn + slot) * prm.n_dopp + dopp) * prm.n_bits;
     uint2 *pk = reinterpret_cast<uint2 *>(&peaks[idx]);
     if (which == 0) {
-      const u32 max_val = k >> 11;
-      pk[0] = make_uint2(max_val, max_val ? 2047u - (k & 2047u) : 0u);   // gpsx_peak_t: max_val, phase
+      const u32 max_val = k >> 11, phase = max_val ? 2047u - (k & 2047u) : 0u;
+      pk[0] = make_uint2(max_val, phase);                                // gpsx_peak_t: max_val, phase
+      if (prm.keys)   // (the packed key k_acq_keys would make of it: one bit shift)
+        prm.keys[idx] = (int64_t)(((unsigned long long)max_val << 14) | (unsigned long long)(16383u - 8u * phase));
     } else {
       pk[1] = make_uint2(t, t / (2u * kChips));                          //              sum, avr
     }
@@ -1952,8 +1987,9 @@ long acq_mx_clusters(const AcqParams &prm)
 
 const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
                           const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks,
-                          uint32_t *d_planes, int n_cus)
+                          uint32_t *d_planes, int n_cus, bool *keys_done)
 {
+  *keys_done = false;   // true: every key of the launch was written by the kernels themselves (prm.keys)
   if (prm.unit_hi <= prm.unit_lo)
     return "";
   int c_lo, c_hi;
@@ -1975,6 +2011,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     if (prm.n_ms * 11573 > 65535)
       hipLaunchKernelGGL(k_acq_mx<kMxWalk>, dim3(n_wg), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
                          d_energy, d_flags);
+    *keys_done = prm.keys != nullptr;
     return "k_acq_mx<3>";
   }
   if (prm.n_bits == 1) {   // byte-phase grid: sample offsets 0 and 8, each started from its own block sums
@@ -1985,6 +2022,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     const int grid = bp.n_clusters < n_cus ? bp.n_clusters : n_cus - n_cus % n_sets;
     hipLaunchKernelGGL(k_acq_mx<kMxByte>, dim3((unsigned)grid), dim3(kMxThreads), 0, s, bp, c_lo, d_if, d_mx_a, d_mx_t, d_peaks,
                        (u32 *)nullptr, (u32 *)nullptr);
+    *keys_done = prm.keys != nullptr;
     return "k_acq_mx<4>";
   }
   if (d_planes && 2 * (c_hi - c_lo) <= n_cus) {
@@ -2026,6 +2064,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   }
   hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,
                      d_peaks, (u32 *)nullptr, (u32 *)nullptr);
+  *keys_done = prm.keys != nullptr;
   return "k_acq_mx<0>";
 }
 
