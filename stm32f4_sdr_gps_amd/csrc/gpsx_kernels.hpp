@@ -108,13 +108,14 @@ inline size_t acq_mx_energy_bytes(long clusters)   // per workgroup: 8 waves x 1
 // d_planes (may be null): 2 * n_peaks u32 of scratch; with it, single-block fine grids of at most n_cus / 2 clusters run as two
 // workgroups per cluster (sample offsets 0..7 / 8..15) that merge through the planes + k_acq_finalize ("k_acq_mx<5>")
 void launch_acq_finalize_from(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t first, size_t n_peaks,
-                              gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from);
+                              gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from,
+                              int64_t *d_keys_opt = nullptr);   // d_keys_opt (n_bits = 8): the packed keys as well
 const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_mx_a,
                           const uint32_t *d_mx_t, gpsx_peak_t *d_peaks, uint32_t *d_energy, bool block_parallel, size_t n_peaks,
                           uint32_t *d_planes, int n_cus, bool *keys_done);
 void launch_acq_vals_search(hipStream_t s, const AcqParams &prm, const uint16_t *d_vals, gpsx_peak_t *d_peaks, size_t n_peaks);
 void launch_acq_finalize(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                         gpsx_peak_t *d_peaks);
+                         gpsx_peak_t *d_peaks, int64_t *d_keys_opt = nullptr);
 
 // keys[unit pair] = max over bit shifts of (max_val << 14 | 16383 - (8 * phase + b)); 0 for pairs of other shards
 void launch_acq_keys(hipStream_t s, const gpsx_peak_t *d_peaks, int64_t *d_keys, int n_search, int n_prn, int n_groups,

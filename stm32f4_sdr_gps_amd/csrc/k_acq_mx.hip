@@ -2036,7 +2036,8 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     sp.n_planes = n_peaks;   // (the planes are all-zero between launches: k_acq_finalize puts back what it reads)
     hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * (c_hi - c_lo))), dim3(kMxThreads), 0, s, sp, c_lo, d_if,
                        d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);
-    launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks);
+    launch_acq_finalize(s, d_planes, d_planes + n_peaks, n_peaks, d_peaks, prm.n_bits == 8 ? prm.keys : nullptr);
+    *keys_done = prm.n_bits == 8 && prm.keys != nullptr;
     return "k_acq_mx<5>";
   }
   // One workgroup per cluster and CU: a launch is rounds of n_cus clusters, and a last round that fills at most half of the
@@ -2059,7 +2060,8 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
     hipLaunchKernelGGL(k_acq_mx<kMxSplit>, dim3((unsigned)(sp.split_segs * tail)), dim3(kMxThreads), 0, s, sp, c_tail, d_if,
                        d_mx_a, d_mx_t, d_peaks, d_planes, (u32 *)nullptr);
     launch_acq_finalize_from(s, d_planes, d_planes + n_peaks, first, n_peaks, d_peaks, prm.n_prn, prm.n_dopp, prm.n_bits, n_sets,
-                             c_tail);
+                             c_tail, prm.n_bits == 8 ? prm.keys : nullptr);
+    *keys_done = prm.n_bits == 8 && prm.keys != nullptr;   // (the full rounds' workgroups wrote theirs in their folds)
     return "k_acq_mx<0>";
   }
   hipLaunchKernelGGL(k_acq_mx<kMxSingle>, dim3((unsigned)(c_hi - c_lo)), dim3(kMxThreads), 0, s, prm, c_lo, d_if, d_mx_a, d_mx_t,

@@ -512,10 +512,34 @@ __global__ __launch_bounds__(kThreads, MODE == kPolyMulti ? 2 : 3) void k_acq_po
 // (packed key, sum) planes -> gpsx_peak_t
 // The planes are all-zero between launches (allocated so, and every entry read here is put back to zero): no memset in front of
 // the kernels that accumulate into them.
-__global__ void k_acq_finalize(u32 *__restrict__ keyacc, u32 *__restrict__ sumacc, size_t n, gpsx_peak_t *__restrict__ peaks)
+// keys_opt (fine grids: eight bit shifts per (search, PRN, Doppler) = eight adjacent threads, entry idx / 8): the packed key
+// k_acq_keys would make of the triplets, while they are in registers
+__device__ __forceinline__ void finalize_key8(const gpsx_peak_t &pk, size_t idx, int64_t *__restrict__ keys)
+{
+  const u32 b = (u32)(idx & 7);
+  unsigned long long key = ((unsigned long long)pk.max_val << 14) | (unsigned long long)(16383u - (8u * pk.phase + b));
+  u32 lo = (u32)key, hi = (u32)(key >> 32);
+#define GPSX_MAX8(ctrl)                                                                         \
+  {                                                                                             \
+    const u32 lo2 = (u32)__builtin_amdgcn_mov_dpp((int)lo, ctrl, 0xF, 0xF, true);               \
+    const u32 hi2 = (u32)__builtin_amdgcn_mov_dpp((int)hi, ctrl, 0xF, 0xF, true);               \
+    const bool g = hi2 > hi || (hi2 == hi && lo2 > lo);                                         \
+    lo = g ? lo2 : lo;                                                                          \
+    hi = g ? hi2 : hi;                                                                          \
+  }
+  GPSX_MAX8(0xB1)    // quad_perm [1, 0, 3, 2]
+  GPSX_MAX8(0x4E)    // quad_perm [2, 3, 0, 1]
+  GPSX_MAX8(0x141)   // row_half_mirror
+#undef GPSX_MAX8
+  if (b == 0)
+    keys[idx >> 3] = (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ void k_acq_finalize(u32 *__restrict__ keyacc, u32 *__restrict__ sumacc, size_t n, gpsx_peak_t *__restrict__ peaks,
+                               int64_t *__restrict__ keys_opt)
 {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n)
+  if (idx >= n)   // (n is a multiple of eight wherever keys_opt is given: whole groups leave)
     return;
   const u32 k = keyacc[idx], t = sumacc[idx];
   keyacc[idx] = 0u;
@@ -526,13 +550,16 @@ __global__ void k_acq_finalize(u32 *__restrict__ keyacc, u32 *__restrict__ sumac
   pk.sum = t;
   pk.avr = t / (2u * kChips);
   peaks[idx] = pk;
+  if (keys_opt)
+    finalize_key8(pk, idx, keys_opt);
 }
 
 // The same for the peaks of clusters >= cluster_from only (a launch whose last, partly filled round went to the split form:
 // the full rounds' workgroups wrote their triplets themselves).  Peak idx = ((search n_prn + prn) n_dopp + dopp) n_bits + b;
 // cluster = (search n_dopp + dopp) n_sets + prn / 32.
 __global__ void k_acq_finalize_from(u32 *__restrict__ keyacc, u32 *__restrict__ sumacc, size_t first, size_t n,
-                                    gpsx_peak_t *__restrict__ peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from)
+                                    gpsx_peak_t *__restrict__ peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from,
+                                    int64_t *__restrict__ keys_opt)
 {
   const size_t idx = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n)
@@ -552,6 +579,8 @@ __global__ void k_acq_finalize_from(u32 *__restrict__ keyacc, u32 *__restrict__ 
   pk.sum = t;
   pk.avr = t / (2u * kChips);
   peaks[idx] = pk;
+  if (keys_opt)   // (n_bits = 8 there: a cluster holds whole groups of eight)
+    finalize_key8(pk, idx, keys_opt);
 }
 
 // Multi-block searches handled block-parallel (k_acq_poly<.., kPolyStore> wrote every block's magnitudes): sum over the
@@ -619,19 +648,20 @@ void launch_acq_vals_search(hipStream_t s, const AcqParams &prm, const uint16_t 
 }
 
 void launch_acq_finalize(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t n_peaks,
-                         gpsx_peak_t *d_peaks)
+                         gpsx_peak_t *d_peaks, int64_t *d_keys_opt)
 {
   hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
-                     d_peaks);
+                     d_peaks, d_keys_opt);
 }
 
 void launch_acq_finalize_from(hipStream_t s, uint32_t *d_keyacc, uint32_t *d_sumacc, size_t first, size_t n_peaks,
-                              gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from)
+                              gpsx_peak_t *d_peaks, int n_prn, int n_dopp, int n_bits, int n_sets, int cluster_from,
+                              int64_t *d_keys_opt)
 {
   if (first >= n_peaks)
     return;
   hipLaunchKernelGGL(k_acq_finalize_from, dim3((unsigned)((n_peaks - first + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc,
-                     first, n_peaks, d_peaks, n_prn, n_dopp, n_bits, n_sets, cluster_from);
+                     first, n_peaks, d_peaks, n_prn, n_dopp, n_bits, n_sets, cluster_from, d_keys_opt);
 }
 
 const char *launch_acq_poly(hipStream_t s, long local_units, const AcqParams &prm, const uint8_t *d_if, const uint32_t *d_cw8,
@@ -683,7 +713,7 @@ const char *launch_acq_poly(hipStream_t s, long local_units, const AcqParams &pr
     hipLaunchKernelGGL((k_acq_poly<kAcqGroup, 8, kPolySingle>), dim3((unsigned)(wg16 * 2)), dim3(kThreads), 0, s, prm, d_if, d_cw8,
                        d_chipbits, d_keyacc, d_sumacc, d_peaks, (u32 *)nullptr);
   hipLaunchKernelGGL(k_acq_finalize, dim3((unsigned)((n_peaks + 255) / 256)), dim3(256), 0, s, d_keyacc, d_sumacc, n_peaks,
-                     d_peaks);
+                     d_peaks, (int64_t *)nullptr);
   return seg == 4 ? "k_acq_poly<8,4,0>" : "k_acq_poly<8,8,0>";
 }
 
