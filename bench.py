@@ -461,9 +461,12 @@ def main():
             gn = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=-7000, dopp_step_hz=500,
                                n_dopp=29, phase_mode=capi.PHASES_BYTE)
             with torch.cuda.stream(stream):
+                native_keys = torch.zeros((n_search, N_PRN, 29), dtype=torch.int64, device=dev)   # (29 bins: its own table)
+                assert d_peaks.numel() * 4 >= n_search * N_PRN * 29 * capi.PEAK_DTYPE.itemsize
+
                 def native_step():
                     rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(gn), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
-                                                   key_bufs[0].data_ptr(), None, None, None)
+                                                   native_keys.data_ptr(), None, None, None)
                     if rc != 0:
                         raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
                 for _ in range(3):
