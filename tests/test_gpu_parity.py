@@ -347,6 +347,43 @@ def test_byte_phase_grid_persistent_workgroups_two_prn_sets_and_two_bit_if(oracl
         ref.close()
 
 
+def test_byte_phase_grid_pipeline_random_descriptors(monkeypatch):
+    """Seeded sweep of byte-phase grids big enough for the pipeline to run several clusters per workgroup: PRN lists of 33..210
+    codes (two to seven 32-slot sets: the grid of persistent workgroups is then a multiple of the set count), arbitrary Doppler
+    grids, windows, shards, strides between the searches' blocks, 1-bit and 2-bit captures -- every triplet and key against the
+    direct 4-bit-dot-product kernel."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    rng = np.random.default_rng(4242)
+    e = capi.Engine(0)
+    monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
+    ref = capi.Engine(0)
+    monkeypatch.delenv("GPSX_ACQ_ALGO")
+    try:
+        for trial in range(8):
+            n_prn = int(rng.integers(33, 211))
+            prns = rng.permutation(np.arange(1, 211))[:n_prn].astype(np.uint8)
+            n_dopp = int(rng.integers(3, 12))
+            n_search = int(rng.integers(12, 40))
+            stride = int(rng.integers(0, 2))
+            two = bool(trial & 1)
+            n_blocks = (n_search - 1) * stride + 1
+            blocks = synth.cold_start_block(n_blocks, seed=300 + trial, amp_scale=0.3, two_bit=two)
+            a, b = sorted(int(x) for x in rng.integers(0, 2047, 2))
+            world = int(rng.integers(1, 4))
+            kw = dict(n_search=n_search, search_stride_blocks=stride, dopp_min_hz=int(rng.integers(-7000, 3000)),
+                      dopp_step_hz=int(rng.integers(1, 900)), n_dopp=n_dopp, phase_mode=capi.PHASES_BYTE, win=(a, b),
+                      shard=(int(rng.integers(world)), world))
+            for eng_ in (e, ref):
+                eng_.set_if_format(capi.IF_2BIT_SM if two else capi.IF_1BIT)
+            pk, keys = e.acq_grid(blocks, prns, **kw)
+            assert e.lib.gpsx_last_kernel(e.h) == b"k_acq_mx<4>", trial
+            want_pk, want_keys = ref.acq_grid(blocks, prns, **kw)
+            assert np.array_equal(pk, want_pk) and np.array_equal(keys, want_keys), (trial, kw, n_prn, two)
+    finally:
+        e.close()
+        ref.close()
+
+
 @pytest.mark.parametrize("n_search,win,shard", [(64, None, None), (37, (5, 2001), (1, 3)), (9, (1, 2), None), (18, None, None),
                                                  (256, None, None)])
 def test_byte_phase_grid_pipeline_depths(oracle, monkeypatch, n_search, win, shard):
