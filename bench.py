@@ -490,6 +490,43 @@ def main():
             native = {"error": repr(exc)}
             print(f"bench.py: native-grid leg failed: {exc!r}", file=sys.stderr, flush=True)
 
+    # The N = 1 point of the series `--gpus N` (N > 1) runs: BASELINE.json configs[3], 10 ms non-coherent integration, here on
+    # ONE GPU, unsharded, no collective -- what the multi-GPU lines' `value` is to be divided by (N x this), since this script's
+    # own N = 1 default is configs[2].  Search s integrates blocks s .. s + 9 of the resident captures (cyclically extended).
+    ten_block = None
+    if world == 1 and n_ms == 1 and not args.no_native:
+        try:
+            with torch.cuda.stream(stream):
+                per_block = dev_blocks.reshape(n_search, -1)
+                d_if10 = torch.from_numpy(np.concatenate([per_block, per_block[:9]]).reshape(-1)).to(dev)
+                g10 = eng.grid_desc(prns, n_search=n_search, n_ms=10, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+                                    dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046))
+
+                def ten_step():
+                    rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g10), d_if10.data_ptr(), n_search + 9, d_peaks.data_ptr(),
+                                                   key_bufs[0].data_ptr(), None, None, None)
+                    if rc != 0:
+                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
+                for _ in range(2):
+                    ten_step()
+                torch.cuda.synchronize()
+                t0e, t1e = eng.event(), eng.event()
+                eng.record(t0e)
+                for _ in range(5):
+                    ten_step()
+                eng.record(t1e)
+                torch.cuda.synchronize()
+                ten_ms = eng.elapsed_ms(t0e, t1e) / 5
+            ten_block = {"workload": "BASELINE.json configs[3] on one GPU: %d searches x 10 blocks, 32 PRN x 21 Doppler x 16368 phases, "
+                                     "unsharded, no collective" % n_search,
+                         "value": n_search * 10 * HYP_PER_SEARCH / (ten_ms * 1e-3), "unit": "hypotheses/s (per 1 ms block)",
+                         "ms_per_step": ten_ms, "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
+                         "note": "the N = 1 point of the `--gpus N` series (whose lines are configs[3], weak scaling): divide their "
+                                 "`value` by N x this one"}
+        except Exception as exc:   # a secondary leg must not take the headline line with it
+            ten_block = {"error": repr(exc)}
+            print(f"bench.py: ten-block leg failed: {exc!r}", file=sys.stderr, flush=True)
+
     # PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
     # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
     # rotation through gpsx_acq_grid_async, so a call's transfers overlap the others' sweeps -- what a host streaming
@@ -780,6 +817,8 @@ def main():
             line["per_gpu_unsharded"] = local_ref
         if native is not None:
             line["native_grid"] = native
+        if ten_block is not None:
+            line["configs3_one_gpu"] = ten_block
         if tracking is not None:
             line["tracking"] = tracking
         if not args.no_cpu_baseline and world == 1:
