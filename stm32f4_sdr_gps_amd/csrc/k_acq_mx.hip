@@ -448,6 +448,54 @@ __device__ __forceinline__ void mx_pass_step_inplace(lds_cu32 *wi, lds_cu32 *wq,
     mx_pass_step_inplace<S + 1, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
 }
 
+// The byte-phase form's two passes of a stage (low vector at 2^0, high vector at 2^3) as ONE walk over the anti-diagonals: the
+// A fragments are fetched once instead of twice, there is no gap between the passes, and every fragment is requested into the
+// registers of its predecessor as soon as that one's MFMAs have been issued -- under the twelve MFMAs of the other three streams.
+template <int S, int NT>
+__device__ __forceinline__ void mx_pass2_step(lds_cu32 *const (&w)[4], const v4i *ca, v4i (&a)[16], v4i (&f)[4], v16f (&acc)[2][NT])
+{
+  constexpr int kSteps = 16 + NT - 1;
+  constexpr bool more = S + 1 < kSteps;
+  if constexpr (more && S + 1 < 16)
+    a[S + 1] = ca[(S + 1) * 64];                           // chips_a[S + 1][h][n]
+  constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < NT - 1 ? S : NT - 1;
+#pragma unroll
+  for (int v = 0; v < 4; v++) {   // I low, Q low, I high, Q high
+#pragma unroll
+    for (int j = j_lo; j <= j_hi; j++)
+      acc[v & 1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(f[v]), acc[v & 1][j], 4, 4, 0, kScaleA, 0,
+                                                                      v < 2 ? kScaleOne : kScaleEight);
+    if constexpr (more)
+      f[v] = lds_frag(w[v], 8 * (S + 1));
+  }
+  if constexpr (more) {
+    if constexpr (S + 1 < 16)
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                 // DS read: the A fragment
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, j_hi - j_lo + 1, 0);   // MFMAs of one stream
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 // DS reads: its next fragment
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (more)
+    mx_pass2_step<S + 1, NT>(w, ca, a, f, acc);
+}
+template <int NT>
+__device__ __forceinline__ void mx_pass2(const MxShared &sh, int lane, int q0_tile, v16f (&acc)[2][NT], const u32 *e8_low,
+                                         const u32 *e8_high)
+{
+  const int n = lane & 31, h = lane >> 5;
+  const int off = (n & 7) * kCopyDwords + 4 * (q0_tile + h) + (n >> 3);
+  lds_cu32 *const w[4] = {lds_opaque(e8_low + off), lds_opaque(e8_low + 8 * kCopyDwords + off), lds_opaque(e8_high + off),
+                          lds_opaque(e8_high + 8 * kCopyDwords + off)};
+  const v4i *ca = &sh.chips_a[0][h][n];
+  v4i a[16];
+  v4i f[4] = {lds_frag(w[0], 0), lds_frag(w[1], 0), lds_frag(w[2], 0), lds_frag(w[3], 0)};
+  a[0] = ca[0];
+  mx_pass2_step<0, NT>(w, ca, a, f, acc);
+}
+
 // AHEAD = false (the walk forms): mx_pass_step_inplace
 // NT = q-tiles of this call (q0_tile + 2 j, j < NT): four everywhere but in the byte-phase form, which works in tile pairs
 template <bool AHEAD, int NT>
@@ -1830,7 +1878,6 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
     mx_byte_vector_pair(base0, &sh.e8[0][0][0][0], &sh.e8[1][0][0][0], tid);
     mx_block_commit(sh, b1, prm.if_format, tid);
   }
-  const v4i a_corr = v4i{0, 0, 0, 0};   // (the fine grid's extra K step: not in this form)
   u32 kq[kMxTiles];   // 2047 - (even byte offset of the lane's chip offset in tile j): the low field of its search keys
 #pragma unroll
   for (int j = 0; j < kMxTiles; j++)
@@ -1933,8 +1980,7 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
         } else {
           mx_init_acc(ones, lane, q0_tile, acc, prm.win_start, prm.win_stop);
         }
-        mx_pass<true>(sh, 0, lane, q0_tile, acc, kScaleOne, a_corr, false, va);
-        mx_pass<true>(sh, 1, lane, q0_tile, acc, kScaleEight, a_corr, false, vb);
+        mx_pass2(sh, lane, q0_tile, acc, va, vb);
       } else {
         mx_epilogue_single(sh, lane, kq, 8 * o, acc, false, false, cc & 1 ? kSlotsOdd : kSlotsEven);
       }
