@@ -1771,6 +1771,8 @@ __device__ __forceinline__ void mx_byte_pipe(MxShared &sh, const AcqParams &prm,
   const int n_sets = (prm.n_groups + 3) / 4;
   const int stride = (int)gridDim.x, first = cluster_lo + (int)blockIdx.x;
   const int n_my = (prm.n_clusters - (int)blockIdx.x + stride - 1) / stride;   // clusters first, first + stride, ...: >= 1
+  if (n_my <= 0)                                         // (a grid larger than the launch's clusters: the launcher never makes one)
+    return;
   const int set = first % n_sets;                        // (the launcher's grid is a multiple of n_sets: one PRN set per workgroup)
   const size_t block_bytes = prm.if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : kBytes;
 
