@@ -278,9 +278,24 @@ int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_tr
  *     bit 4  the false-lock detector moved the carrier (tracking.c:309-326)
  *     bit 5  the bit edge inside the 20 ms grid was located (nav_data.c:145-218): accurate_swap_time =
  *            (tick - 3 + (bit 6 ? 2 : 1)) % 20 -- what the subframe time stamp is made of
+ *     bit 7  the channel was served this millisecond (always set under GPSX_SCHED_EVERY_MS; under GPSX_SCHED_MUX17 the
+ *            bytes of a channel's unserved milliseconds are 0)
  * -- what the word layer (gps_nav_data_words_detection, one call per completed bit; gps_tracking_words_batch in
- * include/gpsx_compat.h does it for a whole launch) needs.  Serving schedule: every channel
- * every millisecond, index = tick & 3 (project_single_sat/main.c:96-109, as gps_tracking_process_batch).
+ * include/gpsx_compat.h does it for a whole launch) needs.
+ * Serving schedule (gpsx_loop_set_schedule), both the reference's own:
+ *   GPSX_SCHED_EVERY_MS (default)  every channel every millisecond, index = tick & 3 (project_single_sat/main.c:96-109, as
+ *       gps_tracking_process_batch).  The 4 ms groups then sit still on the 20 ms bit grid, and the reference's bit-edge
+ *       locator -- it looks at groups with the sign change between index 1 and 2 only, nav_data.c:131-137 -- resolves the
+ *       edge for the channels whose bit edges happen to fall there: one in four.
+ *   GPSX_SCHED_MUX17  project_main's receiver: four channels share one correlator in a 17 ms cycle (PM/main.c:139-152).
+ *       Channel c is slot (c & 3) of receiver (c >> 2); it is served on the ticks t with (t % 17) / 4 == slot, with
+ *       index = (t % 17) % 4; t % 17 == 16 is the idle millisecond (the reference's navigation slot).  The milliseconds a
+ *       channel was not served are made up in its carrier NCO when it is served again (gps_rewind_if_phase with the elapsed
+ *       ticks - 1, PM/GPS/tracking.c:102-113, from prev_track_timestamp); code phase and loop filters stand still, as in the
+ *       reference.  Every 17 ms the group start moves by 17 mod 20 over the bit grid, so every channel gets its bit edge
+ *       located, hence accurate_swap_time, hence subframe time stamps and pseudoranges -- the complete receiver on the
+ *       device loop (tests/test_gpu_track_mux.py: the reference's multiplexed traces, tests/test_gpu_pvt_chain.py: IF
+ *       samples to position).  Hand channels over (gpsx_loop_state_from_channel) on a tick with t % 17 == 0.
  * Differences from the host mode, all stated: the arctangents are the device's (results agree with glibc's to the last
  * bit or the one before it: the stated tolerance of the closed loop is |d code_phase_fine| <= 0.01 sample,
  * |d if_freq_offset_hz| <= 0.5 Hz against the reference's traces, tests/test_gpu_track_loop.py); the false-lock jump
@@ -311,7 +326,9 @@ typedef struct {
   uint8_t  right_period_cnt, old_reminder, accurate_swap_time, accurate_swap_ok;
   uint8_t  last_bit_pos_cnt, last_bit_neg_cnt;
   uint8_t  inv_polarity_flag;                  /* written by the HOST's word layer when it finds inverted preambles */
-} gpsx_loop_state_t;                           /* 96 bytes */
+  uint32_t prev_track_timestamp;               /* gps_tracking_t: tick the channel was last served on */
+  uint32_t snr_i_latch, snr_q_latch;           /* the sums snr_value was last made of (q = 0: snr_value stands as it is) */
+} gpsx_loop_state_t;                           /* 108 bytes */
 
 typedef struct {                               /* optional per-millisecond record, for tests and inspection */
   int16_t  iq[6];                              /* IE, QE, IP, QP, IL, QL of this millisecond */
@@ -328,6 +345,11 @@ int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gp
  * runs, copies the flags (and trace records, if asked for) out, waits.  The states stay on the device. */
 int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
                     uint32_t first_tick_ms, uint8_t *flags, gpsx_loop_trace_t *trace_opt);
+
+/* Serving schedule of this context's gpsx_track_loop* launches from now on (above). */
+#define GPSX_SCHED_EVERY_MS 0
+#define GPSX_SCHED_MUX17    1
+int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule);
 
 /* The host's word layer found (or gave up) inverted data polarity on n channels: d_state[channels[i]].inv_polarity_flag =
  * values[i] (host arrays; enqueued on the context's stream in front of the next launch). */

@@ -1063,6 +1063,16 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
 
 /* ---- the tracking loops on the device ---------------------------------------------------------------------------------- */
 
+int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  if (schedule != GPSX_SCHED_EVERY_MS && schedule != GPSX_SCHED_MUX17)
+    return fail(ctx, GPSX_EINVAL, "unknown serving schedule");
+  ctx->loop_schedule = schedule;
+  return GPSX_OK;
+}
+
 int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
                         uint32_t first_tick_ms, uint8_t *d_flags, gpsx_loop_trace_t *d_trace_opt)
 {
@@ -1071,8 +1081,8 @@ int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gp
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
   launch_track_loop(ctx->stream, static_cast<const uint8_t *>(d_if_blocks), (uint32_t)blk_bytes, n_blocks, ctx->if_format,
-                    ctx->if_hz, d_state, n_ch, first_tick_ms, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace_opt,
-                    ctx->d_bad_prn + 1);
+                    ctx->if_hz, d_state, n_ch, first_tick_ms, ctx->loop_schedule, ctx->d_bits_all, ctx->d_trk_rep, d_flags,
+                    d_trace_opt, ctx->d_bad_prn + 1);
   LAUNCHCHK(ctx, "k_track_loop");
   ctx->last_kernel = "k_track_loop";
   return GPSX_OK;
@@ -1099,7 +1109,7 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
   }
   ctx->h_bad_prn[0] = 0;   // (flag 0: this entry point waits for its kernel, as gpsx_track_epl_batch does)
   launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick_ms,
-                    ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, ctx->d_bad_prn);
+                    ctx->loop_schedule, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, ctx->d_bad_prn);
   LAUNCHCHK(ctx, "k_track_loop");
   ctx->last_kernel = "k_track_loop";
   HIPCHK(ctx, hipMemcpyAsync(flags, d_flags, n_rec, hipMemcpyDeviceToHost, ctx->stream));
@@ -1139,7 +1149,7 @@ int gpsx_loop_reset_code_filter(gpsx_ctx *ctx, gpsx_loop_state_t *d_state, int n
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   static_assert(offsetof(gpsx_loop_state_t, code_phase_fine_filt) == offsetof(gpsx_loop_state_t, code_filt_cnt) + 2,
                 "the two window fields are adjacent");
-  // six bytes per state: a strided fill (rows of 96 B, 6 B wide)
+  // six bytes per state: a strided fill (rows of sizeof(gpsx_loop_state_t), 6 B wide)
   HIPCHK(ctx, hipMemset2DAsync(reinterpret_cast<uint8_t *>(d_state) + offsetof(gpsx_loop_state_t, code_filt_cnt), sizeof(gpsx_loop_state_t),
                                0, 6, (size_t)n_ch, ctx->stream));
   return GPSX_OK;

@@ -2,6 +2,7 @@
 // Host marshalling only: every function forwards to a gpsx_* entry point that runs HIP kernels.
 #include "../../include/gpsx_compat.h"
 
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -174,7 +175,7 @@ void gps_rewind_if_phase(gps_tracking_t *trk_channel, uint8_t steps)
 
 
 // ---- channel record <-> device loop state (include/gpsx.h gpsx_loop_state_t) ------------------------------------------------
-static_assert(sizeof(gpsx_loop_state_t) == 96 && offsetof(gpsx_loop_state_t, pll_check_buf) == 32 &&
+static_assert(sizeof(gpsx_loop_state_t) == 108 && offsetof(gpsx_loop_state_t, pll_check_buf) == 32 &&
                   offsetof(gpsx_loop_state_t, slot_ip) == 80 && sizeof(gpsx_loop_trace_t) == 24,
               "gpsx_loop_state_t layout");
 
@@ -218,6 +219,7 @@ void gpsx_loop_state_from_channel(const gps_ch_t *ch, uint32_t rng_seed, gpsx_lo
   s.last_bit_pos_cnt = n.last_bit_pos_cnt;
   s.last_bit_neg_cnt = n.last_bit_neg_cnt;
   s.inv_polarity_flag = n.inv_polarity_flag;
+  s.prev_track_timestamp = t.prev_track_timestamp;
   *out = s;
 }
 
@@ -241,7 +243,9 @@ void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch)
   t.pll_bad_state_cnt = s.pll_bad_state_cnt;
   t.i_part_summ = s.i_part_summ;
   t.q_part_summ = s.q_part_summ;
-  t.snr_value = s.snr_value;
+  // snr_value: the device's logarithm agrees with the C library's on 99.85 % of the ratios (csrc/gpsx_libm.hpp); the record gets
+  // the C library's, from the sums the device latched when it made the estimate (tracking.c:158-162)
+  t.snr_value = s.snr_q_latch ? 10.0f * log10f((float)s.snr_i_latch / (float)s.snr_q_latch) : s.snr_value;
   t.snr_summ_cnt = s.snr_summ_cnt;
   t.code_filt_cnt = s.code_filt_cnt;
   t.code_phase_fine_filt = s.code_phase_fine_filt;
@@ -253,6 +257,9 @@ void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch)
   n.accurate_swap_ok = s.accurate_swap_ok;
   n.last_bit_pos_cnt = s.last_bit_pos_cnt;
   n.last_bit_neg_cnt = s.last_bit_neg_cnt;
+  // the tick the device last served the channel on: a host that takes the channel back into gps_tracking_process sees the
+  // elapsed time the reference would (tracking.c:102-113), after any number of device milliseconds
+  t.prev_track_timestamp = s.prev_track_timestamp;
 }
 
 }  // extern "C"

@@ -1676,10 +1676,12 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
       t_tick = first_tick + (uint32_t)ms;
       for (int c = lo; c < hi; c++) {
         const uint8_t v = f[c];
-        if ((v & (2 | 8 | 32)) == 0)
+        if ((v & 128) == 0)   // not served this millisecond (GPSX_SCHED_MUX17)
           continue;
         gps_nav_data_t &n = channel[c].nav_data;
         n.period_sync_ok_flag = (v & 8) ? 1 : 0;
+        if ((v & (2 | 32)) == 0)
+          continue;
         if (v & 2) {
           const uint8_t before = n.inv_polarity_flag;
           gps_nav_data_words_detection(&channel[c], (uint8_t)((v >> 2) & 1));

@@ -18,6 +18,7 @@
 
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
+#include "gpsx_libm.hpp"
 #include "gpsx_track_wave.hpp"
 
 namespace gpsx {
@@ -31,6 +32,7 @@ constexpr float kFll1C1 = 200.0f, kFll1C2 = 2000.0f;
 constexpr int kPllBadThreshold = 80;                        // tracking.c:14
 constexpr int kSnrLength = 200;                             // tracking.c:26
 constexpr int kSearchStepHz = 500;                          // ACQ_SEARCH_STEP_HZ
+constexpr int kSlotMs = 4, kSlots = 4;                      // TRACKING_CH_LENGTH, GPS_SAT_CNT (PM/config.h): the 17 ms multiplex
 
 template <int K>
 __device__ __forceinline__ u32 quad_get(u32 v)   // lane k of this lane's quad
@@ -85,13 +87,14 @@ __device__ __forceinline__ void loop_dll(gpsx_loop_state_t &s, int IE, int QE, i
   s.dll_code_err = err;
 }
 
-// gps_tracking_pll (index 0 only has an effect).  The reference's atan2f / atan2 -> the device's double-precision atan2,
-// rounded once: the correctly rounded float in all but ~1 case in 2^29, where glibc's own atan2f is good to an ulp.
+// gps_tracking_pll (index 0 only has an effect).  The reference's atan2f is glibc's float one, restated operation by
+// operation (gpsx_libm.hpp); its double-precision atan2 on the other branch -> the device's, whose result rounded to float
+// after the division is the reference's in all but ~1 case in 2^29.
 __device__ __forceinline__ void loop_pll(gpsx_loop_state_t &s, int IP, int QP)
 {
   float phase_err;   // in units of pi
   if (IP > 0)
-    phase_err = (float)((double)(float)atan2((double)QP, (double)IP) / kPiD);
+    phase_err = (float)((double)gpsx_libm::atan2f_fdlibm((float)QP, (float)IP) / kPiD);
   else
     phase_err = (float)(atan2((double)(float)-QP, (double)(float)-IP) / kPiD);
   float step = phase_err - s.pll_code_err;
@@ -158,7 +161,7 @@ __device__ __forceinline__ float atan_ratio(int q, int i)   // the reference's (
 {
   if (i == 0)
     return (float)(kPiD / 2);
-  return (float)atan((double)((float)q / (float)i));
+  return gpsx_libm::atanf_fdlibm((float)q / (float)i);
 }
 
 // gps_tracking_fll behind its call of the check
@@ -302,10 +305,14 @@ __device__ __forceinline__ void loop_snr(gpsx_loop_state_t &s, int IP, int QP)
   if (s.snr_summ_cnt > kSnrLength) {
     if (s.q_part_summ == 0) {
       s.snr_value = 1.0f;
+      s.snr_i_latch = 0;
+      s.snr_q_latch = 0;
       return;   // sic: the sums are not cleared on this path (tracking.c:152-156)
     }
     const float ratio = (float)s.i_part_summ / (float)s.q_part_summ;
-    s.snr_value = 10.0f * log10f(ratio);
+    s.snr_value = s.i_part_summ ? 10.0f * gpsx_libm::log10f_near(ratio) : 10.0f * log10f(ratio);   // (log10f(0) = -inf)
+    s.snr_i_latch = s.i_part_summ;   // what the estimate was made of: gpsx_loop_state_to_channel takes the host's logarithm
+    s.snr_q_latch = s.q_part_summ;
     s.snr_summ_cnt = 0;
     s.i_part_summ = 0;
     s.q_part_summ = 0;
@@ -314,6 +321,12 @@ __device__ __forceinline__ void loop_snr(gpsx_loop_state_t &s, int IP, int QP)
 
 }  // namespace
 
+// Which channels a wave holds.  GPSX_SCHED_EVERY_MS: cpw consecutive channels.  GPSX_SCHED_MUX17: the reference's receiver is
+// four channels sharing one correlator in a 17 ms cycle (PM/main.c:139-152) -- channel c is slot (c & 3) of receiver c >> 2
+// and is served on the ticks t with (t % 17) / 4 == slot, t % 17 != 16.  A wave then holds channels of ONE slot (wave w of the
+// workgroup: slot w of the workgroup's cpw receivers), so that "is this channel served this millisecond" is wave-uniform: three
+// of a workgroup's four waves skip a millisecond's correlators whole, all four skip the idle slot.
+template <bool MUX>
 __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ if_blocks, u32 block_stride, int n_blocks,
                                                     int if_format, int if_hz, gpsx_loop_state_t *__restrict__ st, int n_ch, int cpw,
                                                     u32 first_tick, const u32 *__restrict__ chipbits_all,
@@ -323,12 +336,19 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
   __shared__ u32 s_x[2][512];        // this and the next millisecond's sign plane: one barrier per millisecond
   __shared__ uint2 s_carrier[4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  const int ch0 = ((int)blockIdx.x * 4 + wave) * cpw;
-  const int n_here = ch0 < n_ch ? min(cpw, n_ch - ch0) : 0;   // (0: an idle wave of the last workgroup still stages blocks)
   const int c_l = lane >> 2, k_l = lane & 3;
+  int n_here, ch_l;                  // channels of this wave (0: an idle wave of the last workgroup still stages blocks)
+  if (MUX) {
+    const int first = (int)blockIdx.x * 4 * cpw + wave;   // the wave's channels: first, first + 4, ...
+    n_here = first < n_ch ? min(cpw, (n_ch - first + 3) >> 2) : 0;
+    ch_l = first + 4 * (c_l < n_here ? c_l : 0);
+  } else {
+    const int ch0 = ((int)blockIdx.x * 4 + wave) * cpw;
+    n_here = ch0 < n_ch ? min(cpw, n_ch - ch0) : 0;
+    ch_l = ch0 + (c_l < n_here ? c_l : 0);
+  }
   const bool in_wave = c_l < n_here;
   const bool mine = in_wave && k_l < 3;
-  const int ch_l = ch0 + (in_wave ? c_l : 0);
   gpsx_loop_state_t s = {};
   int prn = 0;
   if (n_here) {
@@ -345,7 +365,34 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
     if (!n_here)
       continue;
     const u32 now = first_tick + (u32)ms;
-    const int index = (int)(now & 3u);
+    int index = (int)(now & 3u);
+    if (MUX) {
+      const u32 big = now % (u32)(kSlotMs * kSlots + 1);   // PM/main.c:139-152
+      if (big == (u32)(kSlotMs * kSlots) || (int)(big / (u32)kSlotMs) != wave) {
+        // not this wave's slot (or the cycle's idle millisecond): nothing of the channel moves
+        if (in_wave && k_l == 0) {
+          flags[(size_t)ms * n_ch + ch_l] = 0;
+          if (trace) {
+            gpsx_loop_trace_t t = {};
+            t.code_phase_fine = s.code_phase_fine;
+            t.if_freq_offset_hz = s.if_freq_offset_hz;
+            t.if_freq_accum = s.if_freq_accum;
+            trace[(size_t)ms * n_ch + ch_l] = t;
+          }
+        }
+        continue;
+      }
+      index = (int)(big % (u32)kSlotMs);
+      // tracking.c:102-113: the carrier NCO kept running while the other channels were served
+      u32 elapsed = now - s.prev_track_timestamp;
+      if (elapsed > 50u)   // "startup check"
+        elapsed = 1u;
+      if (elapsed != 1u) {
+        const u64 adv = (u64)nco_step_per_sample((float)if_hz + s.if_freq_offset_hz) * (u64)kSamples * (u64)((elapsed - 1u) & 0xFFu);
+        s.if_freq_accum += (u32)adv;   // gps_rewind_if_phase, gps_misc.c:196-204
+      }
+    }
+    s.prev_track_timestamp = now;
     const int fine = (int)(int16_t)(int)s.code_phase_fine;
     const u32 step = nco_step_per_word((float)if_hz + s.if_freq_offset_hz);
     const u32 iq = trkwave::wave_epl(sx, s_carrier, lane, n_here, mine, prn, fine, step, s.if_freq_accum, chipbits_all, rep_all);
@@ -361,7 +408,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
     loop_fll(s, index, IP, QP);
     u32 flag = nav_bit_sync(s, sip, index, IP, now);
     loop_snr(s, IP, QP);
-    flag |= (IP > 0 ? 1u : 0u) | (s.period_sync_ok_flag ? 8u : 0u) | (moved ? 16u : 0u);
+    flag |= (IP > 0 ? 1u : 0u) | (s.period_sync_ok_flag ? 8u : 0u) | (moved ? 16u : 0u) | 128u;
     if (in_wave && k_l == 0) {
       flags[(size_t)ms * n_ch + ch_l] = (uint8_t)flag;
       if (trace) {
@@ -397,15 +444,20 @@ void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int 
 }
 
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
-                       gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, const uint32_t *d_chipbits, const uint32_t *d_trk_rep,
-                       uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
+                       gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, const uint32_t *d_chipbits,
+                       const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
 {
   if (n_ch <= 0 || n_blocks <= 0)
     return;
   int cpw = n_ch / (4 * 256 * 4);   // as launch_track_epl: ~4 workgroups per CU, 16 channels per wave at most
   cpw = cpw < 1 ? 1 : (cpw > 16 ? 16 : cpw);
-  hipLaunchKernelGGL(k_track_loop, dim3((n_ch + 4 * cpw - 1) / (4 * cpw)), dim3(256), 0, s, d_if_blocks, block_stride, n_blocks,
-                     if_format, if_hz, d_st, n_ch, cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn);
+  const dim3 grid((n_ch + 4 * cpw - 1) / (4 * cpw));
+  if (schedule == GPSX_SCHED_MUX17)
+    hipLaunchKernelGGL(k_track_loop<true>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
+                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn);
+  else
+    hipLaunchKernelGGL(k_track_loop<false>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
+                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn);
 }
 
 }  // namespace gpsx

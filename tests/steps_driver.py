@@ -93,7 +93,7 @@ def _fnv1a32(buf: np.ndarray) -> int:
 
 
 def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int, via_capture: bool = False,
-                 digest: bool = False):
+                 digest: bool = False, track_hook=None):
     """Cold boot exactly as PM/main.c does: memset the table, set PRN + Doppler hint, gps_channell_prepare, then the main
     loop: acquisition (one captured block per call) until every channel is GPS_ACQ_DONE, then 17-slot multiplexed
     tracking.  Returns uint8 snapshots [n_ms, 4, 226] taken after each millisecond's calls.
@@ -101,6 +101,9 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int,
     via_capture (libgpsx only): the blocks arrive through the capture interface of PM/signal_capture.h -- pushed as the DMA
     interrupt would, fetched back with signal_capture_get_copy_buf (acquisition, PM/main.c:106-125,163-168) or
     signal_capture_get_ready_buf (tracking, PM/main.c:134-137) -- instead of being handed over as numpy buffers.
+
+    track_hook(t, table) -> bool (libgpsx only): asked on every tracking millisecond; True = the hook served the table for
+    this millisecond itself (tests/test_gpu_track_mux.py: the tracking loops on the device), False = the reference-named call.
 
     digest: long runs -- instead of every snapshot, returns (crc[n_ms] of the 4 x 664-byte state after each millisecond,
     full states every CHECKPOINT_MS, the final state), nav_data included in full."""
@@ -175,7 +178,8 @@ def run_scenario(steps: StepsLib, stream: np.ndarray, prns, hints_hz, n_ms: int,
                 sat = 0
             index = 0xFF if big == 4 * N_CH else big % 4
             data = lib.signal_capture_get_ready_buf() if via_capture else blk.ctypes.data
-            lib.gps_tracking_process(ch_ptr(sat), data, index)
+            if track_hook is None or not track_hook(t, table):
+                lib.gps_tracking_process(ch_ptr(sat), data, index)
             need_acq = master(index)
         if digest:
             full = table[:, :SNAP_FULL]

@@ -193,7 +193,7 @@ def test_reference_step_sources_relink_against_libgpsx_unmodified(lib_path, tmp_
 
 
 def test_loop_state_conversion_round_trips_and_touches_only_the_loops_fields(lib_path):
-    """gpsx_loop_state_from_channel / gpsx_loop_state_to_channel (host code): a tracking channel's record -> the 96-byte
+    """gpsx_loop_state_from_channel / gpsx_loop_state_to_channel (host code): a tracking channel's record -> the 108-byte
     device-resident loop state -> back.  Everything the loops own survives the round trip bit for bit; nothing else of the
     record (acquisition result, word layer, observations, ephemeris, PRN code) is written."""
     import ctypes as C
@@ -230,6 +230,8 @@ def test_loop_state_conversion_round_trips_and_touches_only_the_loops_fields(lib
     untouched[212:225] = False                  # the bit synchroniser's part of nav_data
     assert np.array_equal(back[untouched], rec[untouched])
     # inside tracking_data the fields the loops do NOT own stay as they were (here: scrambled): code_search_*, pre_track_*,
-    # prev_track_timestamp, old_code_phase_fine, code_phase_swap_flag, filt_start_time_ms, state
-    for lo, hi in ((0, 4), (12, 76), (76, 80), (84, 89), (136, 140), (148, 152)):
+    # old_code_phase_fine, code_phase_swap_flag, filt_start_time_ms, state (prev_track_timestamp IS the loops': the tick the
+    # device last served the channel on -- a host that takes the channel back must see the right elapsed time)
+    assert int(st["prev_track_timestamp"][0]) == int(rec[60 + 76:60 + 80].view("<u4")[0])
+    for lo, hi in ((0, 4), (12, 76), (84, 89), (136, 140), (148, 152)):
         assert np.array_equal(back[60 + lo:60 + hi], rec[60 + lo:60 + hi] ^ 0xFF), (lo, hi)

@@ -1,0 +1,311 @@
+"""The tracking loops on the device under the REFERENCE'S OWN serving schedule -- four channels sharing one correlator in a
+17 ms cycle (PM/main.c:139-152; gpsx_loop_set_schedule(GPSX_SCHED_MUX17)): slot t % 17 / 4 served with index t % 17 % 4, the
+idle millisecond, the skipped milliseconds made up in the carrier NCO on the device (gps_rewind_if_phase,
+PM/GPS/tracking.c:102-113), the bit-edge locator at the end of a slot (PM/GPS/nav_data.c:145-214) -- against the reference's
+multiplexed golden traces:
+
+  f7_steps_hints.npz  3000 ms x 4 channels, every channel's acq_data + tracking_data + bit synchroniser after every ms;
+  f7_steps_lnav.npz   15 s with LNAV subframes: a CRC of every channel's WHOLE record (664 bytes: loops, bit synchroniser,
+                      word layer, polarity, subframe image, subframe time stamp, decoded ephemeris) per millisecond, the
+                      records themselves every 500 ms.
+
+The library's host mode (bit-exact against the same traces, tests/test_gpu_steps.py) takes the receiver through
+acquisition and pre-tracking; on the first cycle start with all four channels in GPS_TRACKING_RUN the channels are handed
+to the device loop (gpsx_loop_state_from_channel) and stay there: per launch the flag bytes go through the word layer
+(gps_tracking_words_batch), the states come back into the records (gpsx_loop_state_to_channel), and the records are compared
+with the reference's.  Bar: floats within SURVEY.md 8(c)'s tolerance (|d code_phase_fine| <= 0.01 sample,
+|d if_freq_offset_hz| <= 0.5 Hz), every integer field identical; what is observed is printed (so far: every byte of every
+millisecond identical -- the device's arctangents land on glibc's floats on these traces)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import steps_driver as sd
+from golden_util import fnv1a32, load
+
+pytestmark = pytest.mark.gpu
+
+TOL_FINE, TOL_HZ = 0.01, 0.5
+CYCLE = 17
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from stm32f4_sdr_gps_amd import capi
+    e = capi.Engine(0)
+    e.set_loop_schedule(capi.SCHED_MUX17)
+    yield e
+    e.close()
+
+
+class DeviceMux:
+    """track_hook for steps_driver.run_scenario: from the first cycle start with every channel tracking, the table is served by
+    gpsx_track_loop in launches of k ms (k = 1, or a multiple of the cycle: launches then start on cycle starts)."""
+
+    def __init__(self, eng, stream, k):
+        from stm32f4_sdr_gps_amd import capi
+        assert k == 1 or k % CYCLE == 0
+        self.eng, self.lib, self.stream, self.k = eng, eng.lib, stream, k
+        self.d = None
+        self.t_hand = None
+        self.st = np.zeros(sd.N_CH, capi.LOOP_DTYPE)
+        self.changed = np.zeros(sd.N_CH, np.int32)
+        self.flags = []           # per launch: (first tick, flags [k, 4])
+        self.trace = []
+        self.polarity_changes = 0
+        self.lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
+        self.lib.gpsx_loop_state_to_channel.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+
+    def close(self):
+        if self.d is not None:
+            self.eng.free(self.d)
+            self.d = None
+
+    def __call__(self, t, table):
+        if self.d is None:
+            state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+            if t % CYCLE != 0 or not (state == sd.TRK_RUN).all():
+                return False
+            for i in range(sd.N_CH):
+                self.lib.gpsx_loop_state_from_channel(table[i].ctypes.data, i + 1, self.st[i:i + 1].ctypes.data)
+            self.d = self.eng.malloc(self.st.nbytes)
+            self.eng.h2d(self.d, self.st)
+            self.t_hand = t
+        if (t - self.t_hand) % self.k:
+            return True           # inside a launch that already covered this millisecond
+        kk = min(self.k, len(self.stream) - t)
+        flags, trace = self.eng.track_loop(self.stream[t:t + kk], self.d, sd.N_CH, t, want_trace=True)
+        self.flags.append((t, flags))
+        self.trace.append(trace)
+        m = self.lib.gps_tracking_words_batch(table.ctypes.data, sd.N_CH, flags.ctypes.data, kk, t, self.changed.ctypes.data, sd.N_CH)
+        if m:
+            vals = np.array([table[c, 212 + 13] for c in self.changed[:m]], np.uint8)
+            assert self.lib.gpsx_loop_set_polarity(self.eng.h, self.d, self.changed.ctypes.data, vals.ctypes.data, m) == 0
+            self.polarity_changes += m
+        self.eng.d2h(self.st, self.d)
+        for i in range(sd.N_CH):
+            self.lib.gpsx_loop_state_to_channel(self.st[i:i + 1].ctypes.data, table[i].ctypes.data)
+        return True
+
+
+def _f32(a, off):
+    return a[..., off:off + 4].copy().view("<f4")[..., 0]
+
+
+def _served(t, c):
+    big = t % CYCLE
+    return big != 16 and big // 4 == c
+
+
+def test_schedule_flags_and_rewind(eng, oracle):
+    """The schedule itself, on four channels from chosen states: flag byte 0 and nothing moving on a channel's unserved
+    milliseconds, bit 7 on the served ones; each served millisecond's six accumulators from the state the device had going
+    into it -- the NCO accumulator first advanced by the oracle's gps_rewind_if_phase over the skipped milliseconds --
+    against the CPU oracle, bit for bit; prev_track_timestamp; and the reference's start-up rule (an elapsed time above
+    50 ms counts as 1: no rewind)."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    stream = synth.default_four_sv(2 * CYCLE + 5, seed=7)
+    prns = [5, 14, 20, 30]
+    st = np.zeros(4, capi.LOOP_DTYPE)
+    st["prn"] = prns
+    st["code_phase_fine"] = [1600.0, 4000.5, 9003.0, 13007.9]
+    st["if_freq_offset_hz"] = [912.5, 4037.0, -1025.0, 2018.0]
+    st["if_freq_accum"] = [0, 1 << 31, 12345, 0xFFFFFFF0]
+    st["found_freq_offset_hz"] = [900, 4000, -1000, 2000]
+    st["rng"] = [1, 2, 3, 4]
+    t0 = 5 * CYCLE + 3                                   # a launch may start anywhere in the cycle
+    st["prev_track_timestamp"] = [t0 - 1, t0 - 13, 0, t0 - 60]   # served last ms / 12 skipped / never (t0 > 50: counts as 1) / long ago
+    d = eng.malloc(st.nbytes)
+    try:
+        eng.h2d(d, st)
+        n = len(stream)
+        flags, trace = eng.track_loop(stream, d, 4, t0, want_trace=True)
+        out = np.zeros_like(st)
+        eng.d2h(out, d)
+    finally:
+        eng.free(d)
+    for c in range(4):
+        fine, freq, acc, prev = (float(st["code_phase_fine"][c]), float(st["if_freq_offset_hz"][c]), int(st["if_freq_accum"][c]),
+                                 int(st["prev_track_timestamp"][c]))
+        chips = oracle.ca_code(prns[c])
+        for i in range(n):
+            t = t0 + i
+            if not _served(t, c):
+                assert flags[i, c] == 0 and not trace["iq"][i, c].any(), (c, t)
+                assert trace["code_phase_fine"][i, c] == np.float32(fine) and trace["if_freq_offset_hz"][i, c] == np.float32(freq)
+                assert int(trace["if_freq_accum"][i, c]) == acc
+                continue
+            assert flags[i, c] & 128, (c, t)
+            elapsed = (t - prev) & 0xFFFFFFFF
+            if elapsed > 50:
+                elapsed = 1
+            if elapsed != 1:
+                acc = oracle.rewind(freq, acc, (elapsed - 1) & 0xFF)
+            prev = t
+            iq, acc = oracle.track_epl(stream[i], chips, fine, freq, acc)
+            assert np.array_equal(iq, trace["iq"][i, c]) and acc == int(trace["if_freq_accum"][i, c]), (c, t)
+            fine, freq = float(trace["code_phase_fine"][i, c]), float(trace["if_freq_offset_hz"][i, c])
+        assert int(out["prev_track_timestamp"][c]) == prev
+    assert (flags[[i for i in range(n) if (t0 + i) % CYCLE == 16]] == 0).all()
+
+
+def _compare_snaps(got, want, t_from, label):
+    """per-ms records [n, 4, >= 226]: floats within tolerance, and byte-for-byte where the floats are identical"""
+    d_fine = np.abs(_f32(got, 60 + 80) - _f32(want, 60 + 80))
+    d_freq = np.abs(_f32(got, 60 + 4) - _f32(want, 60 + 4))
+    same = (got == want).all(axis=(1, 2))
+    print(label, "max |d fine|", d_fine.max(), "max |d freq|", d_freq.max(), "milliseconds with every byte identical",
+          int(same.sum()), "of", len(got), "(device from tick", t_from, ")")
+    diff = got != want
+    if diff.any():
+        offs = np.flatnonzero(diff.any(axis=(0, 1)))
+        first = np.argwhere(diff)[0]
+        print(label, "byte offsets that ever differ", offs.tolist(), "first difference (ms, channel, byte)", first.tolist())
+    assert d_fine.max() <= TOL_FINE and d_freq.max() <= TOL_HZ
+    return same
+
+
+def test_device_mux_follows_the_multiplexed_reference_trace(eng):
+    """f7_steps_hints.npz: 3000 ms, acquisition with Doppler hints, pre-tracking, multiplexed tracking; k = 1 (a polarity
+    change of the word layer reaches the device for the next millisecond, as in the reference).  Every millisecond's records
+    against the reference's: tolerance on the floats; if_freq_accum, the E/P/L-driven integers (false-lock buffers and
+    counters, FLL memory, SNR sums), prev_track_timestamp, the bit synchroniser's period flag and counters,
+    accurate_swap_time / _ok, old_swap_time, the vote counters, the polarity flag: identical."""
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_hints.npz")
+    n_ms = int(g["n_ms"])
+    stream = synth.four_sv_with_nav(n_ms, seed=7)
+    assert fnv1a32(stream[::97]) == int(g["stream_fnv"])
+    C.CDLL("libc.so.6").srand(1)
+    hook = DeviceMux(eng, stream, 1)
+    try:
+        snaps = sd.run_scenario(sd.StepsLib(eng.lib, False), stream, g["prns"].tolist(), g["hints"].tolist(), n_ms, track_hook=hook)
+    finally:
+        hook.close()
+    want = g["snaps"]
+    assert hook.t_hand is not None and hook.t_hand < 1000, hook.t_hand
+    assert eng.lib.gpsx_last_kernel(eng.h) == b"k_track_loop"
+    same = _compare_snaps(snaps, want, hook.t_hand, "hints trace:")
+    # integer fields, every millisecond (offsets inside the 226-byte snapshot: tracking_data at 60, nav_data at 212)
+    ints = {"if_freq_accum": (60 + 8, 4), "prev_track_timestamp": (60 + 76, 4), "fll_old_i/q": (60 + 100, 4), "pll_check_buf": (60 + 108, 8),
+            "pll_bad_state_cnt": (60 + 116, 1), "pll_bad_state_master_cnt": (60 + 118, 2), "i/q_part_summ": (60 + 120, 8),
+            "snr_summ_cnt": (60 + 128, 2), "code_filt_cnt": (60 + 140, 2), "state": (60 + 148, 4),
+            "period_sync_ok_flag, right_period_cnt": (212, 2), "old_swap_time": (212 + 4, 4),
+            "old_reminder, accurate_swap_time, accurate_swap_ok, last_bit_pos_cnt, last_bit_neg_cnt, inv_polarity_flag": (212 + 8, 6)}
+    for name, (off, size) in ints.items():
+        bad = np.argwhere((snaps[:, :, off:off + size] != want[:, :, off:off + size]).any(axis=2))
+        assert len(bad) == 0, (name, "first mismatch (ms, channel)", bad[0].tolist())
+    assert snaps[-1, :, 212].any(), "no channel reached bit-period sync inside the trace"
+    # flag bit 7 = served, on exactly the schedule's milliseconds
+    for t, f in hook.flags:
+        for c in range(4):
+            assert bool(f[0, c] & 128) == _served(t, c), (t, c)
+    assert same.mean() > 0.9
+
+
+def _lnav(eng, k):
+    from stm32f4_sdr_gps_amd import synth
+    g = load("f7_steps_lnav.npz")
+    n_ms = int(g["n_ms"])
+    stream = synth.four_sv_with_lnav(n_ms, seed=7)
+    assert fnv1a32(stream[::97]) == int(g["stream_fnv"])
+    C.CDLL("libc.so.6").srand(1)
+    hook = DeviceMux(eng, stream, k)
+    try:
+        crcs, checkpoints, final = sd.run_scenario(sd.StepsLib(eng.lib, False), stream, g["prns"].tolist(), g["hints"].tolist(), n_ms,
+                                                   digest=True, track_hook=hook)
+    finally:
+        hook.close()
+    return g, hook, crcs, checkpoints, final
+
+
+def test_device_mux_with_the_word_layer_reproduces_the_reference_receiver(eng):
+    """f7_steps_lnav.npz, 15 s, k = 1: loops and bit synchroniser on the device, word layer on the flag bytes -- the whole 664-byte
+    record of every channel (words, parity history, polarity, subframe image, the SUBFRAME TIME STAMP made from the located
+    bit edge, the decoded ephemeris) against the reference's CRC of it after every millisecond, and against its records every
+    500 ms.  This is the statement that device-tracked channels deliver what the pseudorange step starts from."""
+    g, hook, crcs, checkpoints, final = _lnav(eng, 1)
+    assert hook.t_hand is not None and hook.t_hand < 600, hook.t_hand
+    cp_w = g["checkpoints"]
+    d_fine = np.abs(_f32(checkpoints, 60 + 80) - _f32(cp_w, 60 + 80))
+    d_freq = np.abs(_f32(checkpoints, 60 + 4) - _f32(cp_w, 60 + 4))
+    same_ms = crcs == g["crcs"]
+    print("lnav trace: device from tick", hook.t_hand, "milliseconds whose 4 x 664 bytes have the reference's CRC", int(same_ms.sum()), "of",
+          len(crcs), "max |d fine|", d_fine.max(), "max |d freq|", d_freq.max(), "polarity changes", hook.polarity_changes)
+    assert d_fine.max() <= TOL_FINE and d_freq.max() <= TOL_HZ
+    # everything that is not a float of the loops: identical at every checkpoint and at the end
+    float_bytes = np.zeros(sd.SNAP_FULL, bool)
+    for off in (60 + 4, 60 + 80, 60 + 92, 60 + 96, 60 + 104, 60 + 132, 60 + 144):   # if_freq_offset_hz, code_phase_fine, dll / pll / fll memories, snr_value, code_phase_fine_filt
+        float_bytes[off:off + 4] = True
+    bad = np.argwhere(checkpoints[:, :, ~float_bytes] != cp_w[:, :, ~float_bytes])
+    assert len(bad) == 0, ("first integer mismatch (checkpoint, channel, byte among the non-float ones)", bad[0].tolist())
+    assert np.array_equal(final[:, ~float_bytes], g["final"][:, ~float_bytes])
+    nav = final[:, 212:324]
+    assert int(nav[0, 60:64].copy().view("<u4")[0]) == 11260 and int(nav[0, 68:70].copy().view("<u2")[0]) == 1   # the subframe's time stamp
+    assert nav[3, 13] == 1 and nav[3, 14] == 1 and hook.polarity_changes >= 2
+    assert nav[:, 10].all(), "accurate_swap_ok on every channel: the multiplex walks every channel's bit edge through position 2"
+    assert same_ms.mean() > 0.9
+
+
+def test_device_mux_in_whole_cycle_launches(eng):
+    """The same 15 s in launches of one 17 ms cycle (what a receiver does: one launch, then the idle millisecond's navigation
+    work).  Against the reference at the end of every cycle; a polarity change now reaches the device at the next cycle instead
+    of the next millisecond, which the reference's records can show as one vote of a bit (stated in include/gpsx.h), so the
+    bar here is: floats within tolerance, loops' integers and the subframe time stamp identical at every checkpoint."""
+    g, hook, crcs, checkpoints, final = _lnav(eng, CYCLE)
+    ends = np.arange(hook.t_hand + CYCLE - 1, len(crcs), CYCLE)
+    same = crcs[ends] == g["crcs"][ends]
+    print("lnav trace, 17 ms launches: cycle ends with the reference's CRC", int(same.sum()), "of", len(ends))
+    nav, nav_w = final[:, 212:324], g["final"][:, 212:324]
+    assert np.array_equal(nav[:, 60:70], nav_w[:, 60:70])          # last / first subframe time, subframe count
+    assert np.array_equal(nav[:, 13:15], nav_w[:, 13:15])          # polarity
+    assert np.array_equal(final[:, 344:664], g["final"][:, 344:664])   # decoded ephemeris
+    assert same.mean() > 0.5
+
+
+def test_mux_at_scale_every_receiver_is_the_four_channel_receiver(eng):
+    """5000 receivers + a ragged last one (20 003 channels: four channels per wave, waves of one slot each) on the same
+    signal, each channel started from the state the four-channel trace has at its hand-over tick; launches of 17, 64 and 1 ms.
+    Every receiver must be bit-identical to the four-channel run."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    g = load("f7_steps_hints.npz")
+    stream = synth.four_sv_with_nav(int(g["n_ms"]), seed=7)
+    snaps = g["snaps"]
+    state = snaps[:, :, 60 + 148:60 + 152].copy().view("<i4")[:, :, 0]
+    first = int(np.flatnonzero((state == sd.TRK_RUN).all(axis=1))[0])
+    t0 = (first + CYCLE) // CYCLE * CYCLE
+    t1 = t0 + 10 * CYCLE + 5
+    recs = np.zeros((4, sd.CH_SIZE), np.uint8)
+    recs[:, :sd.SNAP] = snaps[t0 - 1]
+    recs[:, 664] = g["prns"]
+    st4 = np.zeros(4, capi.LOOP_DTYPE)
+    for i in range(4):
+        eng.lib.gpsx_loop_state_from_channel(recs[i].ctypes.data, i + 1, st4[i:i + 1].ctypes.data)
+
+    def run(st0, k):
+        n = len(st0)
+        d = eng.malloc(st0.nbytes)
+        try:
+            eng.h2d(d, st0)
+            fl = []
+            t = t0
+            while t < t1:
+                kk = min(k, t1 - t)
+                f, _ = eng.track_loop(stream[t:t + kk], d, n, t)
+                fl.append(f)
+                t += kk
+            out = np.zeros_like(st0)
+            eng.d2h(out, d)
+        finally:
+            eng.free(d)
+        return np.concatenate(fl), out
+
+    f4, end4 = run(st4, 1)
+    n = 20003
+    big = st4[np.arange(n) % 4]
+    for k in (17, 64):
+        f, end = run(big, k)
+        assert np.array_equal(f, f4[:, np.arange(n) % 4]), k
+        assert end.tobytes() == end4[np.arange(n) % 4].tobytes(), k
