@@ -299,7 +299,16 @@ int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_tr
  * Differences from the host mode, all stated: the arctangents are the device's (results agree with glibc's to the last
  * bit or the one before it: the stated tolerance of the closed loop is |d code_phase_fine| <= 0.01 sample,
  * |d if_freq_offset_hz| <= 0.5 Hz against the reference's traces, tests/test_gpu_track_loop.py); the false-lock jump
- * draws from a per-channel xorshift32 (`rng`, never 0) instead of libc's process-global rand(). */
+ * draws from a per-channel xorshift32 (`rng`, never 0) instead of libc's process-global rand().
+ * Data polarity (gpsx_loop_set_word_sync): the reference's word layer flips inv_polarity_flag when it has seen two inverted
+ * preambles, and the very next millisecond's vote and sign-change detection use the new value (nav_data.c:60-66, 284-291).
+ *   GPSX_WORDSYNC_DEVICE (default)  the kernel runs the polarity-deciding part of the word layer itself (preamble hunt, word
+ *       collection, parity, the two-subframe timeout: 12 bytes of state) on every completed bit, so the flag changes on the
+ *       millisecond the reference changes it on, whatever the launch length.  The host's word layer
+ *       (gps_tracking_words_batch) sees the same bits at the same ticks and takes the same decisions; it still lists the
+ *       channels whose flag changed, and handing them to gpsx_loop_set_polarity is harmless (the device already has the value).
+ *   GPSX_WORDSYNC_HOST  the device never touches the flag: a host with its own word layer (one that overrides
+ *       gps_nav_data_words_detection) writes it through gpsx_loop_set_polarity; it then takes effect at the next launch. */
 typedef struct {
   int32_t  prn;                                /* 1 .. 210 */
   float    code_phase_fine;                    /* gps_tracking_t, same names, same meaning (include/gpsx_compat.h) */
@@ -325,10 +334,15 @@ typedef struct {
   uint8_t  slot_bits;                          /* bit i = sign bit of index i of the group */
   uint8_t  right_period_cnt, old_reminder, accurate_swap_time, accurate_swap_ok;
   uint8_t  last_bit_pos_cnt, last_bit_neg_cnt;
-  uint8_t  inv_polarity_flag;                  /* written by the HOST's word layer when it finds inverted preambles */
+  uint8_t  inv_polarity_flag;                  /* data polarity inverted: decided by the device's word sync (below), or written
+                                                  through gpsx_loop_set_polarity under GPSX_WORDSYNC_HOST */
   uint32_t prev_track_timestamp;               /* gps_tracking_t: tick the channel was last served on */
   uint32_t snr_i_latch, snr_q_latch;           /* the sums snr_value was last made of (q = 0: snr_value stands as it is) */
-} gpsx_loop_state_t;                           /* 108 bytes */
+  uint32_t word_buf;                           /* gps_nav_data_t.word_buf: bit i = word_buf[i]  (the device's word sync) */
+  uint32_t word_detection_timestamp;
+  uint8_t  word_cnt, word_bit_cnt, inv_preabmle_cnt;
+  uint8_t  word_flags;                         /* bit 0 old_D29, bit 1 old_D30, bit 2 polarity_found */
+} gpsx_loop_state_t;                           /* 120 bytes */
 
 typedef struct {                               /* optional per-millisecond record, for tests and inspection */
   int16_t  iq[6];                              /* IE, QE, IP, QP, IL, QL of this millisecond */
@@ -350,6 +364,10 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
 #define GPSX_SCHED_EVERY_MS 0
 #define GPSX_SCHED_MUX17    1
 int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule);
+
+#define GPSX_WORDSYNC_DEVICE 0
+#define GPSX_WORDSYNC_HOST   1
+int gpsx_loop_set_word_sync(gpsx_ctx *ctx, int owner);
 
 /* The host's word layer found (or gave up) inverted data polarity on n channels: d_state[channels[i]].inv_polarity_flag =
  * values[i] (host arrays; enqueued on the context's stream in front of the next launch). */

@@ -24,6 +24,7 @@ PHASES_BYTE = 2046
 PHASES_FINE = 16368
 IF_HZ = 4092000
 SCHED_EVERY_MS, SCHED_MUX17 = 0, 1
+WORDSYNC_DEVICE, WORDSYNC_HOST = 0, 1
 
 LOOP_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"), ("if_freq_accum", "<u4"),
                        ("dll_code_err", "<f4"), ("pll_code_err", "<f4"), ("fll_err", "<f4"), ("fll_old_i", "<i2"),
@@ -35,9 +36,10 @@ LOOP_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_off
                        ("right_period_cnt", "u1"), ("old_reminder", "u1"), ("accurate_swap_time", "u1"),
                        ("accurate_swap_ok", "u1"), ("last_bit_pos_cnt", "u1"), ("last_bit_neg_cnt", "u1"),
                        ("inv_polarity_flag", "u1"), ("prev_track_timestamp", "<u4"), ("snr_i_latch", "<u4"),
-                       ("snr_q_latch", "<u4")])                # gpsx_loop_state_t, 108 bytes
+                       ("snr_q_latch", "<u4"), ("word_buf", "<u4"), ("word_detection_timestamp", "<u4"), ("word_cnt", "u1"),
+                       ("word_bit_cnt", "u1"), ("inv_preabmle_cnt", "u1"), ("word_flags", "u1")])   # gpsx_loop_state_t, 120 bytes
 LOOP_TRACE_DTYPE = np.dtype([("iq", "<i2", 6), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"), ("if_freq_accum", "<u4")])
-assert LOOP_DTYPE.itemsize == 108 and LOOP_TRACE_DTYPE.itemsize == 24
+assert LOOP_DTYPE.itemsize == 120 and LOOP_TRACE_DTYPE.itemsize == 24
 PEAK_DTYPE = np.dtype([("max_val", "<u4"), ("phase", "<u4"), ("sum", "<u4"), ("avr", "<u4")])
 TRACK_CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)   # gpsx_track_chunk_fn
 TRK_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"),
@@ -107,6 +109,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_loop_set_polarity.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     lib.gpsx_loop_reset_code_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.gpsx_loop_set_schedule.argtypes = [C.c_void_p, C.c_int]
+    lib.gpsx_loop_set_word_sync.argtypes = [C.c_void_p, C.c_int]
     lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.gpsx_loop_state_from_channel.restype = None
@@ -401,6 +404,10 @@ class Engine:
     def set_loop_schedule(self, schedule: int) -> None:
         """SCHED_EVERY_MS or SCHED_MUX17 (the reference's four-channel 17 ms multiplex) for this context's track_loop launches"""
         self._chk(self.lib.gpsx_loop_set_schedule(self.h, schedule), "gpsx_loop_set_schedule")
+
+    def set_loop_word_sync(self, owner: int) -> None:
+        """WORDSYNC_DEVICE (default: the kernel decides the data polarity itself) or WORDSYNC_HOST (gpsx_loop_set_polarity only)"""
+        self._chk(self.lib.gpsx_loop_set_word_sync(self.h, owner), "gpsx_loop_set_word_sync")
 
     def track_loop(self, if_blocks: np.ndarray, d_state: int, n_ch: int, first_tick: int, want_trace=False):
         """K = len(if_blocks) milliseconds of the device tracking loops on the n_ch states at device address d_state.

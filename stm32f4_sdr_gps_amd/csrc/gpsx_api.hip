@@ -1073,6 +1073,16 @@ int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule)
   return GPSX_OK;
 }
 
+int gpsx_loop_set_word_sync(gpsx_ctx *ctx, int owner)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  if (owner != GPSX_WORDSYNC_DEVICE && owner != GPSX_WORDSYNC_HOST)
+    return fail(ctx, GPSX_EINVAL, "unknown word-sync owner");
+  ctx->loop_word_sync = owner;
+  return GPSX_OK;
+}
+
 int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
                         uint32_t first_tick_ms, uint8_t *d_flags, gpsx_loop_trace_t *d_trace_opt)
 {
@@ -1081,8 +1091,8 @@ int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gp
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
   launch_track_loop(ctx->stream, static_cast<const uint8_t *>(d_if_blocks), (uint32_t)blk_bytes, n_blocks, ctx->if_format,
-                    ctx->if_hz, d_state, n_ch, first_tick_ms, ctx->loop_schedule, ctx->d_bits_all, ctx->d_trk_rep, d_flags,
-                    d_trace_opt, ctx->d_bad_prn + 1);
+                    ctx->if_hz, d_state, n_ch, first_tick_ms, ctx->loop_schedule, ctx->loop_word_sync == GPSX_WORDSYNC_DEVICE, ctx->d_bits_all, ctx->d_trk_rep,
+                    d_flags, d_trace_opt, ctx->d_bad_prn + 1);
   LAUNCHCHK(ctx, "k_track_loop");
   ctx->last_kernel = "k_track_loop";
   return GPSX_OK;
@@ -1109,7 +1119,7 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
   }
   ctx->h_bad_prn[0] = 0;   // (flag 0: this entry point waits for its kernel, as gpsx_track_epl_batch does)
   launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick_ms,
-                    ctx->loop_schedule, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, ctx->d_bad_prn);
+                    ctx->loop_schedule, ctx->loop_word_sync == GPSX_WORDSYNC_DEVICE, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, ctx->d_bad_prn);
   LAUNCHCHK(ctx, "k_track_loop");
   ctx->last_kernel = "k_track_loop";
   HIPCHK(ctx, hipMemcpyAsync(flags, d_flags, n_rec, hipMemcpyDeviceToHost, ctx->stream));

@@ -175,7 +175,7 @@ void gps_rewind_if_phase(gps_tracking_t *trk_channel, uint8_t steps)
 
 
 // ---- channel record <-> device loop state (include/gpsx.h gpsx_loop_state_t) ------------------------------------------------
-static_assert(sizeof(gpsx_loop_state_t) == 108 && offsetof(gpsx_loop_state_t, pll_check_buf) == 32 &&
+static_assert(sizeof(gpsx_loop_state_t) == 120 && offsetof(gpsx_loop_state_t, pll_check_buf) == 32 &&
                   offsetof(gpsx_loop_state_t, slot_ip) == 80 && sizeof(gpsx_loop_trace_t) == 24,
               "gpsx_loop_state_t layout");
 
@@ -220,11 +220,20 @@ void gpsx_loop_state_from_channel(const gps_ch_t *ch, uint32_t rng_seed, gpsx_lo
   s.last_bit_neg_cnt = n.last_bit_neg_cnt;
   s.inv_polarity_flag = n.inv_polarity_flag;
   s.prev_track_timestamp = t.prev_track_timestamp;
+  // the word layer's polarity-deciding part (the device's word sync continues where the host's word layer stands)
+  for (int i = 0; i < GPS_NAV_WORD_LENGTH; i++)
+    s.word_buf |= (uint32_t)(n.word_buf[i] & 1u) << i;
+  s.word_detection_timestamp = n.word_detection_timestamp;
+  s.word_cnt = n.word_cnt;
+  s.word_bit_cnt = n.word_bit_cnt;
+  s.inv_preabmle_cnt = n.inv_preabmle_cnt;
+  s.word_flags = (uint8_t)((n.old_D29 & 1u) | ((n.old_D30 & 1u) << 1) | (n.polarity_found ? 4u : 0u));
   *out = s;
 }
 
 // ... and back: everything the loops own is written into the record, the rest of it (acquisition result, word layer,
-// observations, ephemeris) is left alone.
+// observations, ephemeris) is left alone -- the word layer's fields are the HOST's word layer's (gps_tracking_words_batch),
+// which runs on the same bits as the device's word sync; inv_polarity_flag, which both decide identically, is written.
 void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch)
 {
   gps_tracking_t &t = ch->tracking_data;
@@ -257,6 +266,7 @@ void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch)
   n.accurate_swap_ok = s.accurate_swap_ok;
   n.last_bit_pos_cnt = s.last_bit_pos_cnt;
   n.last_bit_neg_cnt = s.last_bit_neg_cnt;
+  n.inv_polarity_flag = s.inv_polarity_flag;
   // the tick the device last served the channel on: a host that takes the channel back into gps_tracking_process sees the
   // elapsed time the reference would (tracking.c:102-113), after any number of device milliseconds
   t.prev_track_timestamp = s.prev_track_timestamp;

@@ -49,6 +49,7 @@ struct gpsx_ctx {
   uint32_t *d_trk_rep = nullptr;     // [211][kTrackRepStride]: replica bit streams for the tracking correlators
   int if_format = GPSX_IF_1BIT;
   int loop_schedule = GPSX_SCHED_EVERY_MS;   // gpsx_loop_set_schedule
+  int loop_word_sync = GPSX_WORDSYNC_DEVICE; // gpsx_loop_set_word_sync
   int if_hz = GPSX_IF_HZ;             // gpsx_config_t.if_hz
   int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: the matrix-core kernel, at every launch size) | poly |
                                            // dot8 | sad, for A/B measurements and the parity tests of the alternative kernels

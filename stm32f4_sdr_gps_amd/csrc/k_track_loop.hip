@@ -16,6 +16,8 @@
 // bytes per channel: the kernel is bound by the correlators' vector instructions exactly as k_track_epl_wave is.
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
+
 #include "gpsx_device.hpp"
 #include "gpsx_kernels.hpp"
 #include "gpsx_libm.hpp"
@@ -235,9 +237,88 @@ __device__ __forceinline__ int nav_refine_edge(gpsx_loop_state_t &s, const Quad1
   return edge;
 }
 
+// IS-GPS-200 table 20-XIV as csrc/gpsx_steps.cpp holds it: source bits d1..d24 (bit i - 1) entering parity bits D25..D30
+constexpr u32 parity_bits(std::initializer_list<int> bits)
+{
+  u32 m = 0;
+  for (int b : bits)
+    m |= 1u << (b - 1);
+  return m;
+}
+constexpr u32 kParityMask[6] = {
+    parity_bits({1, 2, 3, 5, 6, 10, 11, 12, 13, 14, 17, 18, 20, 23}),  parity_bits({2, 3, 4, 6, 7, 11, 12, 13, 14, 15, 18, 19, 21, 24}),
+    parity_bits({1, 3, 4, 5, 7, 8, 12, 13, 14, 15, 16, 19, 20, 22}),   parity_bits({2, 4, 5, 6, 8, 9, 13, 14, 15, 16, 17, 20, 21, 23}),
+    parity_bits({1, 3, 5, 6, 7, 9, 10, 14, 15, 16, 17, 18, 21, 22, 24}), parity_bits({3, 5, 6, 8, 9, 10, 11, 13, 15, 19, 22, 23, 24}),
+};
+constexpr u32 kParityFromD30 = 0x1Au;      // parity bits 1, 3, 4 start from D30*, the others from D29*
+constexpr u32 kPreambleBits = 0xD1u;       // 1 0 0 0 1 0 1 1, first bit in bit 0
+constexpr u32 kBadPolarityTimeoutMs = 12000;
+
+// The part of gps_nav_data_words_detection (PM/GPS/nav_data.c:257-352) that decides the data POLARITY, on a 30-bit word
+// buffer: preamble hunt (upright / inverted), word collection, parity, the two-subframe timeout.  The polarity flag is used
+// by the very next millisecond's vote and sign-change detection (nav_data.c:60-66), so it is decided here, where it is used;
+// subframe images, time stamps and the ephemeris stay with the host's word layer, which sees the same bits at the same
+// ticks and therefore takes the same decisions (gps_tracking_words_batch).
+__device__ __forceinline__ void nav_word_sync(gpsx_loop_state_t &s, u32 new_bit, u32 now)
+{
+  u32 buf = s.word_buf;
+  if (s.word_cnt == 0) {
+    buf = (buf >> 1) | (new_bit << 29);
+    if ((buf & 0xFFu) == kPreambleBits) {
+      s.word_flags = (uint8_t)((s.word_flags & ~3u) | ((buf >> 28) & 3u));   // old_D29, old_D30
+      s.word_cnt = 1;
+      s.word_bit_cnt = 0;
+      s.inv_preabmle_cnt = 0;
+    }
+    if (!(s.word_flags & 4u) && s.word_cnt == 0) {
+      if ((buf & 0xFFu) == (kPreambleBits ^ 0xFFu))
+        s.inv_preabmle_cnt++;
+      if (s.inv_preabmle_cnt >= 2)
+        s.inv_polarity_flag = 1;
+    }
+    if (s.word_flags & 4u) {
+      if (now - s.word_detection_timestamp > kBadPolarityTimeoutMs) {
+        s.word_detection_timestamp = now;
+        s.word_flags &= (uint8_t)~4u;
+        s.inv_polarity_flag = 0;
+      }
+    }
+    s.word_buf = buf;
+    return;
+  }
+  buf = (buf & ~(1u << s.word_bit_cnt)) | (new_bit << s.word_bit_cnt);
+  s.word_bit_cnt++;
+  s.word_buf = buf;
+  if (s.word_bit_cnt < 30)
+    return;
+  const u32 d29 = s.word_flags & 1u, d30 = (s.word_flags >> 1) & 1u;
+  if (d30)
+    buf ^= 0xFFFFFFu;          // the D30* inversion comes off the 24 data bits in place (nav_data.c:439-440)
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const u32 p = ((u32)__popc(buf & kParityMask[k]) & 1u) ^ (((kParityFromD30 >> k) & 1u) ? d30 : d29);
+    ok = ok && ((buf >> (24 + k)) & 1u) == p;
+  }
+  if (!ok) {
+    s.word_cnt = 0;
+    s.word_buf = 0;
+    return;
+  }
+  s.word_flags = (uint8_t)(((buf >> 28) & 3u) | 4u);   // old_D29, old_D30 of the next word; polarity_found
+  s.word_cnt++;
+  s.word_bit_cnt = 0;
+  s.word_detection_timestamp = now;
+  s.word_buf = buf;
+  if (s.word_cnt == 10) {
+    s.word_cnt = 0;
+    s.word_buf = 0;
+  }
+}
+
 // gps_nav_data_analyse_new_code on the channel's own slot state; returns flag bits 1 / 2 (a bit was completed / its value)
 // and 5 / 6 (the bit edge inside the 20 ms grid was located this millisecond / it was edge 2, not 1)
-__device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, int index, int IP, u32 now)
+__device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, int index, int IP, u32 now, bool word_sync)
 {
   u32 out = 0;
   u32 bit = IP > 0 ? 1u : 0u;
@@ -250,7 +331,10 @@ __device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, i
   if (s.period_sync_ok_flag == 1) {   // nav_data.c:223-253
     const u32 rem = (now - s.old_swap_time) % 20u;
     if (rem < s.old_reminder) {
-      out = 2u | (s.last_bit_pos_cnt > s.last_bit_neg_cnt ? 4u : 0u);
+      const u32 nav_bit = s.last_bit_pos_cnt > s.last_bit_neg_cnt ? 1u : 0u;
+      out = 2u | (nav_bit << 2);
+      if (word_sync)
+        nav_word_sync(s, nav_bit, now);   // (this millisecond's own vote was formed with the polarity of before, as in the reference)
       s.last_bit_pos_cnt = 0;
       s.last_bit_neg_cnt = 0;
     }
@@ -331,7 +415,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
                                                     int if_format, int if_hz, gpsx_loop_state_t *__restrict__ st, int n_ch, int cpw,
                                                     u32 first_tick, const u32 *__restrict__ chipbits_all,
                                                     const u32 *__restrict__ rep_all, uint8_t *__restrict__ flags,
-                                                    gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn)
+                                                    gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn, int word_sync)
 {
   __shared__ u32 s_x[2][512];        // this and the next millisecond's sign plane: one barrier per millisecond
   __shared__ uint2 s_carrier[4];
@@ -406,7 +490,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
       loop_pll(s, IP, QP);
     const bool moved = loop_false_lock(s, chk, index, IP);
     loop_fll(s, index, IP, QP);
-    u32 flag = nav_bit_sync(s, sip, index, IP, now);
+    u32 flag = nav_bit_sync(s, sip, index, IP, now, word_sync != 0);
     loop_snr(s, IP, QP);
     flag |= (IP > 0 ? 1u : 0u) | (s.period_sync_ok_flag ? 8u : 0u) | (moved ? 16u : 0u) | 128u;
     if (in_wave && k_l == 0) {
@@ -444,8 +528,9 @@ void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int 
 }
 
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
-                       gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, const uint32_t *d_chipbits,
-                       const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
+                       gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, int word_sync,
+                       const uint32_t *d_chipbits, const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace,
+                       uint32_t *d_bad_prn)
 {
   if (n_ch <= 0 || n_blocks <= 0)
     return;
@@ -454,10 +539,10 @@ void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block
   const dim3 grid((n_ch + 4 * cpw - 1) / (4 * cpw));
   if (schedule == GPSX_SCHED_MUX17)
     hipLaunchKernelGGL(k_track_loop<true>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
-                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn);
+                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync);
   else
     hipLaunchKernelGGL(k_track_loop<false>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
-                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn);
+                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync);
 }
 
 }  // namespace gpsx

@@ -193,7 +193,7 @@ def test_reference_step_sources_relink_against_libgpsx_unmodified(lib_path, tmp_
 
 
 def test_loop_state_conversion_round_trips_and_touches_only_the_loops_fields(lib_path):
-    """gpsx_loop_state_from_channel / gpsx_loop_state_to_channel (host code): a tracking channel's record -> the 108-byte
+    """gpsx_loop_state_from_channel / gpsx_loop_state_to_channel (host code): a tracking channel's record -> the 120-byte
     device-resident loop state -> back.  Everything the loops own survives the round trip bit for bit; nothing else of the
     record (acquisition result, word layer, observations, ephemeris, PRN code) is written."""
     import ctypes as C
@@ -218,16 +218,21 @@ def test_loop_state_conversion_round_trips_and_touches_only_the_loops_fields(lib
     assert int(st["old_swap_time"][0]) == int(rec[212 + 4:212 + 8].view("<u4")[0]) and int(st["inv_polarity_flag"][0]) == rec[212 + 13]
     back = rec.copy()
     back[60:212] ^= 0xFF                        # scramble what the loops own, then restore it from the state
-    back[212:225] ^= 0xFF
+    back[212:226] ^= 0xFF
     lib.gpsx_loop_state_to_channel(st.ctypes.data, back.ctypes.data)
     st2 = np.zeros(1, capi.LOOP_DTYPE)
     lib.gpsx_loop_state_from_channel(back.ctypes.data, 99, st2.ctypes.data)
     for f in st.dtype.names:
-        if f not in ("inv_polarity_flag",):     # (written by the host's word layer, never by the device: not copied back)
-            assert st[f].tobytes() == st2[f].tobytes(), f
+        if f not in ("word_buf", "word_detection_timestamp", "word_cnt", "word_bit_cnt", "inv_preabmle_cnt", "word_flags"):
+            assert st[f].tobytes() == st2[f].tobytes(), f    # (those six: the host word layer's own fields, read, never written back)
+    n = rec[212:324]
+    assert int(st["word_buf"][0]) == sum(int(n[16 + i] & 1) << i for i in range(30))
+    assert int(st["word_cnt"][0]) == n[46] and int(st["word_bit_cnt"][0]) == n[47] and int(st["inv_preabmle_cnt"][0]) == n[15]
+    assert int(st["word_flags"][0]) == (n[48] & 1) | ((n[49] & 1) << 1) | (4 if n[14] else 0)
+    assert int(st["word_detection_timestamp"][0]) == int(n[52:56].copy().view("<u4")[0])
     untouched = np.ones(1688, bool)
     untouched[60:212] = False                   # tracking_data
-    untouched[212:225] = False                  # the bit synchroniser's part of nav_data
+    untouched[212:226] = False                  # the bit synchroniser's part of nav_data and the polarity flag
     assert np.array_equal(back[untouched], rec[untouched])
     # inside tracking_data the fields the loops do NOT own stay as they were (here: scrambled): code_search_*, pre_track_*,
     # old_code_phase_fine, code_phase_swap_flag, filt_start_time_ms, state (prev_track_timestamp IS the loops': the tick the

@@ -249,20 +249,40 @@ def test_device_mux_with_the_word_layer_reproduces_the_reference_receiver(eng):
     assert same_ms.mean() > 0.9
 
 
-def test_device_mux_in_whole_cycle_launches(eng):
-    """The same 15 s in launches of one 17 ms cycle (what a receiver does: one launch, then the idle millisecond's navigation
-    work).  Against the reference at the end of every cycle; a polarity change now reaches the device at the next cycle instead
-    of the next millisecond, which the reference's records can show as one vote of a bit (stated in include/gpsx.h), so the
-    bar here is: floats within tolerance, loops' integers and the subframe time stamp identical at every checkpoint."""
-    g, hook, crcs, checkpoints, final = _lnav(eng, CYCLE)
+@pytest.mark.parametrize("k", [CYCLE, 3 * CYCLE])
+def test_device_mux_in_whole_cycle_launches(eng, k):
+    """The same 15 s in launches of one (three) 17 ms cycles -- what a receiver does: one launch, then the idle millisecond's
+    navigation work.  The polarity of the data is decided on the device (GPSX_WORDSYNC_DEVICE: the word layer's preamble hunt
+    and parity check run in the kernel on every completed bit), so a polarity change lands on the millisecond the reference
+    makes it on, inside a launch: the records at the end of EVERY cycle carry the reference's CRC, the final records are the
+    reference's byte for byte."""
+    g, hook, crcs, checkpoints, final = _lnav(eng, k)
+    ends = np.arange(hook.t_hand + k - 1, len(crcs), k)
+    same = crcs[ends] == g["crcs"][ends]
+    print("lnav trace,", k, "ms launches: launch ends with the reference's CRC", int(same.sum()), "of", len(ends))
+    assert same.all(), ("first launch end that differs", int(ends[np.flatnonzero(~same)[0]]))
+    assert np.array_equal(final, g["final"])
+
+
+def test_host_owned_polarity_arrives_a_launch_late(eng):
+    """GPSX_WORDSYNC_HOST: the device leaves the flag to gpsx_loop_set_polarity (a host with its own word layer).  In 17 ms
+    launches a change then takes effect at the next launch: the loops' state still follows the reference (floats identical,
+    time stamps and ephemeris identical), but the records are no longer the reference's at every cycle end -- the stated
+    difference of that mode."""
+    from stm32f4_sdr_gps_amd import capi
+    eng.set_loop_word_sync(capi.WORDSYNC_HOST)
+    try:
+        g, hook, crcs, checkpoints, final = _lnav(eng, CYCLE)
+    finally:
+        eng.set_loop_word_sync(capi.WORDSYNC_DEVICE)
     ends = np.arange(hook.t_hand + CYCLE - 1, len(crcs), CYCLE)
     same = crcs[ends] == g["crcs"][ends]
-    print("lnav trace, 17 ms launches: cycle ends with the reference's CRC", int(same.sum()), "of", len(ends))
+    print("lnav trace, host-owned polarity, 17 ms launches: cycle ends with the reference's CRC", int(same.sum()), "of", len(ends))
     nav, nav_w = final[:, 212:324], g["final"][:, 212:324]
     assert np.array_equal(nav[:, 60:70], nav_w[:, 60:70])          # last / first subframe time, subframe count
     assert np.array_equal(nav[:, 13:15], nav_w[:, 13:15])          # polarity
     assert np.array_equal(final[:, 344:664], g["final"][:, 344:664])   # decoded ephemeris
-    assert same.mean() > 0.5
+    assert hook.polarity_changes >= 2 and 0.5 < same.mean() < 1.0
 
 
 def test_mux_at_scale_every_receiver_is_the_four_channel_receiver(eng):
