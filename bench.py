@@ -300,6 +300,55 @@ def cpu_baseline(blocks, budget_s=20.0):
     return out
 
 
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: re-executes this script as N ranks (one per GPU) under
+    torch.distributed.run on 127.0.0.1, passes every argument through, and exits with the job's exit code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and os.environ.get("GPSX_BENCH_SHARE_DEVICE") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    with socket.socket() as s:       # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+
+
+def _sign_plane(blocks_2bit):
+    """the 2046-byte sign plane of GPSX_IF_2BIT_SM blocks (sample n: bit 2 (n & 3) of byte n >> 2)"""
+    bits = np.unpackbits(np.ascontiguousarray(blocks_2bit, np.uint8), axis=-1, bitorder="little")
+    return np.packbits(bits[..., 0::2], axis=-1, bitorder="little")
+
+
+def _parity_sample(keys, sign_blocks_of, n_search, n_ms):
+    """Rank 0, outside the timed region: cells of the MERGED key table (what the all-reduce left) against the CPU oracle --
+    two searches, one from each end of the table (in weak scaling: other ranks' units too), PRNs 3 / 11 / 20 / 30 (one per 8-PRN
+    group: four different work units per Doppler bin) x Doppler bins 1 / 6 / 11 / 16, every one of their 16368 x n_ms
+    hypotheses.  The oracle is the checker here, never the thing measured."""
+    from oracle import pyoracle
+    orc = pyoracle.Oracle()
+    prns = np.array([3, 11, 20, 30], np.uint8)
+    bins = [1, 6, 11, 16]
+    searches = sorted({min(1, n_search - 1), max(0, n_search - 2)})
+    threads = max(4, min(32, len(os.sched_getaffinity(0))))
+    t0 = time.perf_counter()
+    for s_ in searches:
+        want = orc.acq_grid(sign_blocks_of(s_), n_ms, prns, DOPP_MIN + bins[0] * DOPP_STEP, (bins[1] - bins[0]) * DOPP_STEP, len(bins), 8,
+                            n_threads=threads)
+        fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+        want_keys = ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)
+        got = keys[s_][np.ix_(prns.astype(int) - 1, bins)]
+        if not np.array_equal(got, want_keys):
+            raise AssertionError(f"merged key table differs from the oracle in search {s_}: {got.tolist()} != {want_keys.tolist()}")
+    return {"parity_checked": True, "against": "CPU oracle (oracle/gpsx_oracle.c)", "searches": searches, "prns": prns.tolist(),
+            "doppler_bins": bins, "hypotheses_checked": len(searches) * len(prns) * len(bins) * 16368 * n_ms,
+            "seconds": time.perf_counter() - t0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,9 +377,16 @@ def main():
     ap.add_argument("--no-tracking", action="store_true",
                     help="skip the secondary metric (real-time tracking channels: E/P/L steps of growing channel counts)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default) = --searches captures PER GPU per step (N x the work); strong = the SAME --searches "
+                         "ten-block searches whatever N: their (search, Doppler, 8-PRN group) units dealt to the N ranks")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="N > 1: skip rank 0's check of the merged key table against the CPU oracle (outside the timed region)")
     args = ap.parse_args()
     if args.n_ms is None:
         args.n_ms = 1 if args.gpus == 1 else 10
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args)      # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run; does not return
 
     # (multi-process GPU work on this driver stack needs dmabuf IPC: RCCL's hipIpcGetMemHandle fails in legacy mode.  The
     #  image exports it; kept here for an environment that was built without it.)
@@ -380,7 +436,8 @@ def main():
                 "rccl_ranks": dist.get_world_size(), "devices": everyone,
                 "distinct_devices": len({(d["device_index"], d["uuid"], d["pci_bus_id"]) for d in everyone})}
 
-    n_search = args.searches * world
+    strong = args.scaling == "strong" and world > 1
+    n_search = args.searches if strong else args.searches * world
     # synthetic captures: consecutive milliseconds of one stream; identical on every rank (each rank reads all of it)
     n_ms = args.n_ms
     two_bit = args.if_format == "2bit"
@@ -527,6 +584,76 @@ def main():
             ten_block = {"error": repr(exc)}
             print(f"bench.py: ten-block leg failed: {exc!r}", file=sys.stderr, flush=True)
 
+    # north_star's letter: "wavefront reductions for the I/Q sums, no MFMA".  The default path above is the exact MX-FP4 Toeplitz
+    # GEMM on the matrix cores; this leg times the SAME launch (same captures, same grid, same outputs, bit for bit) on the
+    # library's vector-ALU form of the grid -- the polyphase popcount kernel, $GPSX_ACQ_ALGO=poly read when a context is created --
+    # so that both have a driver-timed number in the same line.
+    letter = None
+    if world == 1 and n_ms == 1 and not args.no_native:
+        try:
+            prev_algo = os.environ.get("GPSX_ACQ_ALGO")
+            os.environ["GPSX_ACQ_ALGO"] = "poly"
+            try:
+                eng_v = capi.Engine(dev_index, stream=stream.cuda_stream)
+            finally:
+                if prev_algo is None:
+                    os.environ.pop("GPSX_ACQ_ALGO", None)
+                else:
+                    os.environ["GPSX_ACQ_ALGO"] = prev_algo
+            if two_bit:
+                eng_v.set_if_format(capi.IF_2BIT_SM)
+            with torch.cuda.stream(stream):
+                v_keys, m_keys = torch.zeros_like(key_bufs[0]), torch.zeros_like(key_bufs[0])
+                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
+                                               m_keys.data_ptr(), None, None, None)     # the matrix-core path's table, afresh
+                assert rc == 0
+
+                def valu_step():
+                    rc = eng_v.lib.gpsx_acq_grid_dev(eng_v.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
+                                                     v_keys.data_ptr(), None, None, None)
+                    if rc != 0:
+                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng_v.lib.gpsx_last_error(eng_v.h).decode()}")
+                valu_step()
+                torch.cuda.synchronize()
+                v0, v1 = eng_v.event(), eng_v.event()
+                eng_v.record(v0)
+                for _ in range(4):
+                    valu_step()
+                eng_v.record(v1)
+                torch.cuda.synchronize()
+                v_ms = eng_v.elapsed_ms(v0, v1) / 4
+                v_kernel = eng_v.lib.gpsx_last_kernel(eng_v.h).decode()
+                same_keys = bool(torch.equal(v_keys, m_keys)) and int(v_keys.min()) > 0
+            eng_v.close()
+            v_rate = n_search * HYP_PER_SEARCH / (v_ms * 1e-3)
+            issued_per_hyp, src = None, None
+            kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
+            if os.path.exists(kc_file):
+                with open(kc_file) as f:
+                    for ent in json.load(f):
+                        if ent.get("kernel", "").startswith("k_acq_poly") and ent.get("SQ_INSTS_VALU") and ent.get("n_ms") == 1:
+                            issued_per_hyp = ent["SQ_INSTS_VALU"] * 64.0 / (ent["searches_per_launch"] * HYP_PER_SEARCH)
+                            src = ent.get("source")
+            letter = {"workload": "the headline launch (same captures, same grid) on the vector ALU: no MFMA",
+                      "value": v_rate, "unit": "hypotheses/s", "ms_per_launch": v_ms, "kernel": "gpsx::" + v_kernel,
+                      "keys_identical_to_the_matrix_core_path": same_keys,
+                      "roofline_valu": {"bound": "valu-int-issue", "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
+                                        "lane_ops_per_hyp_issued": issued_per_hyp, "counter_source": src,
+                                        "achieved": (issued_per_hyp * v_rate / 1e12) if issued_per_hyp else None,
+                                        "frac": (issued_per_hyp * v_rate / 1e12 / VALU_INT_PEAK_TOPS) if issued_per_hyp else None,
+                                        "lane_ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
+                                        "lane_ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF,
+                                        "note": "issued lane-ops per hypothesis from the committed PMC summary of this kernel (a 64-capture "
+                                                "launch; the count is linear in the captures) x this run's rate.  The reference's own "
+                                                "formulation (1024 xor + 1024 popcount per hypothesis) is 2048 lane-ops: the polyphase "
+                                                "recurrence does the same sums in a tenth of the operations, so 2048 x rate is not a "
+                                                "fraction of this kernel's roofline"}}
+            if not same_keys:
+                raise AssertionError("the vector-ALU path's key table differs from the matrix-core path's")
+        except Exception as exc:   # a secondary leg must not take the headline line with it
+            letter = {"error": repr(exc)}
+            print(f"bench.py: letter-compliant leg failed: {exc!r}", file=sys.stderr, flush=True)
+
     # PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
     # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
     # rotation through gpsx_acq_grid_async, so a call's transfers overlap the others' sweeps -- what a host streaming
@@ -588,6 +715,13 @@ def main():
     keys = d_keys.cpu().numpy()
     energy = keys >> 14
     assert (energy > 0).all() and energy.max() > 1500 * min(1.0, args.amp_scale), "acquisition grid produced no peaks"
+
+    parity = None
+    if use_dist and rank == 0 and not args.no_parity_check:
+        def sign_blocks_of(s_):
+            blk = dev_blocks.reshape(n_search * n_ms, -1)[s_ * n_ms:(s_ + 1) * n_ms]
+            return _sign_plane(blk) if two_bit else blk
+        parity = _parity_sample(keys, sign_blocks_of, n_search, n_ms)   # raises on a mismatch: no line is printed then
 
     if use_dist and os.environ.get("GPSX_BENCH_VERIFY") == "1":
         # the merged table must equal what one GPU computes for the whole grid (checked outside the timed region)
@@ -657,15 +791,18 @@ def main():
         dist.all_reduce(dtl, op=dist.ReduceOp.MAX)
         local_ref = {"value": reps_l * args.searches * n_ms * HYP_PER_SEARCH / float(dtl.item()), "unit": "hypotheses/s",
                      "ms_per_step": float(dtl.item()) / reps_l * 1e3,
-                     "note": f"per GPU: each rank sweeps {args.searches} captures x {n_ms} block(s) of its own, unsharded, no "
-                             "collective, all ranks at once (slowest rank); the job's `value` divided by n_gpus x this is "
-                             "what sharding + the all-reduce cost at this configuration"}
+                     "note": (f"ONE GPU on the whole job: every rank sweeps all {args.searches} searches x {n_ms} block(s) unsharded, no "
+                              "collective, all ranks at once (slowest rank); the job's `value` divided by this is the speed-up of "
+                              "the sharded, all-reduced run over one GPU (strong scaling)") if strong else
+                             (f"per GPU: each rank sweeps {args.searches} captures x {n_ms} block(s) of its own, unsharded, no "
+                              "collective, all ranks at once (slowest rank); the job's `value` divided by n_gpus x this is "
+                              "what sharding + the all-reduce cost at this configuration")}
 
     if rank == 0:
         total_hyp = float(args.steps) * n_search * n_ms * HYP_PER_SEARCH
         value = total_hyp / elapsed_s
         launch_ms = gpu_ms / args.steps                   # HIP events on the engine's stream around the K launches
-        hyp_per_launch = args.searches * n_ms * HYP_PER_SEARCH   # per GPU
+        hyp_per_launch = n_search * n_ms * HYP_PER_SEARCH / world   # per GPU
         kernel = headline_kernel
         # counters of this kernel and launch shape, from the committed rocprofv3 PMC summaries (tools/summarize_profile.py)
         counters = None
@@ -687,7 +824,6 @@ def main():
                     "ops_per_hyp_issued": issued / hyp_per_launch,
                     "ops_per_hyp_min_model": min_model,
                     "useful_frac": min_model * hyp_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
-                    "ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF,
                     "counter_source": counters.get("source"),
                     "note": "issued vector-ALU lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
                             "time) against one wave64 op per 4 cycles per SIMD (256 CU x 64 lanes/clk x 2.4 GHz); a few op "
@@ -780,7 +916,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_s / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u1 samples; MX-FP4 operands, exact f32 accumulation (integers < 2^24)" if is_mx else "u1 (bit planes; u32 popcount accumulators)",
             "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11; "
@@ -791,7 +927,7 @@ def main():
                              "(BASELINE.json configs[2])") if n_ms == 1 else
                             (f"32-PRN acquisition grid (21 Doppler x 16368 phases) with {n_ms} ms non-coherent integration "
                              "(BASELINE.json configs[3]); hypotheses counted per 1 ms block"),
-                "searches_per_gpu_per_step": args.searches,
+                "searches_per_gpu_per_step": n_search / world,
                 "hypotheses_per_step": n_search * n_ms * HYP_PER_SEARCH,
                 "blocks_per_search": n_ms,
                 "parallelism": f"(search, Doppler, 8-PRN group) units as {world} contiguous runs, one per rank; one "
@@ -811,6 +947,8 @@ def main():
                                               "(`serial`: one context, synchronous gpsx_acq_grid)"}
         if comm is not None:
             line["communicator"] = comm
+        if parity is not None:
+            line["parity"] = parity
         if single is not None:
             line["single_search"] = single
         if local_ref is not None:
@@ -819,6 +957,8 @@ def main():
             line["native_grid"] = native
         if ten_block is not None:
             line["configs3_one_gpu"] = ten_block
+        if letter is not None:
+            line["letter_compliant"] = letter
         if tracking is not None:
             line["tracking"] = tracking
         if not args.no_cpu_baseline and world == 1:

@@ -344,6 +344,11 @@ void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch);
 int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, int n_blocks, uint32_t first_tick,
                              int *changed_opt, int max_changed);
 
+/* not in the reference: what a reboot does to the firmware -- the step logic's file-scope state (start flag, need-acquisition
+ * flag, search buffers, slot statics, the pseudorange step's and the solver's memories, gps_sol, final_pos, obsd) back at its
+ * initial values, for a host that starts a second receiver run in the same process.  The channel table is the caller's. */
+void gpsx_compat_receiver_reset(void);
+
 /* not in the reference: release the default context (optional, for leak checkers) */
 void gpsx_compat_shutdown(void);
 

@@ -22,8 +22,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 
 #include "../../include/gpsx_compat.h"
+#include "gpsx_compat_internal.hpp"
 
 namespace {
 
@@ -158,6 +160,16 @@ int nav_step(gps_ch_t *ch, int n, uint32_t now)
 extern "C" {
 
 obsd_t obsd[GPS_SAT_CNT];
+
+}
+
+void gpsx_nav_master_reset()
+{
+  g_prev_calc_ms = 0;
+  std::memset(obsd, 0, sizeof obsd);
+}
+
+extern "C" {
 
 void gps_master_final_pseudorange_calc(gps_ch_t *channels, uint32_t curr_tick_time, uint32_t ref_time_diff_ms,
                                        uint32_t ref_time_ms, uint8_t ref_idx)

@@ -16,6 +16,7 @@
 #include <ctime>
 
 #include "../../include/gpsx_compat.h"
+#include "gpsx_compat_internal.hpp"
 
 namespace {
 
@@ -376,6 +377,19 @@ extern "C" {
 
 sol_t gps_sol;
 double final_pos[3];
+
+}
+
+void gpsx_pvt_reset()
+{
+  g_phase = 0;
+  std::memset(&gps_sol, 0, sizeof gps_sol);
+  std::memset(final_pos, 0, sizeof final_pos);
+  std::memset(g_azel, 0, sizeof g_azel);
+  std::memset(&g_nav, 0, sizeof g_nav);
+}
+
+extern "C" {
 
 const double *gpsx_pvt_azel(void) { return g_azel; }
 

@@ -1293,6 +1293,20 @@ __attribute__((weak)) uint8_t key_up_presed = 0;
 
 uint8_t gps_master_need_acq(void) { return g_need_acq; }
 
+// What a reboot does to the firmware: every file-scope variable of the receiver's step logic back at its initial value
+// (gps_master.c's start flag and need-acquisition flag, acquisition.c's search buffers, tracking.c / nav_data.c's slot
+// statics, the pseudorange step's and the solver's memories).  The channel table is the caller's.
+void gpsx_compat_receiver_reset(void)
+{
+  g_need_acq = 1;
+  g_start_flag = 1;
+  g_ticks = 0;
+  reset_search_buffers();
+  g_shared_slot = SlotState{};
+  gpsx_nav_master_reset();
+  gpsx_pvt_reset();
+}
+
 uint8_t gps_master_need_freq_search(gps_ch_t *channels)
 {
   uint8_t need = 0;

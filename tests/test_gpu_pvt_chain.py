@@ -34,29 +34,27 @@ def _orbit_signal():
     return _signal["v"]
 
 
-def test_if_samples_to_position_through_the_reference_named_calls():
-    """39 s of stream.  The channels get their Doppler as hints to the hertz (PM/main.c's table holds such hints; in the 17 ms
-    multiplex the reference's FLL does not pull a channel in from a 250 Hz bin edge) and the test signal's frames consist of
-    subframes 1, 2, 3 only: a channel whose Costas loop locked upside down needs two inverted preambles (12 s) before its
-    words parse, and every channel must hold all three subframes before the reference solves (gps_master.c:411-424) --
-    observed: the last channel completes at 36.1 s, the first position follows at 36.3 s, then two per second.
-    Bound, and why.  (a) One sample is 18.3 m of range and the reference's DLL settles up to 3 samples off the true code
-    phase, differently per channel (its replica is not circular and its odd byte offsets skip two words: tests of
-    round 1 already allow 1.5 samples on the 4-SV stream); (b) the reference's time-tag convention (tests/test_nav_master.py:
-    the satellites are placed ~69 ms early) moves ranges by up to 55 m; (c) PDOP 2.7, no redundancy with four satellites.
-    Observed on the GPU: 8 .. 26 m for the flow's own fixes, 68 .. 79 m for the same records with their time tags moved by
-    68.802 ms -- on this geometry the DLL's per-channel biases (alone worth those ~75 m) and the time-tag convention
-    (alone worth 76 m with perfect measurements) pull in opposite directions.  Asserted: every fix, either way, within
-    150 m of the truth; final_pos likewise."""
+_fix_cache = {}
+
+
+def _receiver(device: bool):
+    """PM/main.c's loop on the library.  device = False: gps_tracking_process in the 17-slot multiplex all the way (the host
+    mode).  device = True: the same until every channel is in GPS_TRACKING_RUN on a cycle start, then the channels live in the
+    device loop under GPSX_SCHED_MUX17 -- one launch per 17 ms cycle, the flag bytes through the word layer
+    (gps_tracking_words_batch), the states back into the records (gpsx_loop_state_to_channel), gps_master_handling's idle slot
+    on the records (pseudoranges, solver), and the code-phase averaging window reset on the device when the pseudorange step
+    consumed it (gpsx_loop_reset_code_filter).  Returns (table, fixes, acquired_at, handed_over_at, lib)."""
     from stm32f4_sdr_gps_amd import capi
     sats, stream, first = _orbit_signal()
-    lib = capi.load_library()
+    eng = capi.Engine(0) if device else None
+    lib = eng.lib if device else capi.load_library()
     lib.gps_master_handling.argtypes = [C.c_void_p, C.c_uint8]
     lib.acquisition_process.argtypes = [C.c_void_p, C.c_void_p]
     lib.gps_tracking_process.argtypes = [C.c_void_p, C.c_void_p, C.c_uint8]
     lib.gpsx_compat_set_packet_cnt.argtypes = [C.c_uint32]
-    lib.pntpos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.gps_fill_summ_table()
+    lib.gpsx_compat_receiver_reset()      # (a second receiver run in this process: the firmware's statics as after a reboot)
     table = (pc.GpsCh * 4)()
     for i, (raw, row) in enumerate(sats):
         table[i].prn = row["sat"]
@@ -67,26 +65,72 @@ def test_if_samples_to_position_through_the_reference_named_calls():
     obsd = (Obsd * 4).in_dll(lib, "obsd")
     lib.gpsx_compat_set_packet_cnt(0)
     lib.gps_master_handling(table, 0)
-    fixes, acquired_at = [], None
-    for t in range(N_MS):
-        lib.gpsx_compat_set_packet_cnt(t)
-        data = stream[t].ctypes.data
-        if lib.gps_master_need_acq():
-            lib.acquisition_process(table, data)
-            lib.gps_master_handling(table, 0)
-            if not lib.gps_master_need_acq():
-                acquired_at = t
-        else:
+    fixes, acquired_at, handed = [], None, None
+    st = np.zeros(4, capi.LOOP_DTYPE)
+    d_state = None
+
+    def idle_slot(t):
+        was_busy = lib.solving_is_busy()
+        lib.gps_master_handling(table, 0xFF)
+        if not was_busy and lib.solving_is_busy():      # a solution was just found
+            snap = (Obsd * 4)()
+            C.memmove(snap, obsd, C.sizeof(snap))
+            fixes.append((t, np.array(list(sol.rr)[:3]), snap))
+
+    try:
+        t = 0
+        while t < N_MS:
+            lib.gpsx_compat_set_packet_cnt(t)
+            data = stream[t].ctypes.data
+            if lib.gps_master_need_acq():
+                lib.acquisition_process(table, data)
+                lib.gps_master_handling(table, 0)
+                if not lib.gps_master_need_acq():
+                    acquired_at = t
+                t += 1
+                continue
             big = t % 17
+            if device and d_state is None and big == 0 and all(ch.tracking_data.state == 4 for ch in table):
+                for i in range(4):
+                    lib.gpsx_loop_state_from_channel(C.byref(table[i]), i + 1, st[i:i + 1].ctypes.data)
+                d_state = eng.malloc(st.nbytes)
+                eng.h2d(d_state, st)
+                eng.set_loop_schedule(capi.SCHED_MUX17)
+                handed = t
+            if d_state is not None:
+                k = min(17, N_MS - t)
+                flags, _ = eng.track_loop(stream[t:t + k], d_state, 4, t)
+                lib.gps_tracking_words_batch(table, 4, flags.ctypes.data, k, t, None, 0)
+                eng.d2h(st, d_state)
+                for i in range(4):
+                    lib.gpsx_loop_state_to_channel(st[i:i + 1].ctypes.data, C.byref(table[i]))
+                if k == 17:
+                    lib.gpsx_compat_set_packet_cnt(t + 16)
+                    idle_slot(t + 16)
+                    if any(table[i].tracking_data.code_filt_cnt != st["code_filt_cnt"][i] for i in range(4)):
+                        assert all(ch.tracking_data.code_filt_cnt == 0 and ch.tracking_data.code_phase_fine_filt == 0.0 for ch in table)
+                        assert lib.gpsx_loop_reset_code_filter(eng.h, d_state, 4) == 0
+                t += k
+                continue
             sat = big // 4 if big < 16 else 0
             index = 0xFF if big == 16 else big % 4
             lib.gps_tracking_process(C.byref(table[sat]), data, index)
-            was_busy = lib.solving_is_busy()
-            lib.gps_master_handling(table, index)
-            if index == 0xFF and not was_busy and lib.solving_is_busy():      # a solution was just found
-                snap = (Obsd * 4)()
-                C.memmove(snap, obsd, C.sizeof(snap))
-                fixes.append((t, np.array(list(sol.rr)[:3]), snap))
+            if index == 0xFF:
+                idle_slot(t)
+            else:
+                lib.gps_master_handling(table, index)
+            t += 1
+    finally:
+        if d_state is not None:
+            eng.free(d_state)
+        if eng is not None:
+            eng.close()
+    return table, fixes, acquired_at, handed, lib
+
+
+def _check_position(table, fixes, acquired_at, lib):
+    sats, stream, first = _orbit_signal()
+    lib.pntpos.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     assert acquired_at is not None and acquired_at < 3000, acquired_at
     for i, ch in enumerate(table):
         assert ch.tracking_data.state == 4, i
@@ -119,6 +163,45 @@ def test_if_samples_to_position_through_the_reference_named_calls():
         moved_errs.append(float(np.linalg.norm(np.array(list(s2.rr)[:3]) - RX)))
     print("with time tags + 68.802 ms:", [round(e, 1) for e in moved_errs])
     assert max(moved_errs) < 150.0, moved_errs
+
+
+def test_if_samples_to_position_through_the_reference_named_calls():
+    """39 s of stream.  The channels get their Doppler as hints to the hertz (PM/main.c's table holds such hints; in the 17 ms
+    multiplex the reference's FLL does not pull a channel in from a 250 Hz bin edge) and the test signal's frames consist of
+    subframes 1, 2, 3 only: a channel whose Costas loop locked upside down needs two inverted preambles (12 s) before its
+    words parse, and every channel must hold all three subframes before the reference solves (gps_master.c:411-424) --
+    observed: the last channel completes at 36.1 s, the first position follows at 36.3 s, then two per second.
+    Bound, and why.  (a) One sample is 18.3 m of range and the reference's DLL settles up to 3 samples off the true code
+    phase, differently per channel (its replica is not circular and its odd byte offsets skip two words: tests of
+    round 1 already allow 1.5 samples on the 4-SV stream); (b) the reference's time-tag convention (tests/test_nav_master.py:
+    the satellites are placed ~69 ms early) moves ranges by up to 55 m; (c) PDOP 2.7, no redundancy with four satellites.
+    Observed on the GPU: 8 .. 26 m for the flow's own fixes, 68 .. 79 m for the same records with their time tags moved by
+    68.802 ms -- on this geometry the DLL's per-channel biases (alone worth those ~75 m) and the time-tag convention
+    (alone worth 76 m with perfect measurements) pull in opposite directions.  Asserted: every fix, either way, within
+    150 m of the truth; final_pos likewise."""
+    table, fixes, acquired_at, _, lib = _receiver(device=False)
+    _fix_cache["host"] = [(t, p.copy()) for t, p, _ in fixes]
+    _fix_cache["host_records"] = bytes(table)
+    _check_position(table, fixes, acquired_at, lib)
+
+
+def test_if_samples_to_position_with_the_tracking_loops_on_the_device():
+    """The same receiver with the channels in the DEVICE loop from the first cycle start on which all four track (VERDICT r4
+    item 1: device-tracked channels deliver subframe time stamps, hence pseudoranges, hence a position): tracking, bit
+    synchronisation, bit-edge location and data polarity in k_track_loop under the reference's 17 ms multiplex, one launch per
+    cycle; words, ephemeris, pseudoranges and the solver on the host from the flag bytes and the states.  Same bounds as the
+    host mode -- and, because the device loop follows the reference bit for bit (tests/test_gpu_track_mux.py), the same fixes
+    at the same milliseconds and the same final channel records as the host mode's, byte for byte, when that test ran before
+    this one."""
+    table, fixes, acquired_at, handed, lib = _receiver(device=True)
+    assert handed is not None and handed < acquired_at + 1500, (acquired_at, handed)
+    print("handed to the device loop at ms", handed)
+    _check_position(table, fixes, acquired_at, lib)
+    if "host" in _fix_cache:
+        assert [t for t, _, _ in fixes] == [t for t, _ in _fix_cache["host"]]
+        for (_, p, _), (_, q) in zip(fixes, _fix_cache["host"]):
+            assert np.array_equal(p, q)
+        assert bytes(table) == _fix_cache["host_records"]
 
 
 def test_device_loops_track_satellites_on_orbits_and_decode_their_ephemerides():
