@@ -55,3 +55,45 @@ def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode,
         want = oracle.acq_grid(blocks[s_ * n_ms:(s_ + 1) * n_ms], n_ms, prns, -5000, 500, 21, 8, n_threads=threads)
         fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
         assert np.array_equal(keys[s_], ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)), s_
+
+
+@pytest.mark.parametrize("scaling, port", [("strong", 0), ("weak", 0)])
+def test_plain_python_launch_two_ranks(scaling, port, tmp_path, oracle):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its own two ranks under
+    torch.distributed.run on a free port.  strong: the SAME six ten-block searches dealt to the two ranks (units as two
+    contiguous runs); weak: six per rank.  Inside the run rank 0 compares cells of the merged table with the CPU oracle
+    (`parity` in the line); here the merged table is compared with an unsharded sweep (GPSX_BENCH_VERIFY) and other cells of it
+    with the oracle."""
+    import numpy as np
+    from stm32f4_sdr_gps_amd import synth
+    dump = str(tmp_path / "merged_keys.npy")
+    env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1", GPSX_BENCH_DUMP_KEYS=dump)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--searches", "6",
+           "--scaling", scaling, "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "VERIFY sharded == unsharded" in res.stdout
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    n_search = 6 if scaling == "strong" else 12
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["config"]["blocks_per_search"] == 10
+    assert line["config"]["hypotheses_per_step"] == n_search * 10 * 32 * 21 * 16368
+    assert line["config"]["searches_per_gpu_per_step"] == n_search / 2
+    assert line["parity"]["parity_checked"] is True and line["parity"]["hypotheses_checked"] == 2 * 16 * 16368 * 10
+    assert line["communicator"]["rccl_ranks"] == 2 and line["single_search"]["ms_per_search"] > 0
+    keys = np.load(dump)
+    assert keys.shape == (n_search, 32, 21)
+    s_ = n_search // 2
+    blocks = synth.cold_start_block(n_search * 10, seed=11, amp_scale=0.25)[s_ * 10:(s_ + 1) * 10]
+    prns = np.array([5, 14, 27], np.uint8)
+    want = oracle.acq_grid(blocks, 10, prns, -5000, 10000, 2, 8, n_threads=max(4, min(32, len(os.sched_getaffinity(0)))))
+    fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+    assert np.array_equal(keys[s_][np.ix_(prns.astype(int) - 1, [0, 20])], ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2))
+
+
+def test_plain_python_launch_refuses_more_ranks_than_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPSX_BENCH_SHARE_DEVICE")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert res.returncode != 0 and "GPU(s) visible" in res.stderr
