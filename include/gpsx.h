@@ -365,6 +365,18 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
 #define GPSX_SCHED_MUX17    1
 int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule);
 
+/* Where the false-lock detector's random carrier jump (PM/GPS/tracking.c:309-326) draws from.
+ *   GPSX_DRAWS_XORSHIFT (default)  the channel's own xorshift32 (`rng`): any number of channels, nothing leaves the device.
+ *   GPSX_DRAWS_LIBC  the reference's: libc's rand(), drawn on the host in the order a single-threaded loop over the
+ *       milliseconds and channels makes the draws -- so a receiver that seeds as the reference does jumps where the reference
+ *       jumps (tests/test_gpu_track_loop.py: the 64-channel trace with its 21 jumps).  A launch whose channels want to jump is
+ *       run twice for those channels (they report, the host draws, they are replayed from the launch's input state); launches
+ *       are limited to 320 ms and gpsx_track_loop_dev WAITS for its kernels in this mode.  rand() is process-global: the
+ *       caller seeds it (and see INTEGRATION.md on the ROCm runtime's own draws when code objects load). */
+#define GPSX_DRAWS_XORSHIFT 0
+#define GPSX_DRAWS_LIBC     1
+int gpsx_loop_set_draws(gpsx_ctx *ctx, int draws);
+
 #define GPSX_WORDSYNC_DEVICE 0
 #define GPSX_WORDSYNC_HOST   1
 int gpsx_loop_set_word_sync(gpsx_ctx *ctx, int owner);

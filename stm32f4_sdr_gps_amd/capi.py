@@ -25,6 +25,7 @@ PHASES_FINE = 16368
 IF_HZ = 4092000
 SCHED_EVERY_MS, SCHED_MUX17 = 0, 1
 WORDSYNC_DEVICE, WORDSYNC_HOST = 0, 1
+DRAWS_XORSHIFT, DRAWS_LIBC = 0, 1
 
 LOOP_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"), ("if_freq_accum", "<u4"),
                        ("dll_code_err", "<f4"), ("pll_code_err", "<f4"), ("fll_err", "<f4"), ("fll_old_i", "<i2"),
@@ -110,6 +111,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_loop_reset_code_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.gpsx_loop_set_schedule.argtypes = [C.c_void_p, C.c_int]
     lib.gpsx_loop_set_word_sync.argtypes = [C.c_void_p, C.c_int]
+    lib.gpsx_loop_set_draws.argtypes = [C.c_void_p, C.c_int]
     lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.gpsx_loop_state_from_channel.restype = None
@@ -404,6 +406,10 @@ class Engine:
     def set_loop_schedule(self, schedule: int) -> None:
         """SCHED_EVERY_MS or SCHED_MUX17 (the reference's four-channel 17 ms multiplex) for this context's track_loop launches"""
         self._chk(self.lib.gpsx_loop_set_schedule(self.h, schedule), "gpsx_loop_set_schedule")
+
+    def set_loop_draws(self, draws: int) -> None:
+        """DRAWS_XORSHIFT (default) or DRAWS_LIBC (the reference's rand(), drawn on the host in the reference's order)"""
+        self._chk(self.lib.gpsx_loop_set_draws(self.h, draws), "gpsx_loop_set_draws")
 
     def set_loop_word_sync(self, owner: int) -> None:
         """WORDSYNC_DEVICE (default: the kernel decides the data polarity itself) or WORDSYNC_HOST (gpsx_loop_set_polarity only)"""

@@ -234,6 +234,11 @@ void gpsx_destroy(gpsx_ctx *ctx)
   }
   if (ctx->h_bad_prn)
     (void)hipHostFree(ctx->h_bad_prn);
+  if (ctx->h_loop_n_events)
+    (void)hipHostFree(ctx->h_loop_n_events);
+  if (ctx->d_loop_reseeds) (void)hipFree(ctx->d_loop_reseeds);
+  if (ctx->d_loop_events) (void)hipFree(ctx->d_loop_events);
+  if (ctx->d_loop_chmap) (void)hipFree(ctx->d_loop_chmap);
   if (ctx->own_stream && ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1073,6 +1078,101 @@ int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule)
   return GPSX_OK;
 }
 
+int gpsx_loop_set_draws(gpsx_ctx *ctx, int draws)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  if (draws != GPSX_DRAWS_XORSHIFT && draws != GPSX_DRAWS_LIBC)
+    return fail(ctx, GPSX_EINVAL, "unknown source of false-lock draws");
+  ctx->loop_draws = draws;
+  return GPSX_OK;
+}
+
+namespace {
+
+// One launch of the device loops.  GPSX_DRAWS_XORSHIFT: enqueue and return.  GPSX_DRAWS_LIBC (the reference's own
+// draws, PM/GPS/tracking.c:309-326): first pass with an empty candidate table -- a channel whose false-lock detector fires
+// reports (channel, millisecond, its carrier) and stands still, its state in HBM untouched; the host draws for the reported
+// jumps in the order a single-threaded loop over the milliseconds and channels makes them (libc's rand(), the `do ... while`
+// of the reference with its int16 arithmetic); second pass over the reported channels only, one per wave, from the launch's
+// input state, with the candidates in the table.  A channel jumps at most once in 81 four-millisecond groups, hence the
+// launch-length limit; the passes are repeated should a replayed channel report again.  Waits for its kernels.
+int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
+                   uint32_t first_tick, uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
+{
+  const int word_sync = ctx->loop_word_sync == GPSX_WORDSYNC_DEVICE;
+  if (ctx->loop_draws != GPSX_DRAWS_LIBC) {
+    launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick,
+                      ctx->loop_schedule, word_sync, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, d_bad_prn, nullptr, 0, nullptr,
+                      nullptr, nullptr);
+    LAUNCHCHK(ctx, "k_track_loop");
+    return GPSX_OK;
+  }
+  if (n_blocks > 320)
+    return fail(ctx, GPSX_EINVAL, "GPSX_DRAWS_LIBC: at most 320 ms per launch (a channel can jump once per 324 ms)");
+  if (ctx->loop_draws_capacity < n_ch) {
+    if (ctx->d_loop_reseeds) (void)hipFree(ctx->d_loop_reseeds);
+    if (ctx->d_loop_events) (void)hipFree(ctx->d_loop_events);
+    if (ctx->d_loop_chmap) (void)hipFree(ctx->d_loop_chmap);
+    ctx->d_loop_reseeds = nullptr; ctx->d_loop_events = nullptr; ctx->d_loop_chmap = nullptr;
+    ctx->loop_draws_capacity = 0;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_reseeds, (size_t)n_ch * sizeof(gpsx_loop_reseed_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_events, (size_t)n_ch * sizeof(gpsx_loop_event_t)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_chmap, (size_t)n_ch * sizeof(int)));
+    ctx->loop_draws_capacity = n_ch;
+  }
+  if (!ctx->h_loop_n_events) {
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_loop_n_events, sizeof(uint32_t), hipHostMallocMapped));
+    HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->d_loop_n_events, ctx->h_loop_n_events, 0));
+  }
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_loop_reseeds, 0xFF, (size_t)n_ch * sizeof(gpsx_loop_reseed_t), ctx->stream));   // ms = -1: none
+  *ctx->h_loop_n_events = 0;
+  launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick,
+                    ctx->loop_schedule, word_sync, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, d_bad_prn, nullptr, 0,
+                    ctx->d_loop_reseeds, ctx->d_loop_events, ctx->d_loop_n_events);
+  LAUNCHCHK(ctx, "k_track_loop");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<gpsx_loop_event_t> ev;
+  std::vector<gpsx_loop_reseed_t> cand;
+  std::vector<int> chans;
+  for (int pass = 0; *ctx->h_loop_n_events; pass++) {
+    const uint32_t n = *ctx->h_loop_n_events;
+    if (pass >= 4 || n > (uint32_t)n_ch)
+      return fail(ctx, GPSX_EIO, "GPSX_DRAWS_LIBC: the false-lock replay does not settle");
+    ev.resize(n);
+    HIPCHK(ctx, hipMemcpyAsync(ev.data(), ctx->d_loop_events, n * sizeof(gpsx_loop_event_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::sort(ev.begin(), ev.end(), [](const gpsx_loop_event_t &a, const gpsx_loop_event_t &b) {
+      return a.ms != b.ms ? a.ms < b.ms : a.channel < b.channel;
+    });
+    cand.resize(n);
+    chans.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+      int16_t delta, candidate;
+      do {   // tracking.c:313-324, its types
+        const uint16_t r = (uint16_t)(std::rand() % 500);   // ACQ_SEARCH_STEP_HZ
+        candidate = (int16_t)(ev[i].found_freq_hz - r + 250);
+        delta = (int16_t)((int16_t)ev[i].if_freq_i16 - candidate);
+      } while (std::abs((int)delta) < 200);
+      cand[i] = gpsx_loop_reseed_t{ev[i].ms, candidate};
+      chans[i] = ev[i].channel;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->d_loop_reseeds + ev[i].channel, &cand[i], sizeof(gpsx_loop_reseed_t), hipMemcpyHostToDevice,
+                                 ctx->stream));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_loop_chmap, chans.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *ctx->h_loop_n_events = 0;
+    launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick,
+                      ctx->loop_schedule, word_sync, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, d_bad_prn, ctx->d_loop_chmap,
+                      (int)n, ctx->d_loop_reseeds, ctx->d_loop_events, ctx->d_loop_n_events);
+    LAUNCHCHK(ctx, "k_track_loop");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GPSX_OK;
+}
+
+}  // namespace
+
 int gpsx_loop_set_word_sync(gpsx_ctx *ctx, int owner)
 {
   if (!ctx)
@@ -1090,10 +1190,9 @@ int gpsx_track_loop_dev(gpsx_ctx *ctx, const void *d_if_blocks, int n_blocks, gp
   if (!d_if_blocks || !d_state || !d_flags || n_ch < 1 || n_blocks < 1)
     return fail(ctx, GPSX_EINVAL, "null/empty argument");
   const size_t blk_bytes = ctx->if_format == GPSX_IF_2BIT_SM ? GPSX_BYTES_PER_MS_2BIT : GPSX_BYTES_PER_MS;
-  launch_track_loop(ctx->stream, static_cast<const uint8_t *>(d_if_blocks), (uint32_t)blk_bytes, n_blocks, ctx->if_format,
-                    ctx->if_hz, d_state, n_ch, first_tick_ms, ctx->loop_schedule, ctx->loop_word_sync == GPSX_WORDSYNC_DEVICE, ctx->d_bits_all, ctx->d_trk_rep,
-                    d_flags, d_trace_opt, ctx->d_bad_prn + 1);
-  LAUNCHCHK(ctx, "k_track_loop");
+  if (int rc = run_track_loop(ctx, static_cast<const uint8_t *>(d_if_blocks), blk_bytes, n_blocks, d_state, n_ch, first_tick_ms,
+                              d_flags, d_trace_opt, ctx->d_bad_prn + 1))
+    return rc;
   ctx->last_kernel = "k_track_loop";
   return GPSX_OK;
 }
@@ -1118,9 +1217,8 @@ int gpsx_track_loop(gpsx_ctx *ctx, const uint8_t *if_blocks, int n_blocks, gpsx_
     d_if = d_if_copy;
   }
   ctx->h_bad_prn[0] = 0;   // (flag 0: this entry point waits for its kernel, as gpsx_track_epl_batch does)
-  launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick_ms,
-                    ctx->loop_schedule, ctx->loop_word_sync == GPSX_WORDSYNC_DEVICE, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, ctx->d_bad_prn);
-  LAUNCHCHK(ctx, "k_track_loop");
+  if (int rc = run_track_loop(ctx, d_if, blk_bytes, n_blocks, d_state, n_ch, first_tick_ms, d_flags, d_trace, ctx->d_bad_prn))
+    return rc;
   ctx->last_kernel = "k_track_loop";
   HIPCHK(ctx, hipMemcpyAsync(flags, d_flags, n_rec, hipMemcpyDeviceToHost, ctx->stream));
   if (trace_opt)

@@ -50,6 +50,13 @@ struct gpsx_ctx {
   int if_format = GPSX_IF_1BIT;
   int loop_schedule = GPSX_SCHED_EVERY_MS;   // gpsx_loop_set_schedule
   int loop_word_sync = GPSX_WORDSYNC_DEVICE; // gpsx_loop_set_word_sync
+  int loop_draws = GPSX_DRAWS_XORSHIFT;      // gpsx_loop_set_draws
+  // GPSX_DRAWS_LIBC: per-channel candidate table, event list, channel list of the second pass (grow-only), event counter (mapped)
+  gpsx::gpsx_loop_reseed_t *d_loop_reseeds = nullptr;
+  gpsx::gpsx_loop_event_t *d_loop_events = nullptr;
+  int *d_loop_chmap = nullptr;
+  int loop_draws_capacity = 0;
+  uint32_t *h_loop_n_events = nullptr, *d_loop_n_events = nullptr;
   int if_hz = GPSX_IF_HZ;             // gpsx_config_t.if_hz
   int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: the matrix-core kernel, at every launch size) | poly |
                                            // dot8 | sad, for A/B measurements and the parity tests of the alternative kernels

@@ -140,10 +140,14 @@ void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, i
                       uint32_t *d_bad_prn, int wave_from);
 constexpr int kTrackRepStride = 1032;   // words per PRN row of d_trk_rep
 void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n_slots, uint32_t *d_rep);
+// GPSX_DRAWS_LIBC (include/gpsx.h): a channel's false-lock jump reported by the first pass / its carrier candidate for the second
+struct gpsx_loop_event_t { int32_t channel, ms, if_freq_i16, found_freq_hz; };
+struct gpsx_loop_reseed_t { int32_t ms, candidate; };   // ms < 0: none
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, int word_sync,
                        const uint32_t *d_chipbits, const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace,
-                       uint32_t *d_bad_prn);
+                       uint32_t *d_bad_prn, const int *d_ch_map, int n_map, const gpsx_loop_reseed_t *d_reseeds,
+                       gpsx_loop_event_t *d_events, uint32_t *d_n_events);
 void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int *d_channels, const uint8_t *d_values, int n);
 constexpr int kTrackPadPrn = -2147483647 - 1;   // gpsx_trk_state_t.prn of a padding channel: the empty code, not an error
 // N3: 2-bit sign/magnitude samples -> two 1-bit planes

@@ -112,8 +112,9 @@ __device__ __forceinline__ void loop_pll(gpsx_loop_state_t &s, int IP, int QP)
   s.pll_code_err = phase_err;
 }
 
-// gps_tracking_pll_check; true = the carrier was moved
-__device__ __forceinline__ bool loop_false_lock(gpsx_loop_state_t &s, Quad16 &chk, int index, int IP)
+// gps_tracking_pll_check's bookkeeping; true = the carrier must jump (counters already cleared, as the reference clears them
+// before it draws)
+__device__ __forceinline__ bool loop_false_lock_detect(gpsx_loop_state_t &s, Quad16 &chk, int index, int IP)
 {
   chk.set(index, IP);
   if (index < 3)
@@ -140,8 +141,13 @@ __device__ __forceinline__ bool loop_false_lock(gpsx_loop_state_t &s, Quad16 &ch
     return false;
   s.pll_bad_state_master_cnt = 0;
   s.pll_bad_state_cnt = 0;
-  // a random carrier offset around the acquired one, at least 200 Hz from where the loop stands (tracking.c:309-326);
-  // the draws come from the channel's own xorshift32 -- libc's rand() is one sequence per PROCESS
+  return true;
+}
+
+// the jump: a random carrier offset around the acquired one, at least 200 Hz from where the loop stands (tracking.c:309-326);
+// the draws come from the channel's own xorshift32 (GPSX_DRAWS_XORSHIFT) -- libc's rand() is one sequence per PROCESS
+__device__ __forceinline__ void loop_false_lock_jump(gpsx_loop_state_t &s)
+{
   int16_t candidate;
   int delta;
   u32 x = s.rng ? s.rng : 0x9E3779B9u;
@@ -156,7 +162,6 @@ __device__ __forceinline__ bool loop_false_lock(gpsx_loop_state_t &s, Quad16 &ch
   s.rng = x;
   s.reseed_count++;
   s.if_freq_offset_hz = (float)candidate;
-  return true;
 }
 
 __device__ __forceinline__ float atan_ratio(int q, int i)   // the reference's (i == 0) ? pi / 2 : atanf((float)q / (float)i)
@@ -415,14 +420,23 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
                                                     int if_format, int if_hz, gpsx_loop_state_t *__restrict__ st, int n_ch, int cpw,
                                                     u32 first_tick, const u32 *__restrict__ chipbits_all,
                                                     const u32 *__restrict__ rep_all, uint8_t *__restrict__ flags,
-                                                    gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn, int word_sync)
+                                                    gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn, int word_sync,
+                                                    const int *__restrict__ ch_map, int n_map,
+                                                    const gpsx_loop_reseed_t *__restrict__ reseeds,
+                                                    gpsx_loop_event_t *__restrict__ events, u32 *__restrict__ n_events)
 {
   __shared__ u32 s_x[2][512];        // this and the next millisecond's sign plane: one barrier per millisecond
   __shared__ uint2 s_carrier[4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int c_l = lane >> 2, k_l = lane & 3;
   int n_here, ch_l;                  // channels of this wave (0: an idle wave of the last workgroup still stages blocks)
-  if (MUX) {
+  int slot = wave;                   // MUX: the slot of the receiver's 17 ms cycle this wave's channels are served in
+  if (ch_map) {                      // the second pass of GPSX_DRAWS_LIBC: one listed channel per wave
+    const int v = (int)blockIdx.x * 4 + wave;
+    n_here = v < n_map ? 1 : 0;
+    ch_l = n_here ? ch_map[v] : 0;
+    slot = ch_l & 3;
+  } else if (MUX) {
     const int first = (int)blockIdx.x * 4 * cpw + wave;   // the wave's channels: first, first + 4, ...
     n_here = first < n_ch ? min(cpw, (n_ch - first + 3) >> 2) : 0;
     ch_l = first + 4 * (c_l < n_here ? c_l : 0);
@@ -440,6 +454,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
     prn = track_prn(s.prn, bad_prn, mine && k_l == 0);
   }
   Quad16 chk = quad16_load(s.pll_check_buf), sip = quad16_load(s.slot_ip);
+  bool stalled = false;
 
 #pragma unroll 1
   for (int ms = 0; ms < n_blocks; ms++) {
@@ -452,7 +467,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
     int index = (int)(now & 3u);
     if (MUX) {
       const u32 big = now % (u32)(kSlotMs * kSlots + 1);   // PM/main.c:139-152
-      if (big == (u32)(kSlotMs * kSlots) || (int)(big / (u32)kSlotMs) != wave) {
+      if (big == (u32)(kSlotMs * kSlots) || (int)(big / (u32)kSlotMs) != slot) {
         // not this wave's slot (or the cycle's idle millisecond): nothing of the channel moves
         if (in_wave && k_l == 0) {
           flags[(size_t)ms * n_ch + ch_l] = 0;
@@ -488,7 +503,29 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
     loop_dll(s, IE, QE, IL, QL);
     if (index == 0)
       loop_pll(s, IP, QP);
-    const bool moved = loop_false_lock(s, chk, index, IP);
+    bool moved = false;
+    if (loop_false_lock_detect(s, chk, index, IP)) {
+      if (!events) {
+        loop_false_lock_jump(s);
+        moved = true;
+      } else {
+        // GPSX_DRAWS_LIBC: the draw is the host's (libc's rand(), in the reference's order).  First pass: report and stop
+        // advancing this channel -- its state in HBM stays the launch's input; second pass: the host's candidate for this
+        // millisecond is in the table.
+        const gpsx_loop_reseed_t r = reseeds[ch_l];
+        if (r.ms == ms) {
+          s.reseed_count++;
+          s.if_freq_offset_hz = (float)(int16_t)r.candidate;
+          moved = true;
+        } else if (!stalled) {
+          stalled = true;
+          if (in_wave && k_l == 0) {
+            const u32 e = atomicAdd(n_events, 1u);
+            events[e] = gpsx_loop_event_t{ch_l, ms, (int)(int16_t)s.if_freq_offset_hz, (int)s.found_freq_offset_hz};
+          }
+        }
+      }
+    }
     loop_fll(s, index, IP, QP);
     u32 flag = nav_bit_sync(s, sip, index, IP, now, word_sync != 0);
     loop_snr(s, IP, QP);
@@ -505,7 +542,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
       }
     }
   }
-  if (in_wave && k_l == 0) {
+  if (in_wave && k_l == 0 && !stalled) {
     quad16_store(chk, s.pll_check_buf);
     quad16_store(sip, s.slot_ip);
     st[ch_l] = s;
@@ -530,19 +567,22 @@ void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int 
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, int word_sync,
                        const uint32_t *d_chipbits, const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace,
-                       uint32_t *d_bad_prn)
+                       uint32_t *d_bad_prn, const int *d_ch_map, int n_map, const gpsx_loop_reseed_t *d_reseeds,
+                       gpsx_loop_event_t *d_events, uint32_t *d_n_events)
 {
-  if (n_ch <= 0 || n_blocks <= 0)
+  if (n_ch <= 0 || n_blocks <= 0 || (d_ch_map && n_map <= 0))
     return;
   int cpw = n_ch / (4 * 256 * 4);   // as launch_track_epl: ~4 workgroups per CU, 16 channels per wave at most
   cpw = cpw < 1 ? 1 : (cpw > 16 ? 16 : cpw);
-  const dim3 grid((n_ch + 4 * cpw - 1) / (4 * cpw));
+  const dim3 grid(d_ch_map ? (n_map + 3) / 4 : (n_ch + 4 * cpw - 1) / (4 * cpw));
   if (schedule == GPSX_SCHED_MUX17)
     hipLaunchKernelGGL(k_track_loop<true>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
-                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync);
+                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync, d_ch_map, n_map, d_reseeds,
+                       d_events, d_n_events);
   else
     hipLaunchKernelGGL(k_track_loop<false>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
-                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync);
+                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync, d_ch_map, n_map, d_reseeds,
+                       d_events, d_n_events);
 }
 
 }  // namespace gpsx

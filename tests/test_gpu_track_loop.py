@@ -361,3 +361,97 @@ def test_device_loop_from_random_loop_states_equals_the_host_mode(eng):
                 continue       # (not part of gps_ch_t / floats, compared above)
             assert np.array_equal(final[f][same], host[f][same]), (name, f, np.flatnonzero(final[f][same] != host[f][same])[:5])
         assert (final["reseed_count"] == 0).all()
+
+
+_LIBC_DRAWS_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+k = int(sys.argv[2])
+import steps_driver as sd
+from golden_util import fnv1a32, load
+from stm32f4_sdr_gps_amd import capi, synth
+g = load("f7_steps_config5_64ch.npz")
+n_ms, t_hand = int(g["n_ms"]), 200
+sats, chans, seed = sd.config5_64ch_scenario()
+stream = synth.make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+assert fnv1a32(stream[::97]) == int(g["stream_fnv"])
+lib = capi.load_library()
+steps = sd.StepsLib(lib, False)
+lib.gps_tracking_process_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint8]
+lib.gps_tracking_process_batch.restype = None
+lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
+lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+lib.gpsx_loop_state_to_channel.argtypes = [C.c_void_p, C.c_void_p]
+# every kernel of the path once on another context, THEN srand(1): the ROCm runtime draws from rand() when code objects load
+warm = capi.Engine(0)
+jobs = np.zeros(1, capi.JOB_DTYPE); jobs[0] = (0, 1, 5, capi.IF_HZ + 900.0, 0, 0, 2046)
+warm.acq_jobs(stream[:1], jobs)
+st = np.zeros(64, capi.TRK_DTYPE); st["prn"] = 1 + np.arange(64) % 32
+warm.track_epl(stream[0], st); warm.rewind(st, np.full(64, 3, np.uint8))
+wl = np.zeros(4, capi.LOOP_DTYPE); wl["prn"] = 1; wl["rng"] = 1
+wd = warm.malloc(wl.nbytes); warm.h2d(wd, wl)
+warm.set_loop_draws(capi.DRAWS_LIBC); warm.track_loop(stream[:2], wd, 4, 0)
+warm.free(wd); warm.close()
+lib.gps_fill_summ_table()
+C.CDLL("libc.so.6").srand(1)
+table = np.stack([sd.preset_channel(steps, *c) for c in chans])
+for t in range(t_hand):
+    steps.set_time(t)
+    lib.gps_tracking_process_batch(table.ctypes.data, len(chans), stream[t].ctypes.data, t & 3)
+    assert np.array_equal(sd.snapshot_crcs(table), g["crcs"][t]), t
+state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+idx = np.flatnonzero(state == sd.TRK_RUN)
+assert len(idx) == 62
+sub = np.ascontiguousarray(table[idx])
+n = len(idx)
+eng = capi.Engine(0)
+eng.set_loop_draws(capi.DRAWS_LIBC)
+st = np.zeros(n, capi.LOOP_DTYPE)
+for i in range(n):
+    lib.gpsx_loop_state_from_channel(sub[i].ctypes.data, i + 1, st[i:i + 1].ctypes.data)
+d = eng.malloc(st.nbytes); eng.h2d(d, st)
+jumps = []
+checked = 0
+t = t_hand
+while t < n_ms:
+    kk = min(k, n_ms - t)
+    flags, _ = eng.track_loop(stream[t:t + kk], d, n, t)
+    lib.gps_tracking_words_batch(sub.ctypes.data, n, flags.ctypes.data, kk, t, None, 0)
+    eng.d2h(st, d)
+    for i in range(n):
+        lib.gpsx_loop_state_to_channel(st[i:i + 1].ctypes.data, sub[i].ctypes.data)
+    for ms, c in np.argwhere(flags & 16):
+        jumps.append((t + int(ms), int(idx[c])))
+    t += kk
+    bad = np.flatnonzero(sd.snapshot_crcs(sub) != g["crcs"][t - 1][idx])
+    if len(bad):
+        print("MISMATCH after ms", t - 1, "channels", idx[bad][:8].tolist(), "jumps so far", jumps[-4:])
+        sys.exit(1)
+    checked += 1
+assert np.array_equal(sd.snapshot(sub), g["final"][idx])
+assert sorted(jumps) == sorted(map(tuple, g["reseeds"].tolist())), jumps
+assert int(st["reseed_count"].sum()) == len(g["reseeds"])
+print("RESULT", checked, len(jumps), len(set(c for _, c in jumps)))
+eng.free(d); eng.close()
+"""
+
+
+@pytest.mark.parametrize("k", [1, 20, 64])
+def test_device_loop_with_the_references_own_false_lock_draws(k):
+    """GPSX_DRAWS_LIBC against the reference's 64-channel trace (tests/golden/f7_steps_config5_64ch.npz: 1500 ms, 21 false-lock
+    jumps on 14 channels, three of them in the same millisecond, drawn from libc's rand() after srand(1)): the library's host
+    mode takes the channels through pre-tracking; at tick 200 the 62 tracking channels move into the device loop (launches of
+    k ms).  A channel whose detector fires reports and stands still, the host draws in (millisecond, channel) order, the
+    reported channels are replayed from the launch's input state with their candidates -- and every channel's 226 state bytes
+    carry the reference's CRC after every launch (k = 1: after every millisecond), the jumps are the reference's 21 at the
+    reference's milliseconds.  In a process of its own: rand() is process-global."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LIBC_DRAWS_SCRIPT, root, str(k)], capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert r.returncode == 0 and line, (r.stdout[-1500:], r.stderr[-1500:])
+    f = line[0].split()
+    assert int(f[1]) == -(-1300 // k) and f[2:] == ["21", "14"]
