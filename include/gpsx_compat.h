@@ -234,9 +234,14 @@ void     gps_master_final_pseudorange_calc(gps_ch_t *channels, uint32_t curr_tic
 uint16_t gps_master_filter_code_phase(gps_ch_t *channels, uint32_t curr_tick_time);
 void     gps_master_code_phase_filter_reset(gps_ch_t *channels, uint32_t curr_tick_time);
 void     gps_master_calculate_pos(gps_ch_t *channels);
-/* not in the reference: the same step (without the position call) for a table of n_ch channels.  1 = pseudoranges and
- * reception times renewed, 0 = filter window not ready, -1 = subframe epochs not there yet. */
+/* not in the reference: the same step (without the position call) for ONE receiver of n_ch channels served in the reference's
+ * multiplex (channel i of the table 4 i ms into the cycle).  1 = pseudoranges and reception times renewed, 0 = filter window
+ * not ready, -1 = subframe epochs not there yet. */
 int      gpsx_nav_pseudoranges(gps_ch_t *channels, int n_ch, uint32_t now_ms);
+/* ... and for a receiver that is a subset of a large table: channels index[0 .. n), position k of the list served
+ * k * slot_ms ms into the cycle (4 = the reference's multiplex; 0 = every channel on the same millisecond).  The epoch, the
+ * averaging window and the wrap bookkeeping are the subset's own: other channels of the table neither hold it up nor restart it. */
+int      gpsx_nav_pseudoranges_subset(gps_ch_t *channels, const int *index, int n, uint32_t now_ms, uint32_t slot_ms);
 
 /* NOT in the reference: one tracking step of n_ch channels on the same millisecond, each channel served every
  * millisecond as in the single-satellite firmware's schedule (project_single_sat/main.c:96-109; index cycles 0..3).

@@ -1664,9 +1664,12 @@ void gps_tracking_process_batch(gps_ch_t *channel, int n_ch, uint8_t *data, uint
 // millisecond (preamble hunt, parity, polarity, subframe assembly, ephemeris decode, subframe time stamp -- all as in
 // the host mode), then a located bit edge is written into the channel's nav_data (what the NEXT stamp is made from, as
 // nav_data.c orders them).  The bit synchroniser's own state lives on the device; of it the host record keeps
-// period_sync_ok_flag, accurate_swap_time / _ok and inv_polarity_flag current.  Channels whose inv_polarity_flag changed
-// are listed in changed_opt (at most max_changed; returns how many): the caller hands them to gpsx_loop_set_polarity,
-// because the device votes on polarity-corrected signs (nav_data.c:60-66).  From kStepThreadsFrom channels on: worker threads.
+// period_sync_ok_flag, accurate_swap_time / _ok and inv_polarity_flag current.  Channels whose inv_polarity_flag is different
+// after the launch from what it was before are listed in changed_opt, each once, in channel order (at most max_changed are
+// written; the return value is how many there are, at most n_ch).  Under GPSX_WORDSYNC_DEVICE the device's own word sync has
+// taken the same decisions on the same milliseconds and the list is information; under GPSX_WORDSYNC_HOST the caller hands
+// it to gpsx_loop_set_polarity, and the change reaches the device's votes (nav_data.c:60-66) with the next launch.
+// From kStepThreadsFrom channels on: worker threads.
 int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, int n_blocks, uint32_t first_tick,
                              int *changed_opt, int max_changed)
 {
@@ -1680,10 +1683,15 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
   static std::vector<std::vector<int>> changed;
   if ((int)changed.size() < n_workers)
     changed.resize(n_workers);
+  static std::vector<uint8_t> before;
+  if ((int)before.size() < n_ch)
+    before.resize(n_ch);
   auto work = [&](int w) {
     std::vector<int> &mine = changed[w];
     mine.clear();
     const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
+    for (int c = lo; c < hi; c++)
+      before[c] = channel[c].nav_data.inv_polarity_flag;
     t_tick_valid = true;
     for (int ms = 0; ms < n_blocks; ms++) {
       const uint8_t *f = flags + (size_t)ms * n_ch;
@@ -1696,12 +1704,8 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
         n.period_sync_ok_flag = (v & 8) ? 1 : 0;
         if ((v & (2 | 32)) == 0)
           continue;
-        if (v & 2) {
-          const uint8_t before = n.inv_polarity_flag;
+        if (v & 2)
           gps_nav_data_words_detection(&channel[c], (uint8_t)((v >> 2) & 1));
-          if (n.inv_polarity_flag != before && (mine.empty() || mine.back() != c))
-            mine.push_back(c);
-        }
         if (v & 32) {
           n.accurate_swap_time = (uint8_t)((t_tick - 3u + ((v & 64) ? 2u : 1u)) % 20u);
           n.accurate_swap_ok = 1;
@@ -1709,6 +1713,9 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
       }
     }
     t_tick_valid = false;
+    for (int c = lo; c < hi; c++)   // listed once, and only if the launch left the flag different from how it found it
+      if (channel[c].nav_data.inv_polarity_flag != before[c])
+        mine.push_back(c);
   };
   pool.run(n_workers, work);
   int total = 0;

@@ -217,7 +217,7 @@ for t0 in range(0, n_ms, K):
     for ms in range(K):
         t = t0 + ms
         for c in range(n):
-            f = 8                                             # bit period synchronised
+            f = 128 | 8                                       # served this millisecond; bit period synchronised
             k = (t - offset[c]) // 20                         # the bit that completes at this millisecond
             if (t - offset[c]) % 20 == 0 and k >= 1:
                 bit = int(streams[c][k - 1]) ^ int(inverted[c]) ^ int(inv_dev[c])
@@ -336,3 +336,44 @@ def test_pseudorange_step_epoch_bookkeeping_branch_by_branch(lib):
     assert lib.gpsx_nav_pseudoranges(t, 4, 12500) == 1
     assert abs(t[0].obs_data.pseudorange_m - (68.802 + 1000.0 / 16368.0) * c_ms) < 1e-6
     assert abs(t[2].obs_data.pseudorange_m - (68.802 + 0 + 3000.0 / 16368.0) * c_ms) < 1e-6
+
+
+def test_pseudorange_step_on_receivers_inside_a_large_table(lib):
+    """gpsx_nav_pseudoranges_subset: 75 receivers of four channels in one 300-channel table.  Each receiver's step
+    gives what gpsx_nav_pseudoranges gives on a four-channel copy of it; a receiver whose channel never got a stamp, and one
+    whose code phase wrapped inside the window, neither hold up nor restart the others; the reference satellite may sit beyond
+    index 255 (the reference's uint8_t index is its four-entry table's); slot_ms = 0 takes the multiplex's 4 ms per position
+    out of the reception times."""
+    lib.gpsx_nav_pseudoranges_subset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32]
+    n_rx = 75
+    big = (pc.GpsCh * (4 * n_rx))()
+    small = []
+    for r in range(n_rx):
+        t = _plain_table(lib)
+        for i in range(4):                                   # every receiver its own stamps; the LAST channel the earliest
+            t[i].nav_data.last_subframe_time = 12070 + 3 * (3 - i) + r % 5
+            t[i].nav_data.first_subframe_time = 6070 + 3 * (3 - i) + r % 5
+            t[i].eph_data.tow_gpst = 388812.0 + i
+        if r == 10:
+            t[2].nav_data.last_subframe_time = 0             # never stamped
+        if r == 20:
+            t[1].tracking_data.code_phase_fine_filt = -1.0   # the DLL's wrap mark
+        small.append(t)
+        for i in range(4):
+            C.memmove(C.byref(big[4 * r + i]), C.byref(t[i]), C.sizeof(pc.GpsCh))
+    for r in range(n_rx):
+        idx = (C.c_int * 4)(*range(4 * r, 4 * r + 4))
+        got = lib.gpsx_nav_pseudoranges_subset(big, idx, 4, 12500, 4)
+        want = lib.gpsx_nav_pseudoranges(small[r], 4, 12500)
+        assert got == want == (-1 if r == 10 else 0 if r == 20 else 1), r
+        for i in range(4):
+            assert bytes(big[4 * r + i]) == bytes(small[r][i]), (r, i)
+    ch = big[4 * 70 + 3]      # the reference satellite of receiver 70: table index 283
+    assert abs(big[4 * 70].obs_data.tow_s - (ch.eph_data.tow_gpst + (12500 - ch.nav_data.last_subframe_time - 150) / 1e3)) < 1e-4
+    assert big[4 * 20].tracking_data.filt_start_time_ms == 12500 and big[4 * 21].tracking_data.code_filt_cnt == 0   # restarted / consumed
+    # every channel on the same millisecond: the list position adds nothing to the reception time
+    t = _plain_table(lib)
+    idx = (C.c_int * 4)(0, 1, 2, 3)
+    assert lib.gpsx_nav_pseudoranges_subset(t, idx, 4, 12500, 0) == 1
+    assert all(abs(ch.obs_data.tow_s - (388812.0 + (12500 - 12070 - 150) / 1e3)) < 1e-6 for ch in t)
+    assert lib.gpsx_nav_pseudoranges_subset(t, (C.c_int * 2)(0, -1), 2, 12500, 4) == -1
