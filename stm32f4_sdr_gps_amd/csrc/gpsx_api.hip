@@ -614,6 +614,9 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
       ctx->last_kernel = launch_acq_mx(ctx->stream, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_mx_a,
                                        ctx->d_grid_mx_t, d_peaks, ctx->d_energy, mx_blocks, gpsx_acq_peaks_count(g), d_planes,
                                        ctx->prop.multiProcessorCount, &keys_done);
+      if (d_planes && hipPeekAtLastError() != hipSuccess)
+        ctx->acc_entries = 0;   // a launch between the split and finalize kernels failed: the planes may hold partial sums --
+                                // the next use allocates and zeroes them afresh (ensure_acc)
       LAUNCHCHK(ctx, "k_acq_mx");
       if (d_keys && !keys_done) {
         launch_acq_keys(ctx->stream, d_peaks, d_keys, g->n_search, g->n_prn, n_groups, g->n_dopp, n_bits, (int)unit_lo,
@@ -660,6 +663,8 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
     ctx->last_kernel = launch_acq_poly(ctx->stream, local_units, prm, static_cast<const uint8_t *>(d_if_blocks), ctx->d_grid_cw8,
                     ctx->d_grid_bits, ctx->d_acc, ctx->d_acc + n_peaks, n_peaks, d_peaks, shard_count > 1,
                     ctx->d_energy, block_parallel, ctx->seg_force);
+    if (hipPeekAtLastError() != hipSuccess)
+      ctx->acc_entries = 0;     // (as above: stale partial sums must not reach the next call)
     LAUNCHCHK(ctx, "k_acq_poly");
   } else {
     const int algo = ctx->algo == kAlgoSad ? kAlgoSad : kAlgoDot8;

@@ -2099,6 +2099,8 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
                        d_peaks, (u32 *)nullptr, (u32 *)nullptr);
     AcqParams sp = prm;
     sp.split_segs = 8 * tail <= n_cus ? 8 : 4 * tail <= n_cus ? 4 : 2;
+    if (prm.split_segs && prm.split_segs * tail <= n_cus)   // $GPSX_ACQ_SPLIT here too, as long as the tail still fits one round
+      sp.split_segs = prm.split_segs;
     sp.n_planes = n_peaks;
     // the planes of the tail's peaks only: from the first peak of the search the tail begins in
     const int n_sets = (prm.n_groups + 3) / 4;

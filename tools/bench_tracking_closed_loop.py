@@ -38,7 +38,38 @@ def _cpu_throttle():
         return None
 
 
-def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=True, literal=False):
+def _realtime_thread():
+    """What a real-time host does for its per-millisecond thread, as far as this container lets it: resident pages
+    (mlockall(MCL_CURRENT)) and the FIFO scheduling class, so that another tenant's runnable thread does not take the CPU in the
+    middle of a step.  Returns what took (a shared box usually refuses the scheduling class: reported, not hidden) and a
+    function that undoes it."""
+    out = {"mlockall_current": False, "sched": "SCHED_OTHER"}
+    libc = C.CDLL("libc.so.6", use_errno=True)
+    try:
+        out["mlockall_current"] = libc.mlockall(1) == 0                     # MCL_CURRENT
+        if not out["mlockall_current"]:
+            out["mlockall_errno"] = C.get_errno()
+    except Exception as exc:   # noqa: BLE001
+        out["mlockall_error"] = repr(exc)
+    try:
+        os.sched_setscheduler(0, os.SCHED_FIFO, os.sched_param(10))
+        out["sched"] = "SCHED_FIFO 10"
+    except (PermissionError, OSError) as exc:
+        out["sched_refused"] = repr(exc)
+
+    def undo():
+        try:
+            os.sched_setscheduler(0, os.SCHED_OTHER, os.sched_param(0))
+        except Exception:   # noqa: BLE001
+            pass
+        try:
+            libc.munlockall()
+        except Exception:   # noqa: BLE001
+            pass
+    return out, undo
+
+
+def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=True, literal=False, realtime_thread=False):
     """literal: SURVEY.md 8(d) config 5 to the letter -- one signal per channel at -5000 + 39 i Hz exactly (no 7 Hz offset),
     synthesised by synth.make_if_static (the stream tests/golden/f7_steps_config5_256ch.npz was recorded on when channels =
     256 and ms = 10000: the reference's own lock count on it is reported beside the engine's)."""
@@ -75,6 +106,9 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
         delay = np.array(sig_delay)[np.arange(n) % n_sig]
         lat = np.zeros(ms)
         n_trk = np.zeros(ms, np.int64)
+        rt_setup, rt_undo = (None, None)
+        if realtime_thread and n < 2048:      # (one stepping thread below 2048 channels: only that case is raised to FIFO)
+            rt_setup, rt_undo = _realtime_thread()
         thr0 = _cpu_throttle()
         t_start = time.perf_counter()
         for t in range(ms):
@@ -88,6 +122,8 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
             lib.gps_tracking_process_batch(table.ctypes.data, n, blk.ctypes.data, t & 3)
             lat[t] = time.perf_counter() - s
         behind = time.perf_counter() - t_start - ms * 1e-3
+        if rt_undo:
+            rt_undo()
         thr1 = _cpu_throttle()
         fine = table[:, 60 + 80:60 + 84].copy().view("<f4")[:, 0]
         freq = table[:, 60 + 4:60 + 8].copy().view("<f4")[:, 0]
@@ -111,7 +147,7 @@ def closed_loop(channels=256, ms=2000, amp=0.12, signals=0, bind=True, paced=Tru
                 "cpu_quota_throttled_ms_during_run": None if not (thr0 and thr1) else (thr1[1] - thr0[1]) / 1e3,
                 "cpu_quota_throttled_periods_during_run": None if not (thr0 and thr1) else thr1[0] - thr0[0],
                 "host_workers": int(lib.gps_tracking_batch_workers()) if n >= 2048 else 1,
-                "thread_on_gpu_numa_node": bool(bound),
+                "thread_on_gpu_numa_node": bool(bound), "realtime_thread": rt_setup,
                 "p50_us": float(np.percentile(steady, 50) * 1e6), "p99_us": float(np.percentile(steady, 99) * 1e6),
                 "max_us": float(steady.max() * 1e6), "steps_over_1ms": late,
                 "slowest_steady_steps_ms": [int(i) + ms // 2 for i in np.argsort(steady)[::-1][:4]],
