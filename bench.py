@@ -29,7 +29,7 @@ Prints one JSON line on rank 0.  `roofline` prices the resource of the kernel th
   k_acq_mx<3> (n_ms > 1): the running sums' round trip through HBM: bound "hbm", achieved = 4 B per hypothesis and block
     (16-bit records) x (n_ms - 1) / n_ms / launch time, `traffic` = what rocprofv3 counted; the matrix-pipe fraction of
     the same launch is reported beside it (`roofline_mfma`);
-  k_acq_poly (GPSX_ACQ_ALGO=poly, round 1's kernel): integer VALU issue.
+  k_acq_poly (gpsx_set_acq_path(GPSX_ACQ_PATH_VECTOR), round 1's kernel): integer VALU issue.
 The reference-equivalent operand stream (6138 B/hypothesis as the reference re-reads its operands) is
 kept as information only.  `cpu_baseline` times the reference's own C (oracle/_ref, built in place from the reference
 tree) -- or the CPU oracle port when that build is absent -- on a bounded sample.  `tracking` is BASELINE.json's second
@@ -607,20 +607,13 @@ def main():
 
     # north_star's letter: "wavefront reductions for the I/Q sums, no MFMA".  The default path above is the exact MX-FP4 Toeplitz
     # GEMM on the matrix cores; this leg times the SAME launch (same captures, same grid, same outputs, bit for bit) on the
-    # library's vector-ALU form of the grid -- the polyphase popcount kernel, $GPSX_ACQ_ALGO=poly read when a context is created --
+    # library's vector-ALU form of the grid -- the polyphase popcount kernel, gpsx_set_acq_path(GPSX_ACQ_PATH_VECTOR) --
     # so that both have a driver-timed number in the same line.
     letter = None
     if world == 1 and n_ms == 1 and not args.no_native:
         try:
-            prev_algo = os.environ.get("GPSX_ACQ_ALGO")
-            os.environ["GPSX_ACQ_ALGO"] = "poly"
-            try:
-                eng_v = capi.Engine(dev_index, stream=stream.cuda_stream)
-            finally:
-                if prev_algo is None:
-                    os.environ.pop("GPSX_ACQ_ALGO", None)
-                else:
-                    os.environ["GPSX_ACQ_ALGO"] = prev_algo
+            eng_v = capi.Engine(dev_index, stream=stream.cuda_stream)
+            eng_v.set_acq_path(capi.ACQ_PATH_VECTOR)
             if two_bit:
                 eng_v.set_if_format(capi.IF_2BIT_SM)
             with torch.cuda.stream(stream):

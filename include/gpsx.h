@@ -85,6 +85,18 @@ int         gpsx_version(void);
 /* name / CU count / clock of the device behind the context (for bench reports) */
 int         gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *compute_units, int *clock_khz);
 
+/* Which hardware the fine acquisition grid (gpsx_acq_grid*, GPSX_PHASES_FINE) runs on.  Both give the same triplets and keys,
+ * bit for bit (tests/test_gpu_parity.py; bench.py's letter_compliant leg compares the key tables of a whole 256-capture launch).
+ *   GPSX_ACQ_PATH_MATRIX (default)  the exact MX-FP4 Toeplitz GEMM on the matrix cores (k_acq_mx)
+ *   GPSX_ACQ_PATH_VECTOR            bit planes, v_and + v_bcnt polyphase recurrence, wave reductions on the vector ALU
+ *                                   (k_acq_poly): no MFMA, about a sixth of the rate */
+#define GPSX_ACQ_PATH_MATRIX 0
+#define GPSX_ACQ_PATH_VECTOR 1
+int gpsx_set_acq_path(gpsx_ctx *ctx, int path);
+/* 0 for lib/libgpsx.so.  1 for lib/libgpsx_lab.so, the same sources built with -DGPSX_LAB: it additionally reads the
+ * $GPSX_ACQ_* / $GPSX_TRACK_WAVE_FROM knobs that force kernel forms (tests of the alternative kernels, A/B timing). */
+int gpsx_is_lab_build(void);
+
 /* Sample format of the IF blocks passed to gpsx_acq_* and gpsx_track_* from now on (default GPSX_IF_1BIT). */
 int gpsx_set_if_format(gpsx_ctx *ctx, int if_format);
 /* Split n_blocks x 4092 bytes of GPSX_IF_2BIT_SM samples into the sign and magnitude bit planes, each n_blocks x 2046

@@ -16,6 +16,7 @@ import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libgpsx.so")
+LAB_LIB_PATH = os.path.join(PKG, "lib", "libgpsx_lab.so")
 
 BYTES_PER_MS = 2046
 BYTES_PER_MS_2BIT = 4092
@@ -26,6 +27,7 @@ IF_HZ = 4092000
 SCHED_EVERY_MS, SCHED_MUX17 = 0, 1
 WORDSYNC_DEVICE, WORDSYNC_HOST = 0, 1
 DRAWS_XORSHIFT, DRAWS_LIBC = 0, 1
+ACQ_PATH_MATRIX, ACQ_PATH_VECTOR = 0, 1
 
 LOOP_DTYPE = np.dtype([("prn", "<i4"), ("code_phase_fine", "<f4"), ("if_freq_offset_hz", "<f4"), ("if_freq_accum", "<u4"),
                        ("dll_code_err", "<f4"), ("pll_code_err", "<f4"), ("fll_err", "<f4"), ("fll_old_i", "<i2"),
@@ -67,10 +69,16 @@ class GpsxError(RuntimeError):
 CAPTURE_BLOCK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_long)   # gpsx_capture_block_fn
 
 
-def load_library() -> C.CDLL:
-    if not os.path.exists(LIB_PATH):
-        raise GpsxError(f"{LIB_PATH} is missing: run `python -m stm32f4_sdr_gps_amd.build` (needs hipcc)")
-    lib = C.CDLL(LIB_PATH)
+def load_library(lab: bool | None = None) -> C.CDLL:
+    """lib/libgpsx.so -- or, lab=True (or $GPSX_USE_LAB_LIBRARY=1 when lab is None): lib/libgpsx_lab.so, the same sources
+    built with -DGPSX_LAB, the only build that reads the $GPSX_ACQ_* / $GPSX_TRACK_WAVE_FROM knobs forcing a kernel form."""
+    if lab is None:
+        lab = os.environ.get("GPSX_USE_LAB_LIBRARY") == "1"
+    path = LAB_LIB_PATH if lab else LIB_PATH
+    if not os.path.exists(path):
+        raise GpsxError(f"{path} is missing: run `python -m stm32f4_sdr_gps_amd.build` (needs hipcc)")
+    lib = C.CDLL(path)
+    assert lib.gpsx_is_lab_build() == (1 if lab else 0)
     lib.gpsx_last_error.restype = C.c_char_p
     lib.gpsx_strerror.restype = C.c_char_p
     lib.gpsx_last_kernel.restype = C.c_char_p
@@ -112,6 +120,7 @@ def load_library() -> C.CDLL:
     lib.gpsx_loop_set_schedule.argtypes = [C.c_void_p, C.c_int]
     lib.gpsx_loop_set_word_sync.argtypes = [C.c_void_p, C.c_int]
     lib.gpsx_loop_set_draws.argtypes = [C.c_void_p, C.c_int]
+    lib.gpsx_set_acq_path.argtypes = [C.c_void_p, C.c_int]
     lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.gpsx_loop_state_from_channel.restype = None
@@ -183,8 +192,8 @@ def _ptr(a):
 class Engine:
     """One gpsx context.  `stream` may be a raw hipStream_t handle (int), e.g. torch.cuda.current_stream().cuda_stream."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
-        self.lib = load_library()
+    def __init__(self, device: int = 0, stream: int | None = None, lab: bool | None = None):
+        self.lib = load_library(lab)
         h = C.c_void_p()
         rc = self.lib.gpsx_create(C.byref(h), device, C.c_void_p(stream) if stream else None)
         if rc != 0:
@@ -406,6 +415,10 @@ class Engine:
     def set_loop_schedule(self, schedule: int) -> None:
         """SCHED_EVERY_MS or SCHED_MUX17 (the reference's four-channel 17 ms multiplex) for this context's track_loop launches"""
         self._chk(self.lib.gpsx_loop_set_schedule(self.h, schedule), "gpsx_loop_set_schedule")
+
+    def set_acq_path(self, path: int) -> None:
+        """ACQ_PATH_MATRIX (default) or ACQ_PATH_VECTOR (no MFMA: the polyphase popcount kernel)"""
+        self._chk(self.lib.gpsx_set_acq_path(self.h, path), "gpsx_set_acq_path")
 
     def set_loop_draws(self, draws: int) -> None:
         """DRAWS_XORSHIFT (default) or DRAWS_LIBC (the reference's rand(), drawn on the host in the reference's order)"""

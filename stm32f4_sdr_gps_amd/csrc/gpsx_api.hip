@@ -143,6 +143,9 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
     delete ctx;
     return GPSX_ENODEV;
   }
+#ifdef GPSX_LAB
+  // lib/libgpsx_lab.so only (csrc/Makefile; the product library is built without GPSX_LAB and reads none of these): forced
+  // kernel forms for the parity tests of the alternative kernels and for A/B measurements
   if (const char *sg = std::getenv("GPSX_ACQ_SEG")) {
     const int v = std::atoi(sg);
     ctx->seg_force = (v == 4 || v == 8 || v == 16) ? v : 0;
@@ -164,6 +167,7 @@ int gpsx_create(gpsx_ctx **out, int device, void *stream)
   }
   if (ctx->seg_force && ctx->algo == kAlgoMx)
     ctx->algo = kAlgoPoly;   // $GPSX_ACQ_SEG names a form of the polyphase kernel: it selects that kernel too
+#endif
   if (stream) {
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
   } else {
@@ -554,6 +558,9 @@ int gpsx_acq_grid_dev(gpsx_ctx *ctx, const gpsx_acq_grid_t *g, const void *d_if_
   prm.win_stop = g->win_stop;
   prm.if_format = ctx->if_format;
   prm.if_hz = ctx->if_hz;
+#if defined(GPSX_MX_ABLATIONS) && !defined(GPSX_LAB)
+#error "GPSX_MX_ABLATIONS builds wrong-result timing variants: with -DGPSX_LAB only (tools/build_variant.sh), never into lib/libgpsx.so"
+#endif
 #ifdef GPSX_MX_ABLATIONS   // timing ablations of k_acq_mx (results are then wrong): tools/build_variant.sh -DGPSX_MX_ABLATIONS only
   {
     static const char *ex = std::getenv("GPSX_MX_EXPERIMENT");
@@ -1080,6 +1087,25 @@ int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule)
   if (schedule != GPSX_SCHED_EVERY_MS && schedule != GPSX_SCHED_MUX17)
     return fail(ctx, GPSX_EINVAL, "unknown serving schedule");
   ctx->loop_schedule = schedule;
+  return GPSX_OK;
+}
+
+int gpsx_is_lab_build(void)
+{
+#ifdef GPSX_LAB
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+int gpsx_set_acq_path(gpsx_ctx *ctx, int path)
+{
+  if (!ctx)
+    return GPSX_EINVAL;
+  if (path != GPSX_ACQ_PATH_MATRIX && path != GPSX_ACQ_PATH_VECTOR)
+    return fail(ctx, GPSX_EINVAL, "unknown acquisition path");
+  ctx->algo = path == GPSX_ACQ_PATH_VECTOR ? kAlgoPoly : kAlgoMx;
   return GPSX_OK;
 }
 

@@ -45,6 +45,11 @@
 // for k_acq_vals_search; 4 the byte-phase grid (sample offsets 0 and 8, each started directly from its own block sums; one
 // persistent workgroup per CU runs its clusters as ONE software pipeline: mx_byte_pipe); 5 small launches: 2 / 4 / 8 workgroups per cluster, each started directly
 // at its own sample offset (mx_direct_terms: every quirk term as a start value), results merged through global planes.
+#if !defined(GPSX_LAB) && (defined(WALK_ABL_NO_LOAD) || defined(WALK_ABL_NO_STORE) || defined(GPSX_MX_ABLATIONS) || \
+                           defined(GPSX_MX_NO_PIECES) || defined(GPSX_MX_TIMELINE) || defined(MX_BUILD_BEHIND) || defined(GPSX_MX_NT) || \
+                           defined(MX_VARIANT_B))
+#error "timing ablations / instrumented variants of k_acq_mx (some give wrong results) build with -DGPSX_LAB only: tools/build_variant.sh"
+#endif
 #include <cstdlib>
 
 #include "gpsx_device.hpp"

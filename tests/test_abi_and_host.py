@@ -240,3 +240,30 @@ def test_loop_state_conversion_round_trips_and_touches_only_the_loops_fields(lib
     assert int(st["prev_track_timestamp"][0]) == int(rec[60 + 76:60 + 80].view("<u4")[0])
     for lo, hi in ((0, 4), (12, 76), (84, 89), (136, 140), (148, 152)):
         assert np.array_equal(back[60 + lo:60 + hi], rec[60 + lo:60 + hi] ^ 0xFF), (lo, hi)
+
+
+def test_product_and_lab_builds_and_no_register_spills(lib_path):
+    """lib/libgpsx.so is the product: built without GPSX_LAB, it reads none of the $GPSX_ACQ_* / $GPSX_TRACK_WAVE_FROM knobs that
+    force a kernel form (the getenv block is not compiled into it) and cannot carry the wrong-result timing ablations
+    (k_acq_mx.hip / gpsx_api.hip refuse those macros without GPSX_LAB).  lib/libgpsx_lab.so is the same sources with the knobs.
+    And no instance of the matrix-core grid kernel spills registers (k_acq_mx<3> sits at 255 VGPRs)."""
+    import ctypes as C
+    import os
+    import subprocess
+
+    from stm32f4_sdr_gps_amd import build
+    lab_path = os.path.join(os.path.dirname(lib_path), "libgpsx_lab.so")
+    assert C.CDLL(lib_path).gpsx_is_lab_build() == 0 and C.CDLL(lab_path).gpsx_is_lab_build() == 1
+    strings = subprocess.check_output(["strings", "-a", lib_path], text=True)
+    lab_strings = subprocess.check_output(["strings", "-a", lab_path], text=True)
+    for knob in ("GPSX_ACQ_ALGO", "GPSX_ACQ_SEG", "GPSX_ACQ_SPLIT", "GPSX_ACQ_NO_SPLIT", "GPSX_ACQ_MS_MODE", "GPSX_TRACK_WAVE_FROM",
+                 "GPSX_MX_EXPERIMENT"):
+        assert knob not in strings, knob
+    assert "GPSX_ACQ_ALGO" in lab_strings and "GPSX_MX_EXPERIMENT" not in lab_strings
+    mx = build.check_no_scratch()
+    assert len(mx) == 6 and all(v["scratch_bytes"] == 0 and v["vgprs"] <= 256 for v in mx.values())
+    # the ablation macros do not compile into a product object
+    src = os.path.join(os.path.dirname(os.path.dirname(lib_path)), "csrc", "k_acq_mx.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DGPSX_MX_NO_PIECES", src],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "GPSX_LAB" in r.stderr

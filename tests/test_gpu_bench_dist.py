@@ -29,6 +29,8 @@ def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode,
         env["GPSX_ACQ_MS_MODE"] = ms_mode
     if algo:
         env["GPSX_ACQ_ALGO"] = algo
+    if ms_mode or algo:
+        env["GPSX_USE_LAB_LIBRARY"] = "1"       # forced kernel forms: the lab build of the library reads those knobs
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--searches", str(searches), "--no-cpu-baseline"] + (["--n-ms", "1"] if n_ms == 1 else [])

@@ -39,7 +39,7 @@ def eng_wg():
     old = os.environ.get("GPSX_TRACK_WAVE_FROM")
     os.environ["GPSX_TRACK_WAVE_FROM"] = str(1 << 30)
     try:
-        e = capi.Engine(0)
+        e = capi.Engine(0, lab=True)
     finally:
         if old is None:
             del os.environ["GPSX_TRACK_WAVE_FROM"]
@@ -330,7 +330,7 @@ def test_byte_phase_grid_persistent_workgroups_two_prn_sets_and_two_bit_if(oracl
     kw = dict(n_search=6, dopp_min_hz=-7000, dopp_step_hz=500, n_dopp=29, phase_mode=capi.PHASES_BYTE)
     e = capi.Engine(0)
     monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
-    ref = capi.Engine(0)
+    ref = capi.Engine(0, lab=True)
     monkeypatch.delenv("GPSX_ACQ_ALGO")
     try:
         e.set_if_format(capi.IF_2BIT_SM)
@@ -356,7 +356,7 @@ def test_byte_phase_grid_pipeline_random_descriptors(monkeypatch):
     rng = np.random.default_rng(4242)
     e = capi.Engine(0)
     monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
-    ref = capi.Engine(0)
+    ref = capi.Engine(0, lab=True)
     monkeypatch.delenv("GPSX_ACQ_ALGO")
     try:
         for trial in range(8):
@@ -403,7 +403,7 @@ def test_byte_phase_grid_pipeline_depths(oracle, monkeypatch, n_search, win, sha
         kw["shard"] = shard
     e = capi.Engine(0)
     monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
-    ref = capi.Engine(0)
+    ref = capi.Engine(0, lab=True)
     monkeypatch.delenv("GPSX_ACQ_ALGO")
     try:
         pk, keys = e.acq_grid(blocks, prns, **kw)
@@ -950,7 +950,7 @@ def test_alternative_grid_kernels_match_the_oracle(oracle, stream, algo, monkeyp
     monkeypatch.setenv(var, val)
     if algo in ("mx2", "mx4", "mx8"):      # the split form at two / four / eight workgroups per cluster, whatever the launch size
         monkeypatch.setenv("GPSX_ACQ_SPLIT", algo[2])
-    alt = capi.Engine(0)
+    alt = capi.Engine(0, lab=True)
     monkeypatch.delenv(var)
     try:
         prns = _ALT_PRNS
@@ -987,7 +987,7 @@ def eng_poly():
     old = os.environ.get("GPSX_ACQ_ALGO")
     os.environ["GPSX_ACQ_ALGO"] = "poly"
     try:
-        e = capi.Engine(0)
+        e = capi.Engine(0, lab=True)
     finally:
         if old is None:
             del os.environ["GPSX_ACQ_ALGO"]
@@ -1008,7 +1008,7 @@ def eng_mx():
     os.environ["GPSX_ACQ_ALGO"] = "mx"
     os.environ["GPSX_ACQ_NO_SPLIT"] = "1"
     try:
-        e = capi.Engine(0)
+        e = capi.Engine(0, lab=True)
     finally:
         for k, v in old.items():
             if v is None:
@@ -1323,7 +1323,7 @@ def test_both_multi_block_forms_match_the_oracle(oracle, stream, mode, algo, mon
     from stm32f4_sdr_gps_amd import capi
     monkeypatch.setenv("GPSX_ACQ_MS_MODE", mode)
     monkeypatch.setenv("GPSX_ACQ_ALGO", algo)
-    e = capi.Engine(0)
+    e = capi.Engine(0, lab=True)
     monkeypatch.delenv("GPSX_ACQ_MS_MODE")
     monkeypatch.delenv("GPSX_ACQ_ALGO")
     try:
@@ -1403,7 +1403,7 @@ def test_walk_form_16_bit_running_sums_overflow_falls_back_exactly(oracle, strea
     from stm32f4_sdr_gps_amd import capi
     monkeypatch.setenv("GPSX_ACQ_MS_MODE", "walk")
     monkeypatch.setenv("GPSX_ACQ_ALGO", "mx")
-    e = capi.Engine(0)
+    e = capi.Engine(0, lab=True)
     monkeypatch.delenv("GPSX_ACQ_MS_MODE")
     monkeypatch.delenv("GPSX_ACQ_ALGO")
     try:
@@ -1633,7 +1633,7 @@ def test_last_partly_filled_round_of_a_launch_goes_to_the_split_form(n, oracle, 
     from stm32f4_sdr_gps_amd import capi, synth
     e = capi.Engine(0)
     monkeypatch.setenv("GPSX_ACQ_NO_SPLIT", "1")
-    plain = capi.Engine(0)
+    plain = capi.Engine(0, lab=True)
     monkeypatch.delenv("GPSX_ACQ_NO_SPLIT")
     try:
         assert e.device_info()[1] == 256
@@ -1697,3 +1697,33 @@ def test_chunk_callback_may_not_reenter_its_context_and_its_exceptions_reach_the
     finally:
         e.close()
         other.close()
+
+
+def test_the_product_library_ignores_the_lab_knobs(stream, monkeypatch):
+    """lib/libgpsx.so with $GPSX_ACQ_ALGO / $GPSX_ACQ_NO_SPLIT / $GPSX_ACQ_MS_MODE set runs what it runs without them; the public
+    selector gpsx_set_acq_path is how a host chooses the vector-ALU path, and both paths give the same bytes."""
+    from stm32f4_sdr_gps_amd import capi
+    prns = np.arange(1, 33, dtype=np.uint8)
+    kw = dict(n_search=2, dopp_min_hz=-1000, dopp_step_hz=500, n_dopp=5)
+    base = capi.Engine(0)
+    monkeypatch.setenv("GPSX_ACQ_ALGO", "dot8")
+    monkeypatch.setenv("GPSX_ACQ_NO_SPLIT", "1")
+    monkeypatch.setenv("GPSX_ACQ_MS_MODE", "blocks")
+    e = capi.Engine(0)
+    try:
+        assert e.lib.gpsx_is_lab_build() == 0
+        pk0, k0 = base.acq_grid(stream[:2], prns, **kw)
+        ran0 = base.lib.gpsx_last_kernel(base.h)
+        pk, k = e.acq_grid(stream[:2], prns, **kw)
+        assert e.lib.gpsx_last_kernel(e.h) == ran0 and ran0.startswith(b"k_acq_mx")
+        assert pk.tobytes() == pk0.tobytes() and np.array_equal(k, k0)
+        e.set_acq_path(capi.ACQ_PATH_VECTOR)
+        pk_v, k_v = e.acq_grid(stream[:2], prns, **kw)
+        assert e.lib.gpsx_last_kernel(e.h).startswith(b"k_acq_poly")
+        assert pk_v.tobytes() == pk0.tobytes() and np.array_equal(k_v, k0)
+        e.set_acq_path(capi.ACQ_PATH_MATRIX)
+        e.acq_grid(stream[:2], prns, **kw)
+        assert e.lib.gpsx_last_kernel(e.h) == ran0
+    finally:
+        e.close()
+        base.close()

@@ -26,7 +26,7 @@ def _engine(monkeypatch, ms_mode):
     from stm32f4_sdr_gps_amd import capi
     if ms_mode:
         monkeypatch.setenv("GPSX_ACQ_MS_MODE", ms_mode)
-    e = capi.Engine(0)
+    e = capi.Engine(0, lab=bool(ms_mode))      # (the knob is the lab library's: lib/libgpsx_lab.so)
     if ms_mode:
         monkeypatch.delenv("GPSX_ACQ_MS_MODE")
     return e

@@ -4,6 +4,7 @@ ablations ($GPSX_MX_EXPERIMENT) and A/B runs ($GPSX_ACQ_ALGO).  tools/bench_grid
 import ctypes as C
 import json
 import os
+os.environ.setdefault("GPSX_USE_LAB_LIBRARY", "1")   # forced kernel forms ($GPSX_ACQ_*): the lab build of the library
 import sys
 
 import numpy as np
@@ -18,7 +19,7 @@ def main():
     n_ms = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
     if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
-        capi.LIB_PATH = os.environ["GPSX_LIB"]
+        capi.LIB_PATH = capi.LAB_LIB_PATH = os.environ["GPSX_LIB"]   # (tools/build_variant.sh: a lab build)
     eng = capi.Engine(0)
     blocks = synth.cold_start_block(searches * n_ms, seed=11, amp_scale=float(os.environ.get("GPSX_BENCH_AMP", "0.25")), two_bit=True)
     eng.set_if_format(capi.IF_2BIT_SM)

@@ -11,6 +11,7 @@ import argparse
 import ctypes as C
 import json
 import os
+os.environ.setdefault("GPSX_USE_LAB_LIBRARY", "1")   # forced kernel forms ($GPSX_ACQ_*): the lab build of the library
 import sys
 
 import numpy as np
@@ -27,7 +28,7 @@ def main():
     args = ap.parse_args()
     from stm32f4_sdr_gps_amd import capi, synth
     if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
-        capi.LIB_PATH = os.environ["GPSX_LIB"]
+        capi.LIB_PATH = capi.LAB_LIB_PATH = os.environ["GPSX_LIB"]   # (tools/build_variant.sh: a lab build)
     eng = capi.Engine(0)
     n_prn, n_dopp, n_phase = 32, 29, 2046
     blocks = synth.cold_start_block(args.searches, seed=11, amp_scale=0.25)

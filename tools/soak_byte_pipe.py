@@ -5,6 +5,7 @@ count alone, and a slip there would show as a rare mismatch, not as a failed tes
 import argparse
 import json
 import os
+os.environ.setdefault("GPSX_USE_LAB_LIBRARY", "1")   # forced kernel forms ($GPSX_ACQ_*): the lab build of the library
 import sys
 import time
 

@@ -3,6 +3,7 @@
 scratch planes, multi-block scratch, capture rings, tracking graphs) must go with it."""
 import ctypes as C
 import os
+os.environ.setdefault("GPSX_USE_LAB_LIBRARY", "1")   # forced kernel forms ($GPSX_ACQ_*): the lab build of the library
 import sys
 
 import numpy as np
