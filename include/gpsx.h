@@ -308,10 +308,15 @@ int gpsx_track_epl_batch_chunked(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_tr
  *       located, hence accurate_swap_time, hence subframe time stamps and pseudoranges -- the complete receiver on the
  *       device loop (tests/test_gpu_track_mux.py: the reference's multiplexed traces, tests/test_gpu_pvt_chain.py: IF
  *       samples to position).  Hand channels over (gpsx_loop_state_from_channel) on a tick with t % 17 == 0.
- * Differences from the host mode, all stated: the arctangents are the device's (results agree with glibc's to the last
- * bit or the one before it: the stated tolerance of the closed loop is |d code_phase_fine| <= 0.01 sample,
- * |d if_freq_offset_hz| <= 0.5 Hz against the reference's traces, tests/test_gpu_track_loop.py); the false-lock jump
- * draws from a per-channel xorshift32 (`rng`, never 0) instead of libc's process-global rand().
+ * Arithmetic against the host mode (= the reference's C on the host CPU): the float arctangents are the C library's own
+ * algorithm restated operation by operation (csrc/gpsx_libm.hpp, compared with glibc bit for bit on the CPU), so the loops'
+ * floats come out identical -- observed on every committed reference trace and on 26 000 channels from random states: every
+ * byte of every record.  What remains different by construction: the double-precision atan2 of the PLL's IP <= 0 branch is the
+ * device's (its result rounded to float differs from glibc's in about one argument pair in 2^29), and snr_value's logarithm
+ * (a display value; the record gets the host's log10f of the sums the device latched, gpsx_loop_state_to_channel).  The stated
+ * tolerance of SURVEY.md 8(c) -- |d code_phase_fine| <= 0.01 sample, |d if_freq_offset_hz| <= 0.5 Hz -- stays the tests'
+ * fallback bar.  The false-lock jump draws by default from a per-channel xorshift32 (`rng`, never 0) instead of libc's
+ * process-global rand(); gpsx_loop_set_draws(GPSX_DRAWS_LIBC) gives the reference's draws in the reference's order.
  * Data polarity (gpsx_loop_set_word_sync): the reference's word layer flips inv_polarity_flag when it has seen two inverted
  * preambles, and the very next millisecond's vote and sign-change detection use the new value (nav_data.c:60-66, 284-291).
  *   GPSX_WORDSYNC_DEVICE (default)  the kernel runs the polarity-deciding part of the word layer itself (preamble hunt, word

@@ -47,7 +47,7 @@
 // at its own sample offset (mx_direct_terms: every quirk term as a start value), results merged through global planes.
 #if !defined(GPSX_LAB) && (defined(WALK_ABL_NO_LOAD) || defined(WALK_ABL_NO_STORE) || defined(GPSX_MX_ABLATIONS) || \
                            defined(GPSX_MX_NO_PIECES) || defined(GPSX_MX_TIMELINE) || defined(MX_BUILD_BEHIND) || defined(GPSX_MX_NT) || \
-                           defined(MX_VARIANT_B))
+                           defined(MX_VARIANT_B) || defined(WALK_ABL_ALIAS))
 #error "timing ablations / instrumented variants of k_acq_mx (some give wrong results) build with -DGPSX_LAB only: tools/build_variant.sh"
 #endif
 #include <cstdlib>
@@ -942,6 +942,22 @@ __device__ __forceinline__ void mx_prefetch_sums(const u32 *__restrict__ energy,
   // (first block of a search: the running sums are zero -- read from a small all-zero region, `zero_recs`, instead of being
   //  set by the vector ALU: register writes into the prefetch array made the compiler drain every outstanding store first,
   //  an s_waitcnt vmcnt(0) per step; a load is ordered behind them by the memory system and costs nothing)
+#ifdef WALK_ABL_ALIAS   // (timing ablation, results are wrong: sample offsets t0 and t0 & WALK_ABL_ALIAS share their records -- the same
+  t0 &= WALK_ABL_ALIAS;   //  traffic on 1/2 (7), 1/4 (3) ... of the footprint: does the stream fit the memory-side cache then?)
+#endif
+  if constexpr (S16) {
+    // 16-bit records: [sample offset][tile][group pair][lane][2] -- a wave's 16-byte loads and stores of a pair cover ONE
+    // contiguous kilobyte (whole 128-byte lines per instruction, not half lines twice)
+    const SumRecT<S16> *e2 = ms_first ? reinterpret_cast<const SumRecT<S16> *>(zero_recs) + (size_t)lane * 2
+                                      : reinterpret_cast<const SumRecT<S16> *>(energy) + (size_t)(t0 * kMxTiles) * 256 + (size_t)lane * 2;
+#pragma unroll
+    for (int i = FIRST; i < FIRST + COUNT; i += 2) {
+      const RecPairT<S16> rp = *reinterpret_cast<const RecPairT<S16> *>(&e2[(size_t)(i >> 2) * 256 + (size_t)((i & 3) >> 1) * 128]);
+      pre[i] = rp.a;
+      pre[i + 1] = rp.b;
+    }
+    return;
+  }
   const SumRecT<S16> *e4 = ms_first ? reinterpret_cast<const SumRecT<S16> *>(zero_recs) + (size_t)lane * 4
                                     : reinterpret_cast<const SumRecT<S16> *>(energy) + ((size_t)(t0 * kMxTiles) * 64 + lane) * 4;
 #pragma unroll
@@ -1060,7 +1076,14 @@ __device__ __forceinline__ void mx_epilogue(MxShared &sh, int lane, int q0_tile,
           RecPairT<S16> both;
           both.a = held;
           both.b = nr;
-          *reinterpret_cast<RecPairT<S16> *>(e_rec - 1) = both;
+          // ([offset][tile][pair][lane][2]: see mx_prefetch_sums)
+#ifdef WALK_ABL_ALIAS
+          const int t0r = t0 & WALK_ABL_ALIAS;
+#else
+          const int t0r = t0;
+#endif
+          SumRec *e_pair = reinterpret_cast<SumRec *>(energy) + (size_t)(t0r * kMxTiles + j) * 256 + (size_t)(r0 / 8) * 128 + (size_t)lane * 2;
+          *reinterpret_cast<RecPairT<S16> *>(e_pair) = both;
         } else {
           held = nr;
         }

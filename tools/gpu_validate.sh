@@ -4,7 +4,7 @@
 if [ "${1:-}" = "ab" ]; then
   shift
   for i in 1 2 3; do
-    for lib in "" _b; do
+    for lib in _lab _b; do   # (A = the working tree's lab build: same kernels as the product, reads the knobs; B = tools/build_variant.sh)
       echo -n "lib$lib: "
       GPSX_LIB=stm32f4_sdr_gps_amd/lib/libgpsx$lib.so python tools/bench_grid_kernel.py ${@:-256 1 20} 2>/dev/null | tail -1 | cut -c60-200
     done
