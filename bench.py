@@ -254,6 +254,17 @@ def tracking_device_loop(ms=1200, k=20):
             break
         counts.pop()
     best = counts[-1] if counts else None
+    # the reference's own receiver shape on the device: four channels per receiver in the 17 ms multiplex, one launch per cycle
+    mux_rows, mux_best = [], None
+    try:
+        for n in (256, 1048576, 2097152, 4194304):
+            r = mod.device_loop(n, 1275, 17, 32, mux17=True)
+            mux_rows.append({kk: r[kk] for kk in keep})
+            if not r["real_time"]:
+                break
+            mux_best = n
+    except Exception as exc:   # noqa: BLE001 -- reported, the line still goes out
+        mux_rows.append({"error": repr(exc)})
     return {"metric": "closed-loop real-time tracking channels with the loops on the device: largest count of the ladder whose "
                       "launches (K ms of stream each) ALL come back inside K ms, at that count and every smaller one -- in its 1.2 s "
                       "ladder run AND in a 5 s confirmation run",
@@ -261,6 +272,9 @@ def tracking_device_loop(ms=1200, k=20):
             "ms_per_launch": k, "ms_per_count": ms, "signals_in_stream": 32,
             "per_millisecond_launches_256_channels": {kk: per_ms[kk] for kk in keep},
             "config5": {kk: literal[kk] for kk in keep + ("ms", "signals_in_stream", "code_and_carrier_lock_in_the_reference_on_this_stream")},
+            "mux17": {"metric": "channels (= 4 x receivers) under GPSX_SCHED_MUX17, the reference's 17 ms four-channel multiplex, 17 ms "
+                                "of stream per launch: largest count of the ladder whose launches all come back inside 17 ms",
+                      "value": mux_best, "receivers": mux_best // 4 if mux_best else None, "ladder": mux_rows},
             "ladder": rows,
             "note": "ONE run per count; steady state = second half of each run.  With K ms per launch the deadline is K ms: a host "
                     "thread that another tenant holds up for a few milliseconds delays a launch, it does not miss one -- the "

@@ -60,10 +60,14 @@ def check_no_scratch() -> dict:
     mx = {k: v for k, v in res.items() if "k_acq_mx" in k}
     if not mx:
         raise RuntimeError("no k_acq_mx kernels found in build/k_acq_mx.o's code object metadata")
-    bad = {k: v for k, v in mx.items() if v["scratch_bytes"] != 0}
+    # ... and the device tracking loops, whose occupancy (three waves per SIMD: 168 VGPRs) is asked for by __launch_bounds__
+    loops = {k: v for k, v in kernel_resources(os.path.join(PKG, "build", "k_track_loop.o")).items() if "k_track_loop" in k}
+    if len(loops) != 4:
+        raise RuntimeError(f"expected four k_track_loop instances, found {sorted(loops)}")
+    bad = {k: v for k, v in {**mx, **loops}.items() if v["scratch_bytes"] != 0}
     if bad:
-        raise RuntimeError(f"k_acq_mx instances with scratch memory (register spills): {bad}")
-    return mx
+        raise RuntimeError(f"kernels with scratch memory (register spills): {bad}")
+    return {**mx, **loops}
 
 
 if __name__ == "__main__":

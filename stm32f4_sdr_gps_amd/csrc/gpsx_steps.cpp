@@ -1683,15 +1683,17 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
   static std::vector<std::vector<int>> changed;
   if ((int)changed.size() < n_workers)
     changed.resize(n_workers);
-  static std::vector<uint8_t> before;
-  if ((int)before.size() < n_ch)
-    before.resize(n_ch);
+  // (channel, its flag before the launch) of the channels whose flag a word of this launch touched: a handful per launch --
+  // the records themselves (1.7 KB each, gigabytes at a million channels) are only visited where a flag byte says so
+  static std::vector<std::vector<std::pair<int, uint8_t>>> touched;
+  if ((int)touched.size() < n_workers)
+    touched.resize(n_workers);
   auto work = [&](int w) {
     std::vector<int> &mine = changed[w];
+    std::vector<std::pair<int, uint8_t>> &seen = touched[w];
     mine.clear();
+    seen.clear();
     const int lo = (int)((long)n_ch * w / n_workers), hi = (int)((long)n_ch * (w + 1) / n_workers);
-    for (int c = lo; c < hi; c++)
-      before[c] = channel[c].nav_data.inv_polarity_flag;
     t_tick_valid = true;
     for (int ms = 0; ms < n_blocks; ms++) {
       const uint8_t *f = flags + (size_t)ms * n_ch;
@@ -1704,8 +1706,12 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
         n.period_sync_ok_flag = (v & 8) ? 1 : 0;
         if ((v & (2 | 32)) == 0)
           continue;
-        if (v & 2)
+        if (v & 2) {
+          const uint8_t was = n.inv_polarity_flag;
           gps_nav_data_words_detection(&channel[c], (uint8_t)((v >> 2) & 1));
+          if (n.inv_polarity_flag != was)
+            seen.emplace_back(c, was);
+        }
         if (v & 32) {
           n.accurate_swap_time = (uint8_t)((t_tick - 3u + ((v & 64) ? 2u : 1u)) % 20u);
           n.accurate_swap_ok = 1;
@@ -1713,9 +1719,12 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
       }
     }
     t_tick_valid = false;
-    for (int c = lo; c < hi; c++)   // listed once, and only if the launch left the flag different from how it found it
-      if (channel[c].nav_data.inv_polarity_flag != before[c])
-        mine.push_back(c);
+    // listed once, in channel order, and only if the launch left the flag different from how it found it (a channel's FIRST
+    // entry holds the value from before the launch: the sort is stable)
+    std::stable_sort(seen.begin(), seen.end(), [](const std::pair<int, uint8_t> &a, const std::pair<int, uint8_t> &b) { return a.first < b.first; });
+    for (size_t i = 0; i < seen.size(); i++)
+      if ((i == 0 || seen[i].first != seen[i - 1].first) && channel[seen[i].first].nav_data.inv_polarity_flag != seen[i].second)
+        mine.push_back(seen[i].first);
   };
   pool.run(n_workers, work);
   int total = 0;

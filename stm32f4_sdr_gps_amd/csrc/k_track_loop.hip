@@ -171,15 +171,20 @@ __device__ __forceinline__ float atan_ratio(int q, int i)   // the reference's (
   return gpsx_libm::atanf_fdlibm((float)q / (float)i);
 }
 
-// gps_tracking_fll behind its call of the check
-__device__ __forceinline__ void loop_fll(gpsx_loop_state_t &s, int index, int IP, int QP)
+// gps_tracking_fll behind its call of the check.  `before_cache`: atan_ratio(fll_old_q, fll_old_i) as far as this launch has
+// already computed it -- this millisecond's "before" is the last millisecond's "now" (same inputs, same function; NaN = not
+// there: the first millisecond of a launch, or after index 0, computes it afresh)
+__device__ __forceinline__ void loop_fll(gpsx_loop_state_t &s, int index, int IP, int QP, float &before_cache)
 {
   if (index == 0) {
     s.fll_old_i = (int16_t)IP;
     s.fll_old_q = (int16_t)QP;
+    before_cache = __builtin_nanf("");
     return;
   }
-  const float now = atan_ratio(QP, IP), before = atan_ratio(s.fll_old_q, s.fll_old_i);
+  const float now = atan_ratio(QP, IP);
+  const float before = before_cache == before_cache ? before_cache : atan_ratio(s.fll_old_q, s.fll_old_i);
+  before_cache = now;
   float rot = now - before;
   if ((double)rot > kPiD / 2)
     rot = (float)(kPiD - (double)rot);
@@ -264,39 +269,59 @@ constexpr u32 kBadPolarityTimeoutMs = 12000;
 // by the very next millisecond's vote and sign-change detection (nav_data.c:60-66), so it is decided here, where it is used;
 // subframe images, time stamps and the ephemeris stay with the host's word layer, which sees the same bits at the same
 // ticks and therefore takes the same decisions (gps_tracking_words_batch).
-__device__ __forceinline__ void nav_word_sync(gpsx_loop_state_t &s, u32 new_bit, u32 now)
+// ... on the state's COLD part: the fields a channel touches once per completed bit (20 ms) or once per SNR estimate (201 ms)
+// do not ride in registers through the correlators -- they stay in HBM and are read, changed and written back where they are
+// needed (GPSX_DRAWS_LIBC keeps them in registers: a channel that stops for its draw must leave its state in HBM untouched).
+struct WordSync {
+  u32 buf, ts, cnt, bit_cnt, inv_cnt, flags;   // word_buf, word_detection_timestamp, word_cnt, word_bit_cnt, inv_preabmle_cnt, word_flags
+};
+__device__ __forceinline__ WordSync word_sync_load(const gpsx_loop_state_t &g)
 {
-  u32 buf = s.word_buf;
-  if (s.word_cnt == 0) {
+  return WordSync{g.word_buf, g.word_detection_timestamp, g.word_cnt, g.word_bit_cnt, g.inv_preabmle_cnt, g.word_flags};
+}
+__device__ __forceinline__ void word_sync_store(const WordSync &w, gpsx_loop_state_t &g)
+{
+  g.word_buf = w.buf;
+  g.word_detection_timestamp = w.ts;
+  g.word_cnt = (uint8_t)w.cnt;
+  g.word_bit_cnt = (uint8_t)w.bit_cnt;
+  g.inv_preabmle_cnt = (uint8_t)w.inv_cnt;
+  g.word_flags = (uint8_t)w.flags;
+}
+// returns the data polarity flag after the bit (`inv` = before it)
+__device__ __forceinline__ u32 nav_word_sync(WordSync &w, u32 inv, u32 new_bit, u32 now)
+{
+  u32 buf = w.buf;
+  if (w.cnt == 0) {
     buf = (buf >> 1) | (new_bit << 29);
     if ((buf & 0xFFu) == kPreambleBits) {
-      s.word_flags = (uint8_t)((s.word_flags & ~3u) | ((buf >> 28) & 3u));   // old_D29, old_D30
-      s.word_cnt = 1;
-      s.word_bit_cnt = 0;
-      s.inv_preabmle_cnt = 0;
+      w.flags = (w.flags & ~3u) | ((buf >> 28) & 3u);   // old_D29, old_D30
+      w.cnt = 1;
+      w.bit_cnt = 0;
+      w.inv_cnt = 0;
     }
-    if (!(s.word_flags & 4u) && s.word_cnt == 0) {
+    if (!(w.flags & 4u) && w.cnt == 0) {
       if ((buf & 0xFFu) == (kPreambleBits ^ 0xFFu))
-        s.inv_preabmle_cnt++;
-      if (s.inv_preabmle_cnt >= 2)
-        s.inv_polarity_flag = 1;
+        w.inv_cnt = (w.inv_cnt + 1u) & 0xFFu;           // (a uint8_t in the reference)
+      if (w.inv_cnt >= 2)
+        inv = 1;
     }
-    if (s.word_flags & 4u) {
-      if (now - s.word_detection_timestamp > kBadPolarityTimeoutMs) {
-        s.word_detection_timestamp = now;
-        s.word_flags &= (uint8_t)~4u;
-        s.inv_polarity_flag = 0;
+    if (w.flags & 4u) {
+      if (now - w.ts > kBadPolarityTimeoutMs) {
+        w.ts = now;
+        w.flags &= ~4u;
+        inv = 0;
       }
     }
-    s.word_buf = buf;
-    return;
+    w.buf = buf;
+    return inv;
   }
-  buf = (buf & ~(1u << s.word_bit_cnt)) | (new_bit << s.word_bit_cnt);
-  s.word_bit_cnt++;
-  s.word_buf = buf;
-  if (s.word_bit_cnt < 30)
-    return;
-  const u32 d29 = s.word_flags & 1u, d30 = (s.word_flags >> 1) & 1u;
+  buf = (buf & ~(1u << w.bit_cnt)) | (new_bit << w.bit_cnt);
+  w.bit_cnt++;
+  w.buf = buf;
+  if (w.bit_cnt < 30)
+    return inv;
+  const u32 d29 = w.flags & 1u, d30 = (w.flags >> 1) & 1u;
   if (d30)
     buf ^= 0xFFFFFFu;          // the D30* inversion comes off the 24 data bits in place (nav_data.c:439-440)
   bool ok = true;
@@ -306,24 +331,25 @@ __device__ __forceinline__ void nav_word_sync(gpsx_loop_state_t &s, u32 new_bit,
     ok = ok && ((buf >> (24 + k)) & 1u) == p;
   }
   if (!ok) {
-    s.word_cnt = 0;
-    s.word_buf = 0;
-    return;
+    w.cnt = 0;
+    w.buf = 0;
+    return inv;
   }
-  s.word_flags = (uint8_t)(((buf >> 28) & 3u) | 4u);   // old_D29, old_D30 of the next word; polarity_found
-  s.word_cnt++;
-  s.word_bit_cnt = 0;
-  s.word_detection_timestamp = now;
-  s.word_buf = buf;
-  if (s.word_cnt == 10) {
-    s.word_cnt = 0;
-    s.word_buf = 0;
+  w.flags = ((buf >> 28) & 3u) | 4u;   // old_D29, old_D30 of the next word; polarity_found
+  w.cnt++;
+  w.bit_cnt = 0;
+  w.ts = now;
+  w.buf = buf;
+  if (w.cnt == 10) {
+    w.cnt = 0;
+    w.buf = 0;
   }
+  return inv;
 }
 
 // gps_nav_data_analyse_new_code on the channel's own slot state; returns flag bits 1 / 2 (a bit was completed / its value)
 // and 5 / 6 (the bit edge inside the 20 ms grid was located this millisecond / it was edge 2, not 1)
-__device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, int index, int IP, u32 now, bool word_sync)
+__device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, int index, int IP, u32 now)
 {
   u32 out = 0;
   u32 bit = IP > 0 ? 1u : 0u;
@@ -338,8 +364,8 @@ __device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, i
     if (rem < s.old_reminder) {
       const u32 nav_bit = s.last_bit_pos_cnt > s.last_bit_neg_cnt ? 1u : 0u;
       out = 2u | (nav_bit << 2);
-      if (word_sync)
-        nav_word_sync(s, nav_bit, now);   // (this millisecond's own vote was formed with the polarity of before, as in the reference)
+      // (the caller runs the word sync on this bit: nothing below depends on the polarity it may change -- this millisecond's own
+      //  vote was formed with the polarity of before, as in the reference)
       s.last_bit_pos_cnt = 0;
       s.last_bit_neg_cnt = 0;
     }
@@ -386,7 +412,8 @@ __device__ __forceinline__ u32 nav_bit_sync(gpsx_loop_state_t &s, Quad16 &sip, i
   return out;
 }
 
-__device__ __forceinline__ void loop_snr(gpsx_loop_state_t &s, int IP, int QP)
+// returns 0, or 1 = a new estimate was made of (*latch_i, *latch_q), or 2 = the q == 0 case (snr_value = 1, no latch)
+__device__ __forceinline__ int loop_snr(gpsx_loop_state_t &s, int IP, int QP, u32 &latch_i, u32 &latch_q)
 {
   s.i_part_summ += (u32)iabs(IP);
   s.q_part_summ += (u32)iabs(QP);
@@ -394,67 +421,102 @@ __device__ __forceinline__ void loop_snr(gpsx_loop_state_t &s, int IP, int QP)
   if (s.snr_summ_cnt > kSnrLength) {
     if (s.q_part_summ == 0) {
       s.snr_value = 1.0f;
-      s.snr_i_latch = 0;
-      s.snr_q_latch = 0;
-      return;   // sic: the sums are not cleared on this path (tracking.c:152-156)
+      latch_i = 0;
+      latch_q = 0;
+      return 2;   // sic: the sums are not cleared on this path (tracking.c:152-156)
     }
     const float ratio = (float)s.i_part_summ / (float)s.q_part_summ;
     s.snr_value = s.i_part_summ ? 10.0f * gpsx_libm::log10f_near(ratio) : 10.0f * log10f(ratio);   // (log10f(0) = -inf)
-    s.snr_i_latch = s.i_part_summ;   // what the estimate was made of: gpsx_loop_state_to_channel takes the host's logarithm
-    s.snr_q_latch = s.q_part_summ;
+    latch_i = s.i_part_summ;   // what the estimate was made of: gpsx_loop_state_to_channel takes the host's logarithm
+    latch_q = s.q_part_summ;
     s.snr_summ_cnt = 0;
     s.i_part_summ = 0;
     s.q_part_summ = 0;
+    return 1;
   }
+  return 0;
 }
+
+// the part of the state that rides in registers: everything in front of snr_i_latch
+constexpr int kLiveDwords = 25;
+static_assert(offsetof(gpsx_loop_state_t, snr_i_latch) == 4 * kLiveDwords && sizeof(gpsx_loop_state_t) == 120, "gpsx_loop_state_t layout");
+struct LiveWords { u32 w[kLiveDwords]; };
 
 }  // namespace
 
-// Which channels a wave holds.  GPSX_SCHED_EVERY_MS: cpw consecutive channels.  GPSX_SCHED_MUX17: the reference's receiver is
-// four channels sharing one correlator in a 17 ms cycle (PM/main.c:139-152) -- channel c is slot (c & 3) of receiver c >> 2
-// and is served on the ticks t with (t % 17) / 4 == slot, t % 17 != 16.  A wave then holds channels of ONE slot (wave w of the
-// workgroup: slot w of the workgroup's cpw receivers), so that "is this channel served this millisecond" is wave-uniform: three
-// of a workgroup's four waves skip a millisecond's correlators whole, all four skip the idle slot.
-template <bool MUX>
-__global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ if_blocks, u32 block_stride, int n_blocks,
-                                                    int if_format, int if_hz, gpsx_loop_state_t *__restrict__ st, int n_ch, int cpw,
-                                                    u32 first_tick, const u32 *__restrict__ chipbits_all,
-                                                    const u32 *__restrict__ rep_all, uint8_t *__restrict__ flags,
-                                                    gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn, int word_sync,
-                                                    const int *__restrict__ ch_map, int n_map,
-                                                    const gpsx_loop_reseed_t *__restrict__ reseeds,
-                                                    gpsx_loop_event_t *__restrict__ events, u32 *__restrict__ n_events)
+// Which channels a wave holds.  GPSX_SCHED_EVERY_MS: cpw consecutive channels, in registers for the whole launch.
+// GPSX_SCHED_MUX17: the reference's receiver is four channels sharing one correlator in a 17 ms cycle (PM/main.c:139-152) --
+// channel c is slot (c & 3) of receiver c >> 2 and is served on the ticks t with (t % 17) / 4 == slot, t % 17 != 16.  A wave
+// then holds cpw RECEIVERS: on a slot's first millisecond it loads the states of that slot's channels, on its last it stores
+// them (240 B of traffic per channel and slot: nothing next to the correlators' work), so that every wave works on every
+// millisecond but the cycle's idle one -- the multiplex costs no occupancy.  (The second pass of GPSX_DRAWS_LIBC, one listed
+// channel per wave, keeps its channel for the launch and idles through the other slots.)
+// LIBC: GPSX_DRAWS_LIBC -- the whole state, cold part included, stays in registers and a stopped channel is not stored.
+template <bool MUX, bool LIBC>
+__global__ __launch_bounds__(256, LIBC ? 2 : 3) void k_track_loop(const uint8_t *__restrict__ if_blocks, u32 block_stride, int n_blocks,
+                                                       int if_format, int if_hz, gpsx_loop_state_t *__restrict__ st, int n_ch, int cpw,
+                                                       u32 first_tick, const u32 *__restrict__ chipbits_all,
+                                                       const u32 *__restrict__ rep_all, uint8_t *__restrict__ flags,
+                                                       gpsx_loop_trace_t *__restrict__ trace, u32 *__restrict__ bad_prn, int word_sync,
+                                                       const int *__restrict__ ch_map, int n_map,
+                                                       const gpsx_loop_reseed_t *__restrict__ reseeds,
+                                                       gpsx_loop_event_t *__restrict__ events, u32 *__restrict__ n_events)
 {
   __shared__ u32 s_x[2][512];        // this and the next millisecond's sign plane: one barrier per millisecond
   __shared__ uint2 s_carrier[4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int c_l = lane >> 2, k_l = lane & 3;
-  int n_here, ch_l;                  // channels of this wave (0: an idle wave of the last workgroup still stages blocks)
-  int slot = wave;                   // MUX: the slot of the receiver's 17 ms cycle this wave's channels are served in
-  if (ch_map) {                      // the second pass of GPSX_DRAWS_LIBC: one listed channel per wave
+  const bool swap = MUX && !(LIBC && ch_map);   // the wave holds receivers and swaps channel states at the slot boundaries
+  int n_here;                        // channels (swap: receivers) of this wave; 0: an idle wave of the last workgroup still stages blocks
+  int unit0;                         // the wave's first channel (swap: receiver)
+  if (LIBC && ch_map) {              // the second pass of GPSX_DRAWS_LIBC: one listed channel per wave
     const int v = (int)blockIdx.x * 4 + wave;
     n_here = v < n_map ? 1 : 0;
-    ch_l = n_here ? ch_map[v] : 0;
-    slot = ch_l & 3;
-  } else if (MUX) {
-    const int first = (int)blockIdx.x * 4 * cpw + wave;   // the wave's channels: first, first + 4, ...
-    n_here = first < n_ch ? min(cpw, (n_ch - first + 3) >> 2) : 0;
-    ch_l = first + 4 * (c_l < n_here ? c_l : 0);
+    unit0 = n_here ? ch_map[v] : 0;
   } else {
-    const int ch0 = ((int)blockIdx.x * 4 + wave) * cpw;
-    n_here = ch0 < n_ch ? min(cpw, n_ch - ch0) : 0;
-    ch_l = ch0 + (c_l < n_here ? c_l : 0);
+    const int n_units = swap ? (n_ch + 3) >> 2 : n_ch;
+    unit0 = ((int)blockIdx.x * 4 + wave) * cpw;
+    n_here = unit0 < n_units ? min(cpw, n_units - unit0) : 0;
   }
   const bool in_wave = c_l < n_here;
-  const bool mine = in_wave && k_l < 3;
+  const int unit_l = unit0 + (in_wave ? c_l : 0);
   gpsx_loop_state_t s = {};
-  int prn = 0;
-  if (n_here) {
-    s = st[ch_l < n_ch ? ch_l : 0];
-    prn = track_prn(s.prn, bad_prn, mine && k_l == 0);
-  }
-  Quad16 chk = quad16_load(s.pll_check_buf), sip = quad16_load(s.slot_ip);
+  int prn = 0, ch_l = swap ? 0 : unit_l, cur_slot = -1;
+  bool have = in_wave;               // this lane's quad holds a channel right now
+  Quad16 chk = {0}, sip = {0};
   bool stalled = false;
+  u32 stalled_slots = 0;             // swap: the slots whose channel of this receiver stopped for its draw in this launch
+  float fll_before = __builtin_nanf("");
+
+  auto load_state = [&](int ch) {
+    ch_l = ch;
+    if (LIBC) {
+      s = st[ch];
+    } else {     // the live part only: the cold fields are never read from `s` in this instantiation
+      const LiveWords lw = *reinterpret_cast<const LiveWords *>(&st[ch]);
+      __builtin_memcpy(&s, &lw, sizeof lw);
+    }
+    prn = track_prn(s.prn, bad_prn, have && k_l == 0);
+    chk = quad16_load(s.pll_check_buf);
+    sip = quad16_load(s.slot_ip);
+    fll_before = __builtin_nanf("");
+  };
+  auto store_state = [&]() {
+    if (!(have && k_l == 0) || stalled)
+      return;
+    quad16_store(chk, s.pll_check_buf);
+    quad16_store(sip, s.slot_ip);
+    if (LIBC) {
+      st[ch_l] = s;
+    } else {
+      LiveWords lw;
+      __builtin_memcpy(&lw, &s, sizeof lw);
+      *reinterpret_cast<LiveWords *>(&st[ch_l]) = lw;
+    }
+  };
+  if (n_here && !swap)
+    load_state(unit_l < n_ch ? unit_l : 0);
+  const int slot_fixed = ch_l & 3;   // (MUX without swapping: the channel's slot)
 
 #pragma unroll 1
   for (int ms = 0; ms < n_blocks; ms++) {
@@ -465,19 +527,35 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
       continue;
     const u32 now = first_tick + (u32)ms;
     int index = (int)(now & 3u);
+    int n_act = n_here;              // quads with a channel this millisecond
+    int slot_now = 0;
     if (MUX) {
       const u32 big = now % (u32)(kSlotMs * kSlots + 1);   // PM/main.c:139-152
-      if (big == (u32)(kSlotMs * kSlots) || (int)(big / (u32)kSlotMs) != slot) {
-        // not this wave's slot (or the cycle's idle millisecond): nothing of the channel moves
+      slot_now = (int)(big / (u32)kSlotMs);
+      const bool idle = big == (u32)(kSlotMs * kSlots);
+      if (swap) {
+        n_act = idle ? 0 : max(0, min(n_here, (n_ch - slot_now - 4 * unit0 + 3) >> 2));
+        if (n_act == 0) {            // the cycle's idle millisecond (or a ragged last receiver without this slot)
+          const int c = 4 * unit_l + k_l;
+          if (in_wave && c < n_ch) {
+            flags[(size_t)ms * n_ch + c] = 0;
+            if (trace)
+              trace[(size_t)ms * n_ch + c] = gpsx_loop_trace_t{};
+          }
+          continue;
+        }
+        if (slot_now != cur_slot) {  // a slot begins (or the launch begins inside one): its channels' states come in
+          cur_slot = slot_now;
+          have = c_l < n_act;
+          stalled = (stalled_slots >> slot_now) & 1u;
+          load_state(have ? 4 * unit_l + slot_now : 0);
+        }
+      } else if (idle || slot_now != slot_fixed) {
+        // not this channel's slot (or the cycle's idle millisecond): nothing of the channel moves
         if (in_wave && k_l == 0) {
           flags[(size_t)ms * n_ch + ch_l] = 0;
-          if (trace) {
-            gpsx_loop_trace_t t = {};
-            t.code_phase_fine = s.code_phase_fine;
-            t.if_freq_offset_hz = s.if_freq_offset_hz;
-            t.if_freq_accum = s.if_freq_accum;
-            trace[(size_t)ms * n_ch + ch_l] = t;
-          }
+          if (trace)
+            trace[(size_t)ms * n_ch + ch_l] = gpsx_loop_trace_t{};
         }
         continue;
       }
@@ -492,9 +570,10 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
       }
     }
     s.prev_track_timestamp = now;
+    const bool mine = have && k_l < 3;
     const int fine = (int)(int16_t)(int)s.code_phase_fine;
     const u32 step = nco_step_per_word((float)if_hz + s.if_freq_offset_hz);
-    const u32 iq = trkwave::wave_epl(sx, s_carrier, lane, n_here, mine, prn, fine, step, s.if_freq_accum, chipbits_all, rep_all);
+    const u32 iq = trkwave::wave_epl(sx, s_carrier, lane, n_act, mine, prn, fine, step, s.if_freq_accum, chipbits_all, rep_all);
     const u32 e = quad_get<0>(iq), p = quad_get<1>(iq), l = quad_get<2>(iq);
     const int IE = (int16_t)(e & 0xFFFFu), QE = (int16_t)(e >> 16), IP = (int16_t)(p & 0xFFFFu), QP = (int16_t)(p >> 16);
     const int IL = (int16_t)(l & 0xFFFFu), QL = (int16_t)(l >> 16);
@@ -505,7 +584,7 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
       loop_pll(s, IP, QP);
     bool moved = false;
     if (loop_false_lock_detect(s, chk, index, IP)) {
-      if (!events) {
+      if (!LIBC) {
         loop_false_lock_jump(s);
         moved = true;
       } else {
@@ -519,34 +598,73 @@ __global__ __launch_bounds__(256) void k_track_loop(const uint8_t *__restrict__ 
           moved = true;
         } else if (!stalled) {
           stalled = true;
-          if (in_wave && k_l == 0) {
-            const u32 e = atomicAdd(n_events, 1u);
-            events[e] = gpsx_loop_event_t{ch_l, ms, (int)(int16_t)s.if_freq_offset_hz, (int)s.found_freq_offset_hz};
+          stalled_slots |= 1u << slot_now;
+          if (have && k_l == 0) {
+            const u32 ev = atomicAdd(n_events, 1u);
+            events[ev] = gpsx_loop_event_t{ch_l, ms, (int)(int16_t)s.if_freq_offset_hz, (int)s.found_freq_offset_hz};
           }
         }
       }
     }
-    loop_fll(s, index, IP, QP);
-    u32 flag = nav_bit_sync(s, sip, index, IP, now, word_sync != 0);
-    loop_snr(s, IP, QP);
-    flag |= (IP > 0 ? 1u : 0u) | (s.period_sync_ok_flag ? 8u : 0u) | (moved ? 16u : 0u) | 128u;
-    if (in_wave && k_l == 0) {
-      flags[(size_t)ms * n_ch + ch_l] = (uint8_t)flag;
-      if (trace) {
-        gpsx_loop_trace_t t;
-        t.iq[0] = (int16_t)IE; t.iq[1] = (int16_t)QE; t.iq[2] = (int16_t)IP; t.iq[3] = (int16_t)QP; t.iq[4] = (int16_t)IL; t.iq[5] = (int16_t)QL;
-        t.code_phase_fine = s.code_phase_fine;
-        t.if_freq_offset_hz = s.if_freq_offset_hz;
-        t.if_freq_accum = s.if_freq_accum;
-        trace[(size_t)ms * n_ch + ch_l] = t;
+    loop_fll(s, index, IP, QP, fll_before);
+    u32 flag = nav_bit_sync(s, sip, index, IP, now);
+    if (word_sync && (flag & 2u)) {   // a navigation bit was completed: the polarity-deciding part of the word layer
+      if (LIBC) {
+        WordSync w = word_sync_load(s);
+        s.inv_polarity_flag = (uint8_t)nav_word_sync(w, s.inv_polarity_flag, (flag >> 2) & 1u, now);
+        word_sync_store(w, s);
+      } else {
+        u32 inv = s.inv_polarity_flag;
+        if (have && k_l == 0) {       // the cold part, in HBM: one lane of the quad reads, changes and writes it
+          WordSync w = word_sync_load(st[ch_l]);
+          inv = nav_word_sync(w, inv, (flag >> 2) & 1u, now);
+          word_sync_store(w, st[ch_l]);
+        }
+        s.inv_polarity_flag = (uint8_t)quad_get<0>(inv);   // (every lane of the quad runs the loops: they must agree)
       }
     }
+    {
+      u32 latch_i = 0, latch_q = 0;
+      const int made = loop_snr(s, IP, QP, latch_i, latch_q);
+      if (made) {
+        if (LIBC) {
+          s.snr_i_latch = latch_i;
+          s.snr_q_latch = latch_q;
+        } else if (have && k_l == 0) {
+          st[ch_l].snr_i_latch = latch_i;
+          st[ch_l].snr_q_latch = latch_q;
+        }
+      }
+    }
+    flag |= (IP > 0 ? 1u : 0u) | (s.period_sync_ok_flag ? 8u : 0u) | (moved ? 16u : 0u) | 128u;
+    gpsx_loop_trace_t t = {};
+    if (trace) {
+      t.iq[0] = (int16_t)IE; t.iq[1] = (int16_t)QE; t.iq[2] = (int16_t)IP; t.iq[3] = (int16_t)QP; t.iq[4] = (int16_t)IL; t.iq[5] = (int16_t)QL;
+      t.code_phase_fine = s.code_phase_fine;
+      t.if_freq_offset_hz = s.if_freq_offset_hz;
+      t.if_freq_accum = s.if_freq_accum;
+    }
+    if (swap) {
+      // the quad's four lanes write the receiver's four channels: the served one's flag byte, zero for the others
+      const int c = 4 * unit_l + k_l;
+      if (in_wave && c < n_ch) {
+        const bool served = k_l == slot_now && have;
+        flags[(size_t)ms * n_ch + c] = served ? (uint8_t)flag : (uint8_t)0;
+        if (trace)
+          trace[(size_t)ms * n_ch + c] = served ? t : gpsx_loop_trace_t{};
+      }
+      if (index == kSlotMs - 1 || ms == n_blocks - 1) {   // the slot (or the launch) ends: the states go back
+        store_state();
+        cur_slot = -1;
+      }
+    } else if (have && k_l == 0) {
+      flags[(size_t)ms * n_ch + ch_l] = (uint8_t)flag;
+      if (trace)
+        trace[(size_t)ms * n_ch + ch_l] = t;
+    }
   }
-  if (in_wave && k_l == 0 && !stalled) {
-    quad16_store(chk, s.pll_check_buf);
-    quad16_store(sip, s.slot_ip);
-    st[ch_l] = s;
-  }
+  if (n_here && !swap)
+    store_state();
 }
 
 // the host's word layer changed its mind about the data polarity of n channels
@@ -572,17 +690,24 @@ void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block
 {
   if (n_ch <= 0 || n_blocks <= 0 || (d_ch_map && n_map <= 0))
     return;
-  int cpw = n_ch / (4 * 256 * 4);   // as launch_track_epl: ~4 workgroups per CU, 16 channels per wave at most
+  const bool mux = schedule == GPSX_SCHED_MUX17, libc = d_events != nullptr;
+  const int n_units = mux ? (n_ch + 3) / 4 : n_ch;   // MUX: a wave holds receivers (k_track_loop)
+  int cpw = n_units / (4 * 256 * 4);   // as launch_track_epl: ~4 workgroups per CU, 16 channels per wave at most
   cpw = cpw < 1 ? 1 : (cpw > 16 ? 16 : cpw);
-  const dim3 grid(d_ch_map ? (n_map + 3) / 4 : (n_ch + 4 * cpw - 1) / (4 * cpw));
-  if (schedule == GPSX_SCHED_MUX17)
-    hipLaunchKernelGGL(k_track_loop<true>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
-                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync, d_ch_map, n_map, d_reseeds,
-                       d_events, d_n_events);
+  const dim3 grid(d_ch_map ? (n_map + 3) / 4 : (n_units + 4 * cpw - 1) / (4 * cpw));
+#define GPSX_LAUNCH_LOOP(M, L)                                                                                                  \
+  hipLaunchKernelGGL((k_track_loop<M, L>), grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch, \
+                     cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync, d_ch_map, n_map, d_reseeds,  \
+                     d_events, d_n_events)
+  if (mux && libc)
+    GPSX_LAUNCH_LOOP(true, true);
+  else if (mux)
+    GPSX_LAUNCH_LOOP(true, false);
+  else if (libc)
+    GPSX_LAUNCH_LOOP(false, true);
   else
-    hipLaunchKernelGGL(k_track_loop<false>, grid, dim3(256), 0, s, d_if_blocks, block_stride, n_blocks, if_format, if_hz, d_st, n_ch,
-                       cpw, first_tick, d_chipbits, d_trk_rep, d_flags, d_trace, d_bad_prn, word_sync, d_ch_map, n_map, d_reseeds,
-                       d_events, d_n_events);
+    GPSX_LAUNCH_LOOP(false, false);
+#undef GPSX_LAUNCH_LOOP
 }
 
 }  // namespace gpsx

@@ -260,8 +260,13 @@ def test_product_and_lab_builds_and_no_register_spills(lib_path):
                  "GPSX_MX_EXPERIMENT"):
         assert knob not in strings, knob
     assert "GPSX_ACQ_ALGO" in lab_strings and "GPSX_MX_EXPERIMENT" not in lab_strings
-    mx = build.check_no_scratch()
+    res = build.check_no_scratch()
+    mx = {k: v for k, v in res.items() if "k_acq_mx" in k}
+    loops = {k: v for k, v in res.items() if "k_track_loop" in k}
     assert len(mx) == 6 and all(v["scratch_bytes"] == 0 and v["vgprs"] <= 256 for v in mx.values())
+    # the device tracking loops: no spills, and the two xorshift instantiations (the ones that run at scale) at three waves per SIMD
+    assert len(loops) == 4 and all(v["scratch_bytes"] == 0 for v in loops.values())
+    assert sorted(v["vgprs"] for v in loops.values())[:2] <= [168, 168]
     # the ablation macros do not compile into a product object
     src = os.path.join(os.path.dirname(os.path.dirname(lib_path)), "csrc", "k_acq_mx.hip")
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DGPSX_MX_NO_PIECES", src],

@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     from stm32f4_sdr_gps_amd import capi, synth
+    if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
+        capi.LIB_PATH = os.environ["GPSX_LIB"]
     eng = capi.Engine(0)
     k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     blk = synth.default_four_sv(k, seed=7)

@@ -33,11 +33,11 @@ _cache = {}
 T_HAND = 240
 
 
-def _prepare(n_sig, ms, amp, lib, literal=False, fast_synth=False):
-    """stream [ms, 2046], per-signal channel records and device loop states at tick T_HAND (host mode up to there)"""
+def _prepare(n_sig, ms, amp, lib, literal=False, fast_synth=False, t_hand=T_HAND):
+    """stream [ms, 2046], per-signal channel records and device loop states at tick t_hand (host mode up to there)"""
     import steps_driver as sd
     from stm32f4_sdr_gps_amd import capi, synth
-    key = (n_sig, ms, amp, literal, fast_synth)
+    key = (n_sig, ms, amp, literal, fast_synth, t_hand)
     if key in _cache:
         return _cache[key]
     _cache.clear()
@@ -51,7 +51,7 @@ def _prepare(n_sig, ms, amp, lib, literal=False, fast_synth=False):
     lib.gps_tracking_process_batch.restype = None
     table = np.stack([sd.preset_channel(steps, sig_prn[i], int(round(sig_dopp[i] / 500.0)) * 500, int(sig_delay[i] // 8) % 2046)
                       for i in range(n_sig)])
-    for t in range(T_HAND):
+    for t in range(t_hand):
         steps.set_time(t)
         lib.gps_tracking_process_batch(table.ctypes.data, n_sig, stream[t].ctypes.data, t & 3)
     st = np.zeros(n_sig, capi.LOOP_DTYPE)
@@ -62,12 +62,16 @@ def _prepare(n_sig, ms, amp, lib, literal=False, fast_synth=False):
     return _cache[key]
 
 
-def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, bind=True, literal=False, fast_synth=False):
+def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, bind=True, literal=False, fast_synth=False, mux17=False):
     """literal: SURVEY.md 8(d) config 5 to the letter -- one signal per channel at -5000 + 39 i Hz (no 7 Hz offset), the stream
     tests/golden/f7_steps_config5_256ch.npz was recorded on when channels = 256 and ms = 10000 (the reference's own lock count on
-    it is reported beside the device loop's)."""
+    it is reported beside the device loop's).
+    mux17: GPSX_SCHED_MUX17 -- the channels are receivers of four in the reference's 17 ms multiplex (channel c = slot c & 3 of
+    receiver c >> 2, served 4 ms of every 17); k must be a multiple of 17, the hand-over tick is 255 = 15 x 17."""
     from stm32f4_sdr_gps_amd import capi
     n = channels
+    t_hand = 255 if mux17 else T_HAND
+    assert not mux17 or k % 17 == 0
     n_sig = signals if 0 < signals < n and not literal else n
     eng = capi.Engine(0)
     lib = eng.lib
@@ -75,7 +79,9 @@ def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, b
     bound = eng.bind_thread_to_device() if bind else False
     try:
         t0 = time.time()
-        stream, sig_table, sig_st, sig_tracking, sig_dopp, sig_delay = _prepare(n_sig, ms, amp, lib, literal, fast_synth)
+        if mux17:
+            eng.set_loop_schedule(capi.SCHED_MUX17)
+        stream, sig_table, sig_st, sig_tracking, sig_dopp, sig_delay = _prepare(n_sig, ms, amp, lib, literal, fast_synth, t_hand)
         prep_s = time.time() - t0
         idx = np.arange(n) % n_sig
         table = np.ascontiguousarray(sig_table[idx])              # the host's records: word layer state per channel
@@ -88,12 +94,12 @@ def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, b
         blocks = eng.host_array((k, stream.shape[1]), np.uint8)   # page-locked: what a capture driver fills
         flags = eng.host_array((k, n), np.uint8)
         changed = np.zeros(max(16, n), np.int32)
-        n_launch = (ms - T_HAND) // k
+        n_launch = (ms - t_hand) // k
         lat = np.zeros(n_launch)
         gpu = np.zeros(n_launch)
         t_start = time.perf_counter()
         for j in range(n_launch):
-            t = T_HAND + j * k
+            t = t_hand + j * k
             if paced:      # the K-th block of this launch exists (j + 1) K milliseconds after the first block of the run
                 wait = t_start + (j + 1) * k * 1e-3 - time.perf_counter()
                 if wait > 0:
@@ -132,6 +138,7 @@ def device_loop(channels=256, ms=1200, k=20, signals=32, amp=0.12, paced=True, b
                           "false-lock check + SNR + bit synchroniser per channel and ms in one kernel, state in HBM; host: word "
                           "layer per completed navigation bit)",
                 "channels": n, "signals_in_stream": n_sig, "ms": ms, "ms_per_launch": k, "launches": n_launch,
+                "schedule": "GPSX_SCHED_MUX17 (receivers of four channels, each served 4 ms of every 17)" if mux17 else "GPSX_SCHED_EVERY_MS",
                 "paced": bool(paced), "behind_at_end_ms": float(max(0.0, behind) * 1e3),
                 "thread_on_gpu_numa_node": bool(bound), "host_workers": int(lib.gps_tracking_batch_workers()) if n >= 2048 else 1,
                 "launch_p50_us": float(np.percentile(steady, 50) * 1e6), "launch_p99_us": float(np.percentile(steady, 99) * 1e6),
@@ -163,10 +170,11 @@ def main():
     ap.add_argument("--no-bind", action="store_true")
     ap.add_argument("--literal", action="store_true", help="SURVEY.md 8(d) config 5 to the letter (see device_loop)")
     ap.add_argument("--fast-synth", action="store_true", help="synthesise the stream with synth.make_if_static (long soaks)")
+    ap.add_argument("--mux17", action="store_true", help="the reference's 17 ms multiplex (--k a multiple of 17)")
     args = ap.parse_args()
     for n in args.channels:
         print(json.dumps(device_loop(n, args.ms, args.k, args.signals, args.amp, not args.unpaced, not args.no_bind, args.literal,
-                                     args.fast_synth)), flush=True)
+                                     args.fast_synth, args.mux17)), flush=True)
 
 
 if __name__ == "__main__":
