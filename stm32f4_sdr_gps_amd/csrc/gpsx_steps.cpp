@@ -1702,10 +1702,13 @@ int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, 
         const uint8_t v = f[c];
         if ((v & 128) == 0)   // not served this millisecond (GPSX_SCHED_MUX17)
           continue;
+        // The record (1.7 KB, a cache miss at a million channels) is visited only where the flag byte has something for it: a
+        // completed bit, a located edge, or the period flag changing between two milliseconds of this launch.
+        const bool sync_changed = ms > 0 && (f[c - n_ch] & 128) && ((f[c - n_ch] ^ v) & 8);
+        if ((v & (2 | 32)) == 0 && !sync_changed)
+          continue;
         gps_nav_data_t &n = channel[c].nav_data;
         n.period_sync_ok_flag = (v & 8) ? 1 : 0;
-        if ((v & (2 | 32)) == 0)
-          continue;
         if (v & 2) {
           const uint8_t was = n.inv_polarity_flag;
           gps_nav_data_words_detection(&channel[c], (uint8_t)((v >> 2) & 1));
