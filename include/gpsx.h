@@ -245,6 +245,34 @@ void gpsx_group_destroy(gpsx_group *group);
 int  gpsx_acq_grid_sharded(gpsx_group *group, const gpsx_acq_grid_t *g, const void *const *d_if_blocks, int n_blocks,
                            gpsx_peak_t *const *d_peaks, int64_t *const *d_keys);
 
+/* ---- EXTENSION, not in the reference: the acquisition grid on WEIGHTED two-bit samples ---------------------------------
+ * The reference wires the MAX2769's sign bit only (PM/config.h:16), and everything else in this header computes what the
+ * reference computes -- from GPSX_IF_2BIT_SM captures too, whose magnitude bit it ignores.  This entry point is the one place
+ * that uses both bits; it has its own oracle (oracle/gpsx_oracle.c orc_acq_grid_weighted) and cannot change a one-bit result.
+ *   sample value   v[n] = (sign ? +1 : -1) * (magnitude ? 3 : 1)       GPSX_WEIGHTS_SIGN_MAGNITUDE
+ *                  v[n] = (sign ? +1 : -1)                              GPSX_WEIGHTS_SIGN_ONLY (the same correlator on the sign
+ *                                                                       plane: the point a processing gain is measured from)
+ *   carrier        the reference's NCO (gps_shift_to_zero_freq, PM/GPS/gps_misc.c:211-240: the accumulator's quadrant picks the
+ *                  Fs/4 pattern per 32-sample word, phase 0 at the block's start); the sixteen samples it never mixes: weight 0
+ *   replica        the C/A code circularly at fine phase tau: chip ((n - tau) mod 16368) / 16
+ *   result         per (search, PRN, Doppler bin): max over the 16368 phases of floor(sqrt(I^2 + Q^2)) (exact integers), the first
+ *                  phase reaching it (0 .. 16367), the sum over the phases and sum / 16368 -- peaks[n_search][n_prn][n_dopp].
+ * One 1 ms block per search (search s reads block s * search_stride_blocks), 4092-byte blocks whatever the context's format.
+ * Runs on the vector ALU (v_dot4_i32_i8 on sums of sixteen samples): an extension mode, about 5 x 10^10 hypotheses/s. */
+#define GPSX_WEIGHTS_SIGN_ONLY      0
+#define GPSX_WEIGHTS_SIGN_MAGNITUDE 1
+typedef struct {
+  int32_t        n_search, search_stride_blocks;
+  int32_t        n_prn;
+  const uint8_t *prns;                 /* HOST pointer, n_prn PRN numbers 1 .. 210 */
+  int32_t        dopp_min_hz, dopp_step_hz, n_dopp;
+  int32_t        weights;              /* GPSX_WEIGHTS_* */
+} gpsx_acq_weighted_t;
+int gpsx_acq_grid_weighted_dev(gpsx_ctx *ctx, const gpsx_acq_weighted_t *g, const void *d_if_blocks_2bit, int n_blocks,
+                               gpsx_peak_t *d_peaks);
+int gpsx_acq_grid_weighted(gpsx_ctx *ctx, const gpsx_acq_weighted_t *g, const uint8_t *if_blocks_2bit, int n_blocks,
+                           gpsx_peak_t *peaks);
+
 /* ---- K2+K3+K5: Early/Prompt/Late tracking correlators  (replaces the correlator part of
  *      gps_tracking_data_process, PM/GPS/tracking.c:115-138, for n_ch channels at once) ------------------------- */
 

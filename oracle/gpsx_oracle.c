@@ -318,3 +318,117 @@ void orc_track_epl(const uint8_t signal[ORC_BYTES], const uint8_t chips[ORC_CHIP
   orc_correlation_iq(rep, di, dq, prompt, &iq_out[2], &iq_out[3]);
   orc_correlation_iq(rep, di, dq, late, &iq_out[4], &iq_out[5]);
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------
+ * EXTENSION: weighted two-bit correlation (see gpsx_oracle.h).  Not a restatement of reference code: the reference
+ * has no such mode.  The grid works on sums of sixteen samples (one chip's worth) per code-phase offset; the single-hypothesis
+ * function below it is the definition itself and the tests pin one against the other.
+ * ---------------------------------------------------------------------------------------------------------- */
+static void weighted_streams(const uint8_t *blk2, float freq_hz, int use_magnitude, int8_t *vi, int8_t *vq)
+{
+  uint8_t sign[ORC_BYTES], mag[ORC_BYTES], di[ORC_BYTES], dq[ORC_BYTES];
+  memset(sign, 0, sizeof sign);
+  memset(mag, 0, sizeof mag);
+  memset(di, 0, sizeof di);
+  memset(dq, 0, sizeof dq);
+  for (int n = 0; n < ORC_SAMPLES; n++) {
+    const unsigned pair = (blk2[n >> 2] >> (2 * (n & 3))) & 3u;
+    sign[n >> 3] |= (uint8_t)((pair & 1u) << (n & 7));
+    mag[n >> 3] |= (uint8_t)((pair >> 1) << (n & 7));
+  }
+  uint32_t acc = 0;
+  orc_wipeoff(sign, freq_hz, &acc, di, dq);
+  for (int n = 0; n < ORC_SAMPLES; n++) {
+    const int w = (use_magnitude && ((mag[n >> 3] >> (n & 7)) & 1)) ? 3 : 1;
+    const int mixed = n < 511 * 32;            /* the NCO loop's 511 words; the last sixteen samples stay out */
+    vi[n] = (int8_t)(mixed ? (((di[n >> 3] >> (n & 7)) & 1) ? w : -w) : 0);
+    vq[n] = (int8_t)(mixed ? (((dq[n >> 3] >> (n & 7)) & 1) ? w : -w) : 0);
+  }
+}
+
+void orc_weighted_iq(const uint8_t if_2bit[2 * ORC_BYTES], int prn, float freq_hz, unsigned tau, int use_magnitude,
+                     int32_t *i_out, int32_t *q_out)
+{
+  static int8_t vi[ORC_SAMPLES], vq[ORC_SAMPLES];
+  uint8_t chips[ORC_CHIPS];
+  orc_ca_code(prn, chips);
+  weighted_streams(if_2bit, freq_hz, use_magnitude, vi, vq);
+  int32_t si = 0, sq = 0;
+  for (int n = 0; n < ORC_SAMPLES; n++) {
+    const int c = chips[((n + ORC_SAMPLES - (int)(tau % ORC_SAMPLES)) % ORC_SAMPLES) / 16] ? -1 : 1;
+    si += c * vi[n];
+    sq += c * vq[n];
+  }
+  *i_out = si;
+  *q_out = sq;
+}
+
+static uint32_t isqrt_u64(uint64_t e)
+{
+  uint64_t r = (uint64_t)sqrt((double)e);
+  while (r * r > e) r--;
+  while ((r + 1) * (r + 1) <= e) r++;
+  return (uint32_t)r;
+}
+
+void orc_acq_grid_weighted(const uint8_t *if_2bit_blocks, int n_search, int stride_blocks, const uint8_t *prns, int n_prn,
+                           int dopp_min_hz, int dopp_step_hz, int n_dopp, int use_magnitude, orc_peak_t *peaks, int n_threads)
+{
+  const int n_jobs = n_search * n_dopp;
+#ifdef _OPENMP
+  if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#else
+  (void)n_threads;
+#endif
+  for (int job = 0; job < n_jobs; job++) {
+    const int s = job / n_dopp, d = job % n_dopp;
+    const float freq_hz = (float)(ORC_IF_HZ + dopp_min_hz + d * dopp_step_hz);
+    int8_t *vi = malloc(ORC_SAMPLES), *vq = malloc(ORC_SAMPLES);
+    /* chip sums: sum[t0][k] = sum_{j < 16} v[(16 k + t0 + j) mod 16368], doubled so that k + c needs no wrap */
+    int16_t (*sumi)[2 * ORC_CHIPS] = malloc(sizeof(int16_t[16][2 * ORC_CHIPS]));
+    int16_t (*sumq)[2 * ORC_CHIPS] = malloc(sizeof(int16_t[16][2 * ORC_CHIPS]));
+    weighted_streams(if_2bit_blocks + (size_t)s * stride_blocks * 2 * ORC_BYTES, freq_hz, use_magnitude, vi, vq);
+    for (int t0 = 0; t0 < 16; t0++)
+      for (int k = 0; k < ORC_CHIPS; k++) {
+        int a = 0, b = 0;
+        for (int j = 0; j < 16; j++) {
+          const int n = (16 * k + t0 + j) % ORC_SAMPLES;
+          a += vi[n];
+          b += vq[n];
+        }
+        sumi[t0][k] = sumi[t0][k + ORC_CHIPS] = (int16_t)a;
+        sumq[t0][k] = sumq[t0][k + ORC_CHIPS] = (int16_t)b;
+      }
+    for (int p = 0; p < n_prn; p++) {
+      uint8_t chips[ORC_CHIPS];
+      int16_t csign[ORC_CHIPS];
+      memset(chips, 0, sizeof chips);
+      orc_ca_code(prns[p], chips);
+      for (int c = 0; c < ORC_CHIPS; c++)
+        csign[c] = chips[c] ? -1 : 1;
+      uint32_t mx = 0, at = 0, sum = 0;
+      for (int q = 0; q < ORC_CHIPS; q++)
+        for (int t0 = 0; t0 < 16; t0++) {
+          /* tau = 16 q + t0: chip c of the replica lies on samples 16 (q + c) + t0 .. + 15 */
+          int32_t ai = 0, aq = 0;
+          const int16_t *ri = &sumi[t0][q], *rq = &sumq[t0][q];
+          for (int c = 0; c < ORC_CHIPS; c++) {
+            ai += csign[c] * ri[c];
+            aq += csign[c] * rq[c];
+          }
+          const uint32_t m = isqrt_u64((uint64_t)((int64_t)ai * ai) + (uint64_t)((int64_t)aq * aq));
+          const uint32_t tau = (uint32_t)(16 * q + t0);
+          if (m > mx || (m == mx && m > 0 && tau < at)) { mx = m; at = tau; }
+          sum += m;
+        }
+      orc_peak_t *pk = &peaks[((size_t)s * n_prn + p) * n_dopp + d];
+      pk->max_val = mx;
+      pk->phase = at;
+      pk->sum = sum;
+      pk->avr = sum / ORC_SAMPLES;
+    }
+    free(vi); free(vq); free(sumi); free(sumq);
+  }
+}

@@ -92,6 +92,22 @@ void orc_acq_grid(const uint8_t *if_blocks, int n_ms, const uint8_t *prns, int n
 void orc_track_epl(const uint8_t signal[ORC_BYTES], const uint8_t chips[ORC_CHIPS], float code_phase_fine,
                    float if_freq_offset_hz, uint32_t *accum, int16_t iq_out[6]);
 
+/* ---- EXTENSION (not in the reference: it wires the MAX2769's sign bit only, PM/config.h:16): weighted correlation of
+ * two-bit sign/magnitude captures (include/gpsx.h gpsx_acq_grid_weighted).  Own entry points; nothing above calls them.
+ *   sample n of a 4092-byte block: sign = bit 2 (n & 3) of byte n >> 2, magnitude = the bit above it;
+ *   value v[n] = (sign ? +1 : -1) * (magnitude && use_magnitude ? 3 : 1);
+ *   carrier wipe-off = the reference's NCO on the sign (orc_wipeoff, phase 0 at the block's start): the sixteen samples
+ *   it never mixes (n >= 16352) carry weight 0;
+ *   replica at fine phase tau: chip ((n - tau) mod 16368) / 16, +1 for a 0 chip, -1 for a 1 chip;
+ *   I(tau) = sum_n vI[n] c(n, tau), Q likewise; magnitude = floor(sqrt(I^2 + Q^2)), exact integers. */
+/* one hypothesis straight from the definition, sample by sample */
+void orc_weighted_iq(const uint8_t if_2bit[2 * ORC_BYTES], int prn, float freq_hz, unsigned tau, int use_magnitude,
+                     int32_t *i_out, int32_t *q_out);
+/* the grid: peaks[search][prn][dopp] = {max over tau, first tau reaching it, sum over tau, sum / 16368}; search s reads
+ * block s * stride_blocks; freq = (float)(IF + dopp_min + idx * dopp_step) as orc_acq_grid */
+void orc_acq_grid_weighted(const uint8_t *if_2bit_blocks, int n_search, int stride_blocks, const uint8_t *prns, int n_prn,
+                           int dopp_min_hz, int dopp_step_hz, int n_dopp, int use_magnitude, orc_peak_t *peaks, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

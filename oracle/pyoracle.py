@@ -74,6 +74,9 @@ class Oracle:
         L.orc_acq_grid.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int]
         L.orc_track_epl.argtypes = [_u8p, _u8p, C.c_float, C.c_float, C.POINTER(C.c_uint32), _i16p]
+        L.orc_weighted_iq.argtypes = [_u8p, C.c_int, C.c_float, C.c_uint, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_acq_grid_weighted.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int]
 
     def ca_code(self, prn: int) -> np.ndarray:
         chips = np.zeros(CHIPS, np.uint8)
@@ -142,6 +145,21 @@ class Oracle:
         peaks = np.zeros((len(prns), n_dopp, n_bits), PEAK_DTYPE)
         self.lib.orc_acq_grid(np.ascontiguousarray(if_blocks, np.uint8).reshape(-1), n_ms, prns, len(prns),
                               dopp_min_hz, dopp_step_hz, n_dopp, n_bits, peaks.ctypes.data, n_threads)
+        return peaks
+
+    # -- extension: weighted two-bit correlation (not in the reference; gpsx_oracle.h) -------------------------------
+    def weighted_iq(self, block_2bit, prn, freq_hz, tau, use_magnitude=True):
+        i, q = C.c_int32(), C.c_int32()
+        self.lib.orc_weighted_iq(np.ascontiguousarray(block_2bit, np.uint8).reshape(-1), prn, np.float32(freq_hz), tau,
+                                 1 if use_magnitude else 0, C.byref(i), C.byref(q))
+        return i.value, q.value
+
+    def acq_grid_weighted(self, blocks_2bit, n_search, prns, dopp_min_hz, dopp_step_hz, n_dopp, use_magnitude=True, stride_blocks=1,
+                          n_threads=1):
+        prns = np.ascontiguousarray(prns, np.uint8)
+        peaks = np.zeros((n_search, len(prns), n_dopp), PEAK_DTYPE)
+        self.lib.orc_acq_grid_weighted(np.ascontiguousarray(blocks_2bit, np.uint8).reshape(-1), n_search, stride_blocks, prns, len(prns),
+                                       dopp_min_hz, dopp_step_hz, n_dopp, 1 if use_magnitude else 0, peaks.ctypes.data, n_threads)
         return peaks
 
     def track_epl(self, signal, chips, code_phase_fine, if_freq_offset_hz, accum):

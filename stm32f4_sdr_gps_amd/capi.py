@@ -62,6 +62,11 @@ class Config(C.Structure):   # gpsx_config_t
     _fields_ = [("sample_rate_hz", C.c_uint32), ("if_hz", C.c_int32)]
 
 
+class AcqWeightedT(C.Structure):          # gpsx_acq_weighted_t
+    _fields_ = [("n_search", C.c_int32), ("search_stride_blocks", C.c_int32), ("n_prn", C.c_int32), ("prns", C.POINTER(C.c_uint8)),
+                ("dopp_min_hz", C.c_int32), ("dopp_step_hz", C.c_int32), ("n_dopp", C.c_int32), ("weights", C.c_int32)]
+
+
 class GpsxError(RuntimeError):
     pass
 
@@ -121,6 +126,8 @@ def load_library(lab: bool | None = None) -> C.CDLL:
     lib.gpsx_loop_set_word_sync.argtypes = [C.c_void_p, C.c_int]
     lib.gpsx_loop_set_draws.argtypes = [C.c_void_p, C.c_int]
     lib.gpsx_set_acq_path.argtypes = [C.c_void_p, C.c_int]
+    lib.gpsx_acq_grid_weighted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gpsx_acq_grid_weighted_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
     lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     lib.gpsx_loop_state_from_channel.restype = None
@@ -411,6 +418,18 @@ class Engine:
             raise raised[0]
         self._chk(rc, "gpsx_track_epl_batch_chunked")
         return iq
+
+    def acq_grid_weighted(self, blocks_2bit: np.ndarray, prns, n_search: int, dopp_min_hz: int, dopp_step_hz: int, n_dopp: int,
+                          use_magnitude: bool = True, stride_blocks: int = 1) -> np.ndarray:
+        """EXTENSION (not in the reference): the acquisition grid on weighted two-bit samples -> PEAK_DTYPE [n_search, n_prn, n_dopp]"""
+        blocks = np.ascontiguousarray(blocks_2bit, np.uint8).reshape(-1, BYTES_PER_MS_2BIT)
+        prns = np.ascontiguousarray(prns, np.uint8)
+        g = AcqWeightedT(n_search, stride_blocks, len(prns), prns.ctypes.data_as(C.POINTER(C.c_uint8)), dopp_min_hz, dopp_step_hz, n_dopp,
+                         1 if use_magnitude else 0)
+        peaks = np.zeros((n_search, len(prns), n_dopp), PEAK_DTYPE)
+        self._chk(self.lib.gpsx_acq_grid_weighted(self.h, C.byref(g), blocks.ctypes.data, len(blocks), peaks.ctypes.data),
+                  "gpsx_acq_grid_weighted")
+        return peaks
 
     def set_loop_schedule(self, schedule: int) -> None:
         """SCHED_EVERY_MS or SCHED_MUX17 (the reference's four-channel 17 ms multiplex) for this context's track_loop launches"""

@@ -240,6 +240,7 @@ void gpsx_destroy(gpsx_ctx *ctx)
     (void)hipHostFree(ctx->h_bad_prn);
   if (ctx->h_loop_n_events)
     (void)hipHostFree(ctx->h_loop_n_events);
+  if (ctx->d_weighted_prns) (void)hipFree(ctx->d_weighted_prns);
   if (ctx->d_loop_reseeds) (void)hipFree(ctx->d_loop_reseeds);
   if (ctx->d_loop_events) (void)hipFree(ctx->d_loop_events);
   if (ctx->d_loop_chmap) (void)hipFree(ctx->d_loop_chmap);
@@ -1076,6 +1077,71 @@ int gpsx_track_epl_batch(gpsx_ctx *ctx, const uint8_t *if_block, gpsx_trk_state_
   HIPCHK(ctx, hipMemcpyAsync(iq_out, d_iq, (size_t)n_ch * 12, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return track_prn_verdict(ctx);
+}
+
+/* ---- extension: weighted two-bit acquisition grid ------------------------------------------------------------------------ */
+
+namespace {
+int check_weighted(gpsx_ctx *ctx, const gpsx_acq_weighted_t *g, int n_blocks)
+{
+  if (!g || !g->prns)
+    return fail(ctx, GPSX_EINVAL, "null descriptor");
+  if (g->n_search < 1 || g->n_prn < 1 || g->n_dopp < 1 || g->search_stride_blocks < 0 || g->n_prn > 255)
+    return fail(ctx, GPSX_EINVAL, "bad grid shape");
+  if (g->weights != GPSX_WEIGHTS_SIGN_ONLY && g->weights != GPSX_WEIGHTS_SIGN_MAGNITUDE)
+    return fail(ctx, GPSX_EINVAL, "unknown weights");
+  if ((long)(g->n_search - 1) * g->search_stride_blocks + 1 > n_blocks)
+    return fail(ctx, GPSX_EINVAL, "not enough blocks for the searches");
+  for (int i = 0; i < g->n_prn; i++)
+    if (g->prns[i] < 1 || g->prns[i] > GPSX_MAX_PRN)
+      return fail(ctx, GPSX_EINVAL, "PRN outside 1..210");
+  return GPSX_OK;
+}
+}  // namespace
+
+int gpsx_acq_grid_weighted_dev(gpsx_ctx *ctx, const gpsx_acq_weighted_t *g, const void *d_if_blocks_2bit, int n_blocks,
+                               gpsx_peak_t *d_peaks)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (int rc = check_weighted(ctx, g, n_blocks)) return rc;
+  if (!d_if_blocks_2bit || !d_peaks)
+    return fail(ctx, GPSX_EINVAL, "null device pointer");
+  // the PRN list behind the kernel: a few bytes through the arena's tail would collide with a host-pointer caller's buffers --
+  // its own small allocation, grow-only
+  if (ctx->weighted_prns_cap < g->n_prn) {
+    if (ctx->d_weighted_prns) (void)hipFree(ctx->d_weighted_prns);
+    ctx->d_weighted_prns = nullptr;
+    ctx->weighted_prns_cap = 0;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_weighted_prns, 256));
+    ctx->weighted_prns_cap = 255;
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_weighted_prns, g->prns, (size_t)g->n_prn, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (the caller's PRN array is the caller's again)
+  if (launch_acq_weighted(ctx->stream, static_cast<const uint8_t *>(d_if_blocks_2bit), g->n_search, g->search_stride_blocks, g->n_prn,
+                          ctx->d_chips_all, ctx->d_weighted_prns, ctx->if_hz, g->dopp_min_hz, g->dopp_step_hz, g->n_dopp,
+                          g->weights == GPSX_WEIGHTS_SIGN_MAGNITUDE, d_peaks))
+    return fail(ctx, GPSX_EIO, "k_acq_weighted: the kernel's LDS size was refused");
+  LAUNCHCHK(ctx, "k_acq_weighted");
+  ctx->last_kernel = "k_acq_weighted";
+  return GPSX_OK;
+}
+
+int gpsx_acq_grid_weighted(gpsx_ctx *ctx, const gpsx_acq_weighted_t *g, const uint8_t *if_blocks_2bit, int n_blocks, gpsx_peak_t *peaks)
+{
+  if (int rc = use_device(ctx)) return rc;
+  if (int rc = check_weighted(ctx, g, n_blocks)) return rc;
+  if (!if_blocks_2bit || !peaks)
+    return fail(ctx, GPSX_EINVAL, "null host pointer");
+  const size_t if_bytes = (size_t)n_blocks * GPSX_BYTES_PER_MS_2BIT, n_peaks = (size_t)g->n_search * g->n_prn * g->n_dopp;
+  if (int rc = arena_reset(ctx, arena_size(if_bytes + 2) + arena_size(n_peaks * sizeof(gpsx_peak_t))))
+    return rc;
+  uint8_t *d_if = arena_take<uint8_t>(ctx, if_bytes + 2);
+  gpsx_peak_t *d_peaks = arena_take<gpsx_peak_t>(ctx, n_peaks);
+  HIPCHK(ctx, hipMemcpyAsync(d_if, if_blocks_2bit, if_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (int rc = gpsx_acq_grid_weighted_dev(ctx, g, d_if, n_blocks, d_peaks)) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(peaks, d_peaks, n_peaks * sizeof(gpsx_peak_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GPSX_OK;
 }
 
 /* ---- the tracking loops on the device ---------------------------------------------------------------------------------- */

@@ -50,6 +50,8 @@ struct gpsx_ctx {
   int if_format = GPSX_IF_1BIT;
   int loop_schedule = GPSX_SCHED_EVERY_MS;   // gpsx_loop_set_schedule
   int loop_word_sync = GPSX_WORDSYNC_DEVICE; // gpsx_loop_set_word_sync
+  uint8_t *d_weighted_prns = nullptr;        // gpsx_acq_grid_weighted's PRN list
+  int weighted_prns_cap = 0;
   int loop_draws = GPSX_DRAWS_XORSHIFT;      // gpsx_loop_set_draws
   // GPSX_DRAWS_LIBC: per-channel candidate table, event list, channel list of the second pass (grow-only), event counter (mapped)
   gpsx::gpsx_loop_reseed_t *d_loop_reseeds = nullptr;

@@ -140,6 +140,10 @@ void launch_track_epl(hipStream_t s, const uint8_t *d_if_block, int if_format, i
                       uint32_t *d_bad_prn, int wave_from);
 constexpr int kTrackRepStride = 1032;   // words per PRN row of d_trk_rep
 void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n_slots, uint32_t *d_rep);
+// extension: the acquisition grid on weighted two-bit samples (k_acq_weighted.hip); -1 if the kernel's LDS size is refused
+int launch_acq_weighted(hipStream_t s, const uint8_t *d_if_blocks, int n_search, int stride_blocks, int n_prn,
+                        const uint8_t *d_chips_all, const uint8_t *d_prns, int if_hz, int dopp_min_hz, int dopp_step_hz, int n_dopp,
+                        int use_magnitude, gpsx_peak_t *d_peaks);
 // GPSX_DRAWS_LIBC (include/gpsx.h): a channel's false-lock jump reported by the first pass / its carrier candidate for the second
 struct gpsx_loop_event_t { int32_t channel, ms, if_freq_i16, found_freq_hz; };
 struct gpsx_loop_reseed_t { int32_t ms, candidate; };   // ms < 0: none
