@@ -894,6 +894,9 @@ def main():
                                                            (counters.get("kernel_trace_min_ns") or 0) * 1e-6 or None,
                                                            (counters.get("kernel_trace_max_ns") or 0) * 1e-6 or None]
                 roof["frac_profiled"] = flops / (prof_ns * 1e-9) / 1e12 / MFMA_FP4_PEAK_TFLOPS
+                roof["frac_profiled_basis"] = "median launch of the committed rocprofv3 kernel trace" if counters.get("kernel_trace_median_ns") \
+                    else "mean launch of the committed rocprofv3 kernel trace"
+                roof["frac_profiled_mean"] = flops / (counters["kernel_trace_avg_ns"] * 1e-9) / 1e12 / MFMA_FP4_PEAK_TFLOPS
             if counters and counters.get("gpu_cycles_per_launch") and counters.get("SQ_VALU_MFMA_BUSY_CYCLES"):
                 # the profiled launch: shader cycles actually spent (the clock follows the power budget) -- the share of
                 # them the matrix pipe was busy, and the clock they imply; `frac` above is against the 2.4 GHz peak

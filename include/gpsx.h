@@ -248,7 +248,7 @@ int  gpsx_acq_grid_sharded(gpsx_group *group, const gpsx_acq_grid_t *g, const vo
 /* ---- EXTENSION, not in the reference: the acquisition grid on WEIGHTED two-bit samples ---------------------------------
  * The reference wires the MAX2769's sign bit only (PM/config.h:16), and everything else in this header computes what the
  * reference computes -- from GPSX_IF_2BIT_SM captures too, whose magnitude bit it ignores.  This entry point is the one place
- * that uses both bits; it has its own oracle (oracle/gpsx_oracle.c orc_acq_grid_weighted) and cannot change a one-bit result.
+ * that uses both bits; it has its own CPU restatement to be tested against (tests/test_gpu_weighted.py) and cannot change a one-bit result.
  *   sample value   v[n] = (sign ? +1 : -1) * (magnitude ? 3 : 1)       GPSX_WEIGHTS_SIGN_MAGNITUDE
  *                  v[n] = (sign ? +1 : -1)                              GPSX_WEIGHTS_SIGN_ONLY (the same correlator on the sign
  *                                                                       plane: the point a processing gain is measured from)

@@ -7,7 +7,7 @@
 //            word, phase 0 at the block's start, PM/GPS/gps_misc.c:211-240); the sixteen samples the NCO never mixes: weight 0
 //   I(tau) = sum_n vI[n] c[((n - tau) mod 16368) / 16],  c = +1 / -1 for chip 0 / 1;  Q likewise
 //   per (search, PRN, Doppler): max over the 16368 fine phases tau of floor(sqrt(I^2 + Q^2)), the first tau reaching it, the sum.
-// Checked against oracle/gpsx_oracle.c orc_acq_grid_weighted (tests/test_gpu_weighted.py), which is pinned to the definition.
+// Checked against its own CPU restatement (tests/test_gpu_weighted.py), itself pinned to this definition sample by sample.
 //
 // Formulation: with tau = 16 q + t0 the replica's chip c lies on samples 16 (q + c) + t0 .. + 15, so
 //   I(16 q + t0) = sum_c c[c] S_t0[(q + c) mod 1023],   S_t0[k] = sum_{j < 16} vI[(16 k + t0 + j) mod 16368]   (|S| <= 48: int8)
