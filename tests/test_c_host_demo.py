@@ -36,15 +36,20 @@ def test_c_host_builds_and_fails_loudly_without_gpu(demo_exe, tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_reaches_the_reference_end_state(demo_exe, tmp_path):
+@pytest.mark.parametrize("device_loops", [False, True])
+def test_c_host_reaches_the_reference_end_state(demo_exe, tmp_path, device_loops):
+    """... with the tracking steps through the reference-named calls, and (--device-loops) with the loops on the GPU in the
+    firmware's 17 ms multiplex from the first cycle start on which all four channels track: the same end state, bit for bit."""
     from stm32f4_sdr_gps_amd import synth
     g = load("f7_steps_hints.npz")
     n_ms = int(g["n_ms"])
     cap = tmp_path / "rec_file.bin"
     synth.four_sv_with_nav(n_ms, seed=7).tofile(cap)
-    out = subprocess.run([demo_exe, str(cap)], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([demo_exe, str(cap)] + (["--device-loops"] if device_loops else []), capture_output=True, text=True, check=True).stdout
     lines = [l for l in out.splitlines() if l.startswith("PRN=")]
     assert len(lines) == 4 and f"processed_ms={n_ms}" in out
+    handed = int(re.search(r"handed_to_the_device_at_ms=(-?\d+)", out).group(1))
+    assert (400 < handed < 600 and handed % 17 == 0) if device_loops else handed == -1
     last = g["snaps"][-1]
     for i, line in enumerate(lines):
         m = re.search(r"acq_state=(\d+) code_phase=(\d+) doppler_hz=(-?\d+) trk_state=(\d+) code_phase_fine=\S+\(0x(\w+)\) "
