@@ -257,7 +257,7 @@ def tracking_device_loop(ms=1200, k=20):
     # the reference's own receiver shape on the device: four channels per receiver in the 17 ms multiplex, one launch per cycle
     mux_rows, mux_best = [], None
     try:
-        for n in (256, 1048576, 4194304, 5242880, 6291456):
+        for n in (256, 1048576, 4194304, 5242880):   # (5 M channels = 8.8 GB of host channel records: the ladder stops there)
             r = mod.device_loop(n, 1275, 17, 32, mux17=True)
             mux_rows.append({kk: r[kk] for kk in keep})
             if not r["real_time"]:
