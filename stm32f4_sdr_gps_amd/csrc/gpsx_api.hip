@@ -1189,10 +1189,11 @@ namespace {
 
 // One launch of the device loops.  GPSX_DRAWS_XORSHIFT: enqueue and return.  GPSX_DRAWS_LIBC (the reference's own
 // draws, PM/GPS/tracking.c:309-326): first pass with an empty candidate table -- a channel whose false-lock detector fires
-// reports (channel, millisecond, its carrier) and stands still, its state in HBM untouched; the host draws for the reported
+// reports (channel, millisecond, its carrier) and stands still, its state in HBM as it came into the registers (the launch's
+// input, or under the multiplex the start of the slot it stops in -- ms_from); the host draws for the reported
 // jumps in the order a single-threaded loop over the milliseconds and channels makes them (libc's rand(), the `do ... while`
-// of the reference with its int16 arithmetic); second pass over the reported channels only, one per wave, from the launch's
-// input state, with the candidates in the table.  A channel jumps at most once in 81 four-millisecond groups, hence the
+// of the reference with its int16 arithmetic); second pass over the reported channels only, one per wave, each from its ms_from
+// on, with the candidates in the table.  A channel jumps at most once in 81 four-millisecond groups, hence the
 // launch-length limit; the passes are repeated should a replayed channel report again.  Waits for its kernels.
 int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_blocks, gpsx_loop_state_t *d_state, int n_ch,
                    uint32_t first_tick, uint8_t *d_flags, gpsx_loop_trace_t *d_trace, uint32_t *d_bad_prn)
@@ -1244,6 +1245,7 @@ int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_b
     });
     cand.resize(n);
     chans.resize(n);
+
     for (uint32_t i = 0; i < n; i++) {
       int16_t delta, candidate;
       do {   // tracking.c:313-324, its types
@@ -1251,7 +1253,7 @@ int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_b
         candidate = (int16_t)(ev[i].found_freq_hz - r + 250);
         delta = (int16_t)((int16_t)ev[i].if_freq_i16 - candidate);
       } while (std::abs((int)delta) < 200);
-      cand[i] = gpsx_loop_reseed_t{ev[i].ms, candidate};
+      cand[i] = gpsx_loop_reseed_t{ev[i].ms, candidate, ev[i].ms_from};
       chans[i] = ev[i].channel;
       HIPCHK(ctx, hipMemcpyAsync(ctx->d_loop_reseeds + ev[i].channel, &cand[i], sizeof(gpsx_loop_reseed_t), hipMemcpyHostToDevice,
                                  ctx->stream));

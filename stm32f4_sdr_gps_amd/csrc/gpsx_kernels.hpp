@@ -145,8 +145,10 @@ int launch_acq_weighted(hipStream_t s, const uint8_t *d_if_blocks, int n_search,
                         const uint8_t *d_chips_all, const uint8_t *d_prns, int if_hz, int dopp_min_hz, int dopp_step_hz, int n_dopp,
                         int use_magnitude, gpsx_peak_t *d_peaks);
 // GPSX_DRAWS_LIBC (include/gpsx.h): a channel's false-lock jump reported by the first pass / its carrier candidate for the second
-struct gpsx_loop_event_t { int32_t channel, ms, if_freq_i16, found_freq_hz; };
-struct gpsx_loop_reseed_t { int32_t ms, candidate; };   // ms < 0: none
+// (ms_from: the millisecond of the launch at which the channel's state in HBM is valid -- 0, or, under the multiplex, the first
+//  millisecond of the slot it stopped in: its earlier slots of the launch were stored when they ended -- the replay starts there)
+struct gpsx_loop_event_t { int32_t channel, ms, if_freq_i16, found_freq_hz, ms_from; };
+struct gpsx_loop_reseed_t { int32_t ms, candidate, ms_from; };   // ms < 0: none
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, int word_sync,
                        const uint32_t *d_chipbits, const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace,

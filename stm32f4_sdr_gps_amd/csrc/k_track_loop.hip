@@ -517,6 +517,8 @@ __global__ __launch_bounds__(256, LIBC ? 2 : 3) void k_track_loop(const uint8_t 
   if (n_here && !swap)
     load_state(unit_l < n_ch ? unit_l : 0);
   const int slot_fixed = ch_l & 3;   // (MUX without swapping: the channel's slot)
+  int state_from = 0;                // the millisecond of this launch at which the state now in registers was in HBM
+  const int replay_from = (LIBC && ch_map && n_here) ? reseeds[ch_l].ms_from : 0;
 
 #pragma unroll 1
   for (int ms = 0; ms < n_blocks; ms++) {
@@ -525,6 +527,8 @@ __global__ __launch_bounds__(256, LIBC ? 2 : 3) void k_track_loop(const uint8_t 
     __syncthreads();
     if (!n_here)
       continue;
+    if (LIBC && ms < replay_from)    // a replayed channel: its state in HBM is the one it had HERE (the launch's earlier
+      continue;                      // milliseconds are the first pass's, and valid)
     const u32 now = first_tick + (u32)ms;
     int index = (int)(now & 3u);
     int n_act = n_here;              // quads with a channel this millisecond
@@ -549,6 +553,7 @@ __global__ __launch_bounds__(256, LIBC ? 2 : 3) void k_track_loop(const uint8_t 
           have = c_l < n_act;
           stalled = (stalled_slots >> slot_now) & 1u;
           load_state(have ? 4 * unit_l + slot_now : 0);
+          state_from = ms;
         }
       } else if (idle || slot_now != slot_fixed) {
         // not this channel's slot (or the cycle's idle millisecond): nothing of the channel moves
@@ -589,8 +594,9 @@ __global__ __launch_bounds__(256, LIBC ? 2 : 3) void k_track_loop(const uint8_t 
         moved = true;
       } else {
         // GPSX_DRAWS_LIBC: the draw is the host's (libc's rand(), in the reference's order).  First pass: report and stop
-        // advancing this channel -- its state in HBM stays the launch's input; second pass: the host's candidate for this
-        // millisecond is in the table.
+        // advancing this channel -- its state in HBM stays what it was when it came into the registers (the launch's input;
+        // under the multiplex the state at the start of the slot it stops in); second pass: replayed from there, the host's
+        // candidate for this millisecond is in the table.
         const gpsx_loop_reseed_t r = reseeds[ch_l];
         if (r.ms == ms) {
           s.reseed_count++;
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(256, LIBC ? 2 : 3) void k_track_loop(const uint8_t 
           stalled_slots |= 1u << slot_now;
           if (have && k_l == 0) {
             const u32 ev = atomicAdd(n_events, 1u);
-            events[ev] = gpsx_loop_event_t{ch_l, ms, (int)(int16_t)s.if_freq_offset_hz, (int)s.found_freq_offset_hz};
+            events[ev] = gpsx_loop_event_t{ch_l, ms, (int)(int16_t)s.if_freq_offset_hz, (int)s.found_freq_offset_hz, state_from};
           }
         }
       }

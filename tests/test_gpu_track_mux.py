@@ -327,3 +327,109 @@ def test_mux_at_scale_every_receiver_is_the_four_channel_receiver(eng):
         f, end = run(big, k)
         assert np.array_equal(f, f4[:, np.arange(n) % 4]), k
         assert end.tobytes() == end4[np.arange(n) % 4].tobytes(), k
+
+
+_MUX_LIBC_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+k = int(sys.argv[2])
+import steps_driver as sd
+from stm32f4_sdr_gps_amd import capi, synth
+CYCLE, n_ms = 17, 5100
+sats = [synth.Sat(5, 912.5, 1600.0, 0.6, 0.3), synth.Sat(14, 4037.0, 4000.0, 0.6, 1.1), synth.Sat(20, -1025.0, 9000.0, 0.6, 2.5),
+        synth.Sat(30, 2018.0, 13000.0, 0.6, 4.0)]
+stream = synth.make_if(n_ms, sats, noise_amp=1.0, seed=7)
+# channels 1 and 3 handed over one Doppler bin off: they settle in a false lock, the detector counts (at index 3 of their slot
+# only: every 17 ms) and after ~1.6 s moves them by a draw from rand() (tracking.c:309-326)
+presets = [(5, 1000, 200), (14, 4500, 500), (20, -1000, 1125), (30, 2500, 1625)]
+lib = capi.load_library()
+steps = sd.StepsLib(lib, False)
+lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
+lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+lib.gpsx_loop_state_to_channel.argtypes = [C.c_void_p, C.c_void_p]
+# every kernel of both paths once on another context, THEN srand(): the ROCm runtime draws from rand() when code objects load
+warm = capi.Engine(0)
+jobs = np.zeros(1, capi.JOB_DTYPE); jobs[0] = (0, 1, 5, capi.IF_HZ + 900.0, 0, 0, 2046)
+warm.acq_jobs(stream[:1], jobs)
+st = np.zeros(4, capi.TRK_DTYPE); st["prn"] = [5, 14, 20, 30]
+warm.track_epl(stream[0], st); warm.rewind(st, np.full(4, 3, np.uint8))
+wl = np.zeros(4, capi.LOOP_DTYPE); wl["prn"] = 1; wl["rng"] = 1
+wd = warm.malloc(wl.nbytes); warm.h2d(wd, wl)
+warm.set_loop_draws(capi.DRAWS_LIBC); warm.set_loop_schedule(capi.SCHED_MUX17); warm.track_loop(stream[:2], wd, 4, 0)
+warm.free(wd); warm.close()
+lib.gps_fill_summ_table()
+libc = C.CDLL("libc.so.6")
+
+def host_step(table, t):
+    steps.set_time(t)
+    big = t % CYCLE
+    sat = big // 4 if big < 16 else 0
+    lib.gps_tracking_process(table[sat].ctypes.data, stream[t].ctypes.data, 0xFF if big == 16 else big % 4)
+
+# run A: the host mode (the reference's own calls) all the way
+libc.srand(1)
+table = np.stack([sd.preset_channel(steps, *p) for p in presets])
+want = {}
+for t in range(n_ms):
+    host_step(table, t)
+    if t % CYCLE == CYCLE - 1:
+        want[t] = sd.snapshot(table)
+freq_a = table[:, 60 + 4:60 + 8].copy().view("<f4")[:, 0]
+# run B: host mode to the first cycle start with every channel tracking, then the device loop (MUX17, libc draws)
+libc.srand(1)
+table = np.stack([sd.preset_channel(steps, *p) for p in presets])
+eng = capi.Engine(0)
+eng.set_loop_schedule(capi.SCHED_MUX17)
+eng.set_loop_draws(capi.DRAWS_LIBC)
+st = np.zeros(4, capi.LOOP_DTYPE)
+d, t, jumps, checked, handed = None, 0, [], 0, None
+while t < n_ms:
+    if d is None:
+        state = table[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0]
+        if t % CYCLE == 0 and (state == sd.TRK_RUN).all():
+            for i in range(4):
+                lib.gpsx_loop_state_from_channel(table[i].ctypes.data, i + 1, st[i:i + 1].ctypes.data)
+            d = eng.malloc(st.nbytes); eng.h2d(d, st); handed = t
+        else:
+            host_step(table, t); t += 1
+            continue
+    kk = min(k, n_ms - t)
+    flags, _ = eng.track_loop(stream[t:t + kk], d, 4, t)
+    lib.gps_tracking_words_batch(table.ctypes.data, 4, flags.ctypes.data, kk, t, None, 0)
+    eng.d2h(st, d)
+    for i in range(4):
+        lib.gpsx_loop_state_to_channel(st[i:i + 1].ctypes.data, table[i].ctypes.data)
+    jumps += [(t + int(ms), int(c)) for ms, c in np.argwhere(flags & 16)]
+    t += kk
+    if (t - 1) in want:
+        if not np.array_equal(sd.snapshot(table), want[t - 1]):
+            bad = np.argwhere(sd.snapshot(table) != want[t - 1])
+            print("MISMATCH at cycle end", t - 1, "(channel, byte)", bad[:24].tolist(), "jumps so far", jumps,
+                  "freq got / want", sd.snapshot(table)[:, 64:68].copy().view("<f4")[:, 0].tolist(), want[t - 1][:, 64:68].copy().view("<f4")[:, 0].tolist(),
+                  "accum got / want", sd.snapshot(table)[:, 68:72].copy().view("<u4")[:, 0].tolist(), want[t - 1][:, 68:72].copy().view("<u4")[:, 0].tolist())
+            sys.exit(1)
+        checked += 1
+print("RESULT", handed, checked, len(jumps), sorted(set(c for _, c in jumps)), [round(float(f), 1) for f in freq_a])
+eng.free(d); eng.close()
+"""
+
+
+@pytest.mark.parametrize("k", [17, 51])
+def test_mux_receiver_with_false_lock_jumps_follows_the_host_mode_draw_for_draw(k):
+    """GPSX_SCHED_MUX17 + GPSX_DRAWS_LIBC, the combination a four-channel receiver that seeds rand() like the reference runs: two
+    of the four channels are handed over one Doppler bin off, fall into a false lock and are moved by draws from rand().  Run A:
+    the library's host mode (the reference's own calls in the 17 ms multiplex; pinned to the reference incl. its draws by
+    tests/test_gpu_steps.py) all the way.  Run B: the device loop from the first cycle start on which all four track, launches
+    of k ms -- a channel that wants to jump reports and stands still, the host draws, the channel is replayed (one wave, its own
+    slot).  The four records must be the host mode's, byte for byte, at the end of every launch; there must be jumps."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _MUX_LIBC_SCRIPT, root, str(k)], capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+    assert r.returncode == 0 and line, (r.stdout[-1500:], r.stderr[-1500:])
+    f = line[0].split()
+    print(line[0])
+    assert int(f[1]) % 17 == 0 and int(f[2]) >= (5100 - int(f[1])) // k - 1 and int(f[3]) >= 1
