@@ -5,15 +5,20 @@
 // a wave at once, what gps_tracking_data_process does with the six accumulators (PM/GPS/tracking.c:132-170):
 //   gps_tracking_dll :338-393   gps_tracking_pll :175-205   gps_tracking_fll :208-256 with gps_tracking_pll_check :261-327
 //   gps_nav_data_analyse_new_code, PM/GPS/nav_data.c:46-253 (20 ms bit period, bit edge, bit votes)   SNR :141-169
+//   the polarity-deciding part of gps_nav_data_words_detection, nav_data.c:257-352 (nav_word_sync)
 // restated from csrc/gpsx_steps.cpp's host versions expression by expression: the same float32 operations in the same order
-// (this file is built with -ffp-contract=off and correctly rounded division like the rest), so that everything but the
-// three arctangents and the SNR's logarithm is bit-identical to the host mode.
+// (this file is built with -ffp-contract=off and correctly rounded division like the rest), the float arctangents as the C
+// library computes them (gpsx_libm.hpp): bit-identical to the host mode but for the double-precision atan2 of the PLL's
+// IP <= 0 branch (one argument pair in ~2^29) and the SNR's logarithm (a display value; the host record gets the host's).
+// Serving schedules (every millisecond / the reference's 17 ms four-channel multiplex), the false-lock draws' two sources and
+// what stays in registers: in front of the kernel below.
 //
 // Lanes: lane 4 c + k of a wave holds channel c of the wave (k = 0 / 1 / 2 = Early / Prompt / Late in the correlators).
 // All four lanes of a quad carry the channel's whole loop state and run the loops redundantly -- they all need the new
 // code phase and carrier for the next millisecond's correlators, and a broadcast would cost what the arithmetic does.
-// HBM traffic per launch: K x 2 KB of samples per workgroup (L2 hits after the first), 96 B of state in and out and K flag
-// bytes per channel: the kernel is bound by the correlators' vector instructions exactly as k_track_epl_wave is.
+// HBM traffic per launch: K x 2 KB of samples per workgroup (L2 hits after the first), 100 B of live state in and out (per slot
+// under the multiplex), the 20 cold bytes where a bit completes, and K flag bytes per channel: the kernel is bound by the
+// correlators' vector instructions exactly as k_track_epl_wave is.
 #include <hip/hip_runtime.h>
 
 #include <initializer_list>

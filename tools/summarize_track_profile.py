@@ -65,9 +65,9 @@ def main(tag="r03_track", channels=212992, match="k_track_epl", ms_per_launch=1)
         d["vmem_read_instructions_per_channel"] = c["SQ_INSTS_VMEM_RD"] / channels
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         d["hbm_bytes_per_launch"] = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
-        if int(ms_per_launch) > 1 or "loop" in match:   # k_track_loop: 96 B of state in and out per channel, K flag bytes, K blocks
+        if int(ms_per_launch) > 1 or "loop" in match:   # k_track_loop: 100 B of live state in and out per channel, K flag bytes, K blocks
             n_real = channels // int(ms_per_launch)
-            d["algorithmic_bytes_per_launch"] = n_real * (2 * 96 + int(ms_per_launch)) + 2046 * int(ms_per_launch)
+            d["algorithmic_bytes_per_launch"] = n_real * (2 * 100 + int(ms_per_launch)) + 2046 * int(ms_per_launch)
         else:
             d["algorithmic_bytes_per_launch"] = channels * (16 + 4 + 12) + 2046
     d["round2"] = {"kernel_trace_avg_ns": 234458.8, "valu_instructions_per_channel": 523.0,
