@@ -999,11 +999,23 @@ def main():
             except Exception as exc:   # (the reported baseline: its failure is reported, the line still goes out)
                 line["cpu_baseline"] = {"error": repr(exc)}
             line["cpu_host"] = {"logical_cpus": os.cpu_count()}
-        print(json.dumps(line), flush=True)
+        out_line = json.dumps(line)
+    else:
+        out_line = None
 
     eng.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    # The line is the LAST thing this job writes to stdout: RCCL prints a version banner to stdout when its communicator goes
+    # (seen behind the line on the test box) -- so the communicator goes first, and with a process group around every rank
+    # leaves through os._exit, which skips the library's exit-time printing.
+    sys.stdout.flush()
+    if out_line is not None:
+        print(out_line, flush=True)
+    if use_dist:
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
