@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_track_loop alone (device-resident blocks, states and flag bytes; HIP events on the engine's stream): K milliseconds per
-launch for n channels.  usage: bench_track_loop_kernel.py [K] [channels ...]"""
+launch for n channels.  usage: bench_track_loop_kernel.py [K] [channels ...]   ($GPSX_LOOP_MUX17=1: the 17 ms multiplex, K a multiple of 17)"""
 import ctypes as C
 import json
 import os
@@ -17,7 +17,10 @@ def main():
     if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library
         capi.LIB_PATH = os.environ["GPSX_LIB"]
     eng = capi.Engine(0)
-    k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    mux = os.environ.get("GPSX_LOOP_MUX17") == "1"
+    if mux:
+        eng.set_loop_schedule(capi.SCHED_MUX17)
+    k = int(sys.argv[1]) if len(sys.argv) > 1 else (17 if mux else 20)
     blk = synth.default_four_sv(k, seed=7)
     d_if = eng.malloc(blk.nbytes + 2)
     eng.h2d(d_if, np.concatenate([blk.reshape(-1), np.zeros(2, np.uint8)]))
@@ -45,7 +48,7 @@ def main():
         rows.append({"channels": n, "ms_per_launch": k, "kernel_us": us, "us_per_ms_of_stream": us / k})
         eng.free(d_st)
         eng.free(d_fl)
-    print(json.dumps({"kernel": "gpsx::k_track_loop", "rows": rows}))
+    print(json.dumps({"kernel": "gpsx::k_track_loop", "schedule": "GPSX_SCHED_MUX17" if mux else "GPSX_SCHED_EVERY_MS", "rows": rows}))
 
 
 if __name__ == "__main__":
