@@ -99,3 +99,36 @@ def test_plain_python_launch_refuses_more_ranks_than_gpus():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
                          capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert res.returncode != 0 and "GPU(s) visible" in res.stderr
+
+
+def test_eight_ranks_on_one_device(tmp_path, oracle):
+    """The driver's largest launch shape -- eight ranks -- on the one-GPU box: every rank on device 0, gloo instead of RCCL, the
+    plain-`python` launch.  One ten-block search per rank (weak scaling): 8 x 84 units as eight contiguous runs of 84; and the
+    strong form of ONE search (north_star's literal point): its 84 units as runs of 10 or 11.  Merged table = unsharded sweep
+    (GPSX_BENCH_VERIFY), rank 0's oracle sample inside the run, a full row of the merged table against the oracle here."""
+    import numpy as np
+    from stm32f4_sdr_gps_amd import synth
+    for scaling, searches, n_search in (("weak", 1, 8), ("strong", 1, 1)):
+        dump = str(tmp_path / f"merged_{scaling}.npy")
+        env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1", GPSX_BENCH_DUMP_KEYS=dump)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--searches", str(searches),
+               "--scaling", scaling, "--no-cpu-baseline"]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert "VERIFY sharded == unsharded" in res.stdout
+        out_lines = [l for l in res.stdout.splitlines() if l.strip()]
+        line = json.loads(out_lines[-1])                      # the JSON line is the LAST thing on stdout
+        assert line["n_gpus"] == 8 and line["scaling"] == scaling and line["communicator"]["rccl_ranks"] == 8
+        assert line["config"]["hypotheses_per_step"] == n_search * 10 * 32 * 21 * 16368
+        assert line["parity"]["parity_checked"] is True
+        keys = np.load(dump)
+        assert keys.shape == (n_search, 32, 21)
+        s_ = n_search - 1
+        blocks = synth.cold_start_block(n_search * 10, seed=11, amp_scale=0.25)[s_ * 10:(s_ + 1) * 10]
+        prns = np.array([9, 17, 25], np.uint8)                 # one PRN of each of three 8-PRN groups, a Doppler bin per rank's run
+        want = oracle.acq_grid(blocks, 10, prns, -5000, 2500, 5, 8, n_threads=max(4, min(32, len(os.sched_getaffinity(0)))))
+        fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+        assert np.array_equal(keys[s_][np.ix_(prns.astype(int) - 1, [0, 5, 10, 15, 20])],
+                              ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)), scaling
