@@ -433,3 +433,71 @@ def test_mux_receiver_with_false_lock_jumps_follows_the_host_mode_draw_for_draw(
     f = line[0].split()
     print(line[0])
     assert int(f[1]) % 17 == 0 and int(f[2]) >= (5100 - int(f[1])) // k - 1 and int(f[3]) >= 1
+
+
+def test_twelve_random_receivers_on_the_device_equal_their_host_mode_runs(eng):
+    """Beyond the one four-channel trace: twelve receivers with random channel tables on a stream of eight satellites (each receiver
+    tracks four of them, in a random slot order, handed over from random acquisition results: Doppler to the 500 Hz bin, code phase
+    to the byte) -- so that slots meet bit edges, code phases and carrier phases in many alignments.  Reference per receiver: the
+    library's host mode, the reference's own calls in the 17 ms multiplex (pinned to the reference's C by tests/test_gpu_steps.py),
+    run alone from tick 0 to the end, pre-tracking included.  Device: all receivers in ONE table under GPSX_SCHED_MUX17 from tick
+    1020 (a cycle start; each receiver's records as its own host run has them there), 34 ms per launch, the word layer on the flag
+    bytes.  Every channel's 226 state bytes must be its host run's at three later ticks, byte for byte."""
+    from stm32f4_sdr_gps_amd import capi, synth
+    n_ms, t0, n_rx = 2737, 1020, 12                      # 2737 = 161 cycles; ticks compared: cycle ends
+    checks = [1597, 2175, 2736]
+    rng = np.random.default_rng(20)
+    sats = [synth.Sat(p, float(rng.uniform(-4500, 4500)), float(rng.uniform(0, 16368)), 0.5, float(rng.uniform(0, 6.28)),
+                      1.0 - 2.0 * rng.integers(0, 2, n_ms // 20 + 2).astype(np.float64))
+            for p in (2, 6, 9, 13, 17, 22, 27, 31)]
+    stream = synth.make_if(n_ms, sats, noise_amp=1.0, seed=31)
+    lib = eng.lib
+    steps = sd.StepsLib(lib, False)
+    lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
+    lib.gpsx_loop_state_to_channel.argtypes = [C.c_void_p, C.c_void_p]
+    lib.gpsx_loop_state_from_channel.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    lib.gpsx_compat_receiver_reset.restype = None
+    hand, want = [], []
+    for r in range(n_rx):
+        pick = rng.permutation(8)[:4]
+        table = np.stack([sd.preset_channel(steps, sats[i].prn, int(round(sats[i].doppler_hz / 500.0)) * 500, int(sats[i].delay_samples // 8) % 2046)
+                          for i in pick])
+        lib.gpsx_compat_receiver_reset()                 # (the step logic's slot statics: every receiver boots afresh)
+        snaps = {}
+        for t in range(n_ms):
+            steps.set_time(t)
+            big = t % CYCLE
+            lib.gps_tracking_process(table[big // 4 if big < 16 else 0].ctypes.data, stream[t].ctypes.data, 0xFF if big == 16 else big % 4)
+            if t == t0 - 1:
+                hand.append(table.copy())
+            if t in checks:
+                snaps[t] = sd.snapshot(table)
+        want.append(snaps)
+    tracking = [bool((h[:, 60 + 148:60 + 152].copy().view("<i4")[:, 0] == sd.TRK_RUN).all()) for h in hand]
+    use = [r for r in range(n_rx) if tracking[r]]
+    assert len(use) >= 10, tracking
+    table = np.ascontiguousarray(np.concatenate([hand[r] for r in use]))
+    n = len(table)
+    st = np.zeros(n, capi.LOOP_DTYPE)
+    for i in range(n):
+        lib.gpsx_loop_state_from_channel(table[i].ctypes.data, i + 1, st[i:i + 1].ctypes.data)
+    d = eng.malloc(st.nbytes)
+    try:
+        eng.h2d(d, st)
+        t = t0
+        while t < n_ms:
+            kk = min(2 * CYCLE, n_ms - t)
+            flags, _ = eng.track_loop(stream[t:t + kk], d, n, t)
+            lib.gps_tracking_words_batch(table.ctypes.data, n, flags.ctypes.data, kk, t, None, 0)
+            t += kk
+            if (t - 1) in checks:
+                eng.d2h(st, d)
+                for i in range(n):
+                    lib.gpsx_loop_state_to_channel(st[i:i + 1].ctypes.data, table[i].ctypes.data)
+                got = sd.snapshot(table)
+                for k, r in enumerate(use):
+                    bad = np.argwhere(got[4 * k:4 * k + 4] != want[r][t - 1])
+                    assert len(bad) == 0, ("receiver", r, "tick", t - 1, "first (channel, byte)", bad[0].tolist())
+    finally:
+        eng.free(d)
+    assert int(st["reseed_count"].sum()) == 0 and st["period_sync_ok_flag"].sum() >= 3      # (under the multiplex bit-period sync takes seconds)
