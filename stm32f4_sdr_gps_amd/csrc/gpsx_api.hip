@@ -1106,8 +1106,18 @@ int gpsx_acq_grid_weighted_dev(gpsx_ctx *ctx, const gpsx_acq_weighted_t *g, cons
   if (int rc = check_weighted(ctx, g, n_blocks)) return rc;
   if (!d_if_blocks_2bit || !d_peaks)
     return fail(ctx, GPSX_EINVAL, "null device pointer");
-  // the PRN list behind the kernel: a few bytes through the arena's tail would collide with a host-pointer caller's buffers --
-  // its own small allocation, grow-only
+  if (ctx->algo == kAlgoMx) {
+    // the matrix-core form (GPSX_ACQ_PATH_MATRIX, the default): chips from the sign-only grid's tables
+    if (int rc = ensure_grid_tables(ctx, g->prns, g->n_prn)) return rc;
+    launch_acq_mxw(ctx->stream, static_cast<const uint8_t *>(d_if_blocks_2bit), g->n_search, g->search_stride_blocks, g->n_prn,
+                   ctx->d_grid_mx_a, ctx->if_hz, g->dopp_min_hz, g->dopp_step_hz, g->n_dopp,
+                   g->weights == GPSX_WEIGHTS_SIGN_MAGNITUDE, d_peaks);
+    LAUNCHCHK(ctx, "k_acq_mxw");
+    ctx->last_kernel = "k_acq_mxw";
+    return GPSX_OK;
+  }
+  // the vector-ALU form (GPSX_ACQ_PATH_VECTOR).  The PRN list behind the kernel: a few bytes through the arena's tail would
+  // collide with a host-pointer caller's buffers -- its own small allocation, grow-only
   if (ctx->weighted_prns_cap < g->n_prn) {
     if (ctx->d_weighted_prns) (void)hipFree(ctx->d_weighted_prns);
     ctx->d_weighted_prns = nullptr;

@@ -144,6 +144,9 @@ void launch_build_track_rep(hipStream_t s, const uint32_t *d_chipbits_all, int n
 int launch_acq_weighted(hipStream_t s, const uint8_t *d_if_blocks, int n_search, int stride_blocks, int n_prn,
                         const uint8_t *d_chips_all, const uint8_t *d_prns, int if_hz, int dopp_min_hz, int dopp_step_hz, int n_dopp,
                         int use_magnitude, gpsx_peak_t *d_peaks);
+// the same grid on the matrix cores (k_acq_mx.hip: k_acq_mxw): d_mx_a = the chip tables of the sign-only grid (launch_build_mx_tables)
+void launch_acq_mxw(hipStream_t s, const uint8_t *d_if_blocks, int n_search, int stride_blocks, int n_prn, const uint32_t *d_mx_a,
+                    int if_hz, int dopp_min_hz, int dopp_step_hz, int n_dopp, int use_magnitude, gpsx_peak_t *d_peaks);
 // GPSX_DRAWS_LIBC (include/gpsx.h): a channel's false-lock jump reported by the first pass / its carrier candidate for the second
 // (ms_from: the millisecond of the launch at which the channel's state in HBM is valid -- 0, or, under the multiplex, the first
 //  millisecond of the slot it stopped in: its earlier slots of the launch were stored when they ended -- the replay starts there)

@@ -2148,4 +2148,358 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
   return "k_acq_mx<0>";
 }
 
+// =============================================================================================================================
+// EXTENSION, not in the reference: the weighted two-bit grid (include/gpsx.h gpsx_acq_grid_weighted, k_acq_weighted.hip for the
+// definition) on the matrix cores -- the same Toeplitz GEMM, with values where the sign-only grid has bits.
+//   v(n) in {0, +-1, +-3}: the wiped sample's sign x its magnitude weight; the sixteen samples the carrier NCO never mixes: 0
+//   I(16 q + t0) = sum_c s[c] S_t0[(q + c) mod 1023],  s = 1 - 2 chip,  S_t0[k] = sum of v over the window [16 k + t0, +16)
+//                = T - 2 sum_c chip[c] S_t0[q + c],    T = sum of all v (every sample sits in exactly one window)
+// A = chips (FP4 1.0 at block scale 2^-13, the tables of the sign-only grid), the accumulators start at T / 8192 and take
+//   * sample offset 0 in THREE passes: y = -S_0 in [-48, 48] = y0 + 4 y1 + 16 y2 with balanced base-4 digits in [-2, 2]
+//     (|y2| <= 3), the vector carries 2 y_i (FP4-exact: 0, +-2, +-4, +-6) at block scales 2^0, 2^2, 2^4;
+//   * every further offset in one: S_{t0+1}[k] - S_t0[k] = v_t0(k + 1) - v_t0(k) in {0, +-1, +-2, +-3, +-4, +-6} (a difference
+//     of 5 does not exist) with v_t0(i) = v(16 i + t0), i mod 1023, and v_t0(1022) = 0 (the unmixed samples, whatever t0):
+//     the vector carries its negative at block scale 2^1.
+// Every partial sum is an integer below 2^24 at a power-of-two scale: exact in f32 in any order, like the sign-only grid.
+// The epilogue is this grid's own: no clipping (the correlation is signed), floor(sqrt(I^2 + Q^2)) exactly, the first fine phase
+// reaching the maximum, the sum.  Work split, pipelining of the two roles and the result slots are k_acq_mx<0>'s.
+namespace {
+
+struct MxwShared {
+  MxShared s;
+  u32 mag[514];                     // the capture's magnitude plane, laid out as s.d (zero in the sign-only mode)
+  u32 mplane[16][kPlaneWordsMx];    // polyphase magnitude planes, as s.plane
+  int wsum[2];                      // sum over the mixed samples of (2 d - 1) m, per stream
+};
+constexpr int kWPasses = 18;                 // 3 for the first offset + 15 recurrence steps
+constexpr u32 kScaleTwo = 0x80808080u;       // E8M0 128 = 2^1
+constexpr u32 kScaleFour = 0x81818181u;      // 2^2
+constexpr u32 kScaleSixteen = 0x83838383u;   // 2^4
+
+__device__ __forceinline__ void mxw_write_copies(u32 *dst, u32 lo, u32 hi)
+{
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    dst[c * kCopyDwords] = c ? __builtin_amdgcn_alignbit(hi, lo, 4u * (u32)c) : lo;
+}
+
+// digit `which` of the first offset's chip sums (thread (stream, j): entries 8 j .. 8 j + 15 of copy 0 -> dword j of the copies)
+__device__ __forceinline__ void mxw_build_start(MxwShared &shw, int which, int buf, int tid)
+{
+  const int iq = tid >> 8, j = tid & 255;
+  const u32 *dd = shw.s.d[iq], *mm = shw.mag;
+  u32 w2[2] = {0, 0};
+#pragma unroll
+  for (int e = 0; e < 16; e++) {
+    const int k = wrap1023(8 * j + e);
+    const u32 x = (dd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, m = (mm[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+    int y = -((2 * (int)__popc(x) - 16) + 2 * (2 * (int)__popc(x & m) - (int)__popc(m)));
+    y = k == kChips - 1 ? 0 : y;                       // window 1022 = the sixteen unmixed samples
+    const int y0 = ((y + 2) & 3) - 2, r1 = (y - y0) >> 2;
+    const int y1 = ((r1 + 2) & 3) - 2, y2 = (r1 - y1) >> 2;
+    const int digit = which == 0 ? y0 : which == 1 ? y1 : y2;
+    w2[e >> 3] |= fp4_code(2 * digit) << (4 * (e & 7));
+  }
+  mxw_write_copies(&shw.s.e8[buf][iq][0][j], w2[0], w2[1]);
+}
+
+// the vector that takes the accumulators from sample offset t0 to t0 + 1: entry k = v_t0(k) - v_t0(k + 1).
+// Lookup table (in the sign-only grid's t_lut, which this kernel does not use otherwise): (sign, magnitude) pairs of five
+// consecutive samples -- ten bits, sample i in bits 2 i, 2 i + 1 -- -> the FP4 codes of their four differences
+__device__ __forceinline__ int mxw_val2(u32 sm) { return ((sm & 1u) ? 1 : -1) * ((sm & 2u) ? 3 : 1); }
+__device__ void mxw_fill_table(MxShared &sh, int tid)
+{
+  uint16_t *lut = reinterpret_cast<uint16_t *>(sh.t_lut);
+  static_assert(sizeof(sh.t_lut) >= 1024 * sizeof(uint16_t), "difference table fits");
+  for (int i = tid; i < 1024; i += kMxThreads) {
+    u32 codes = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      codes |= fp4_code(mxw_val2(((u32)i >> (2 * k)) & 3u) - mxw_val2(((u32)i >> (2 * k + 2)) & 3u)) << (4 * k);
+    lut[i] = (uint16_t)codes;
+  }
+}
+// 16 bits -> the even bit positions of 32
+__device__ __forceinline__ u32 spread16(u32 x)
+{
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  return (x | (x << 1)) & 0x55555555u;
+}
+// v_t0(i) from the planes, i < 3 * 1023 (the sixteen unmixed samples, i = 1022 mod 1023: 0)
+__device__ __forceinline__ int mxw_plane_val(const u32 *pl, const u32 *mp, int i)
+{
+  const int c = wrap1023(i);
+  const u32 sm = ((pl[c >> 5] >> (c & 31)) & 1u) | (((mp[c >> 5] >> (c & 31)) & 1u) << 1);
+  return c == kChips - 1 ? 0 : mxw_val2(sm);
+}
+__device__ __forceinline__ void mxw_build_step(MxwShared &shw, int t0, int buf, int tid)
+{
+  const int iq = tid >> 8, j = tid & 255;
+  const u32 *pl = shw.s.plane[iq][t0], *mp = shw.mplane[t0];
+  const uint16_t *lut = reinterpret_cast<const uint16_t *>(shw.s.t_lut);
+  const u32 sx = __builtin_amdgcn_alignbit(pl[(j >> 2) + 1], pl[j >> 2], 8u * (u32)(j & 3));   // plane bits 8 j .. 8 j + 31
+  const u32 mx = __builtin_amdgcn_alignbit(mp[(j >> 2) + 1], mp[j >> 2], 8u * (u32)(j & 3));
+  const u32 z_lo = spread16(sx & 0xFFFFu) | (spread16(mx & 0xFFFFu) << 1);                      // samples 0..15 of the window
+  const u32 z_hi = ((sx >> 16) & 1u) | (((mx >> 16) & 1u) << 1);                                // sample 16
+  u32 w2[2];
+  w2[0] = (u32)lut[z_lo & 0x3FFu] | ((u32)lut[(z_lo >> 8) & 0x3FFu] << 16);
+  w2[1] = (u32)lut[(z_lo >> 16) & 0x3FFu] | ((u32)lut[(z_lo >> 24) | ((z_hi & 3u) << 8)] << 16);
+  // entries 1021, 1022 (dword 127) and their wrap-around copies 2044, 2045 (dword 255) touch the unmixed samples
+  if ((j & 127) >= 126) {
+    const int dword = j | 1;                              // 127 or 255: this thread's high dword (j even) or low dword (j odd)
+    u32 &w = w2[(j & 1) ^ 1];
+    w &= ~0x0FFF0000u;                                    // (1021, 1022 = nibbles 5, 6 of dword 127; 2044, 2045 = 4, 5 of dword 255)
+#pragma unroll
+    for (int e = 4; e <= 6; e++)
+      w |= fp4_code(mxw_plane_val(pl, mp, 8 * dword + e) - mxw_plane_val(pl, mp, 8 * dword + e + 1)) << (4 * e);
+  }
+  mxw_write_copies(&shw.s.e8[buf][iq][0][j], w2[0], w2[1]);
+}
+
+__device__ __forceinline__ u32 mxw_root_exact(int i, int q)
+{
+  const u64 e = (u64)((long long)i * i) + (u64)((long long)q * q);
+  u64 r = (u64)__builtin_sqrt((double)e);
+  r = r * r > e ? r - 1 : r;
+  r = (r + 1) * (r + 1) <= e ? r + 1 : r;
+  return (u32)r;
+}
+
+// floor(sqrt(E)) for E = I^2 + Q^2 < 2^24 (an integer, exact in f32): v_sqrt_f32 is good to one ulp, at most 2^-12 below 4096,
+// so the truncation of root + 2^-11 is the floor or the integer above it, and the sign of E - r^2 (exact) tells which
+__device__ __forceinline__ u32 mxw_root_small(float fi, float fq)
+{
+  const float e = __builtin_fmaf(fi, fi, fq * fq);
+  const u32 r = (u32)(__builtin_amdgcn_sqrtf(e) + 0.00048828125f);
+  const float rf = (float)r;
+  return __builtin_fmaf(-rf, rf, e) < 0.0f ? r - 1u : r;
+}
+
+// the epilogue of sample offset t0: 64 hypotheses per lane into the slots of bit shift t0 & 7 (byte offset 2 q + (t0 >> 3))
+template <bool ALL_SMALL>
+__device__ __forceinline__ void mxw_epilogue_body(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles],
+                                                  const bool (&small)[kMxTiles])
+{
+  const int n = lane & 31, h = lane >> 5;
+  u32 key_lo[kMxTiles];
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++)
+    key_lo[j] = (u32)(2047 - (2 * (32 * (q0_tile + 2 * j) + n) + (t0 >> 3)));
+  const bool last_exists = 32 * (q0_tile + 2 * (kMxTiles - 1)) + n < kChips;   // chip offset 1023 (tile 31, lane 31) does not exist
+  u32 *slot = &sh.part[t0 & 7][4 * h][0][n];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    u32 best = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < kMxTiles; j++) {
+      const float fi = acc[0][j][r] * 8192.0f, fq = acc[1][j][r] * 8192.0f;
+      u32 m;
+      if (ALL_SMALL || small[j])
+        m = mxw_root_small(fi, fq);
+      else
+        m = mxw_root_exact((int)fi, (int)fq);
+      if (j == kMxTiles - 1)
+        m = last_exists ? m : 0u;
+      const u32 key = (m << 11) | key_lo[j];
+      best = key > best ? key : best;
+      total += m;
+    }
+    const int p = (r & 3) + 8 * (r >> 2);              // PRN p + 4 h of the cluster
+    atomicMax(&slot[p * 64], best);
+    atomicAdd(&slot[p * 64 + 32], total);
+  }
+}
+__device__ __forceinline__ void mxw_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles])
+{
+  bool small[kMxTiles];   // (wave-uniform) every |I|, |Q| of the tile below 2896: I^2 + Q^2 < 2^24
+  bool all_small = true;
+#pragma unroll
+  for (int j = 0; j < kMxTiles; j++) {
+    float lim = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+      lim = __builtin_fmaxf(lim, __builtin_fmaxf(__builtin_fabsf(acc[0][j][r]), __builtin_fabsf(acc[1][j][r])));
+    small[j] = __builtin_amdgcn_ballot_w64(lim >= 2896.0f * kAccScale) == 0;
+    all_small = all_small && small[j];
+  }
+  if (all_small)
+    mxw_epilogue_body<true>(sh, lane, q0_tile, t0, acc, small);
+  else
+    mxw_epilogue_body<false>(sh, lane, q0_tile, t0, acc, small);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kMxThreads, 1) void k_acq_mxw(const uint8_t *__restrict__ if_blocks, int stride_blocks, int n_prn,
+                                                           const u32 *__restrict__ mx_a, int if_hz, int dopp_min_hz, int dopp_step_hz,
+                                                           int n_dopp, int use_magnitude, gpsx_peak_t *__restrict__ peaks)
+{
+  __shared__ MxwShared shw;
+  MxShared &sh = shw.s;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2;                            // waves w and w + 4 share a SIMD: half a step apart
+  const int q0_tile = 8 * (wave >> 1) + (wave & 1);      // this wave owns q-tiles q0_tile + 2 j
+  const int n_sets = (n_prn + 31) / 32;
+  const int cluster = (int)blockIdx.x;
+  const int set = cluster % n_sets, sd = cluster / n_sets, dopp = sd % n_dopp, search = sd / n_dopp;
+  const u32 step_word = nco_step_per_word((float)(if_hz + dopp_min_hz + dopp * dopp_step_hz));
+  const uint8_t *blk = if_blocks + (size_t)search * stride_blocks * GPSX_BYTES_PER_MS_2BIT;
+
+  // ---- the cluster's chips, the capture's two bit planes -----------------------------------------------------------------
+  {
+    const u32 *src_a = mx_a + (size_t)set * (16 * 2 * 32 * 4);
+    u32 *dst_a = reinterpret_cast<u32 *>(&sh.chips_a[0][0][0]);
+    for (int i = tid; i < 16 * 2 * 32 * 4; i += kMxThreads)
+      dst_a[i] = src_a[i];
+  }
+  for (int i = tid; i < 8 * 32 * 2 * 32 / 4; i += kMxThreads)
+    reinterpret_cast<uint4 *>(&sh.part[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
+  mxw_fill_table(sh, tid);
+  mx_load_block(sh, blk, GPSX_IF_2BIT_SM, tid);
+  for (int w = tid; w < 514; w += kMxThreads) {
+    u32 m = 0;
+    if (use_magnitude && w < 512) {
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const int w16 = 2 * w + hh;
+        if (w16 < kWords16) {
+          const uint16_t *p = reinterpret_cast<const uint16_t *>(blk) + 2 * w16;
+          m |= even_bits16(((u32)p[0] | ((u32)p[1] << 16)) >> 1) << (16 * hh);
+        }
+      }
+    }
+    shw.mag[w] = m;
+  }
+  if (tid < 2)
+    shw.wsum[tid] = 0;
+  __syncthreads();
+  if (tid == 0)
+    shw.mag[511] |= shw.mag[0] << 16;                    // the stream wraps to sample 0 (as s.d's word 511)
+  mx_wipe_block(sh, step_word, tid, lane);
+  // ---- magnitude planes (first period), the weighted part of the streams' totals, the first two vectors -----------------------
+  for (int m = tid; m < 32 * 16; m += kMxThreads) {
+    const int t0 = m & 15, w = m >> 4;
+    const u32 *src = &shw.mag[16 * w];
+    u32 bits = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const u32 sk = src[k];
+      bits |= ((sk >> t0) & 1u) << (2 * k);
+      bits |= ((sk >> (16 + t0)) & 1u) << (2 * k + 1);
+    }
+    shw.mplane[t0][w] = bits;
+  }
+  {
+    int part_i = 0, part_q = 0;
+    for (int w = tid; w < kWords32; w += kMxThreads) {
+      const u32 m = shw.mag[w];
+      part_i += 2 * (int)__popc(sh.d[0][w] & m) - (int)__popc(m);
+      part_q += 2 * (int)__popc(sh.d[1][w] & m) - (int)__popc(m);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      part_i += __shfl_xor(part_i, off);
+      part_q += __shfl_xor(part_q, off);
+    }
+    if (lane == 0) {
+      atomicAdd(&shw.wsum[0], part_i);
+      atomicAdd(&shw.wsum[1], part_q);
+    }
+  }
+  mxw_build_start(shw, 0, 0, tid);
+  mxw_build_start(shw, 1, 1, tid);
+  __syncthreads();
+  for (int m = tid; m < 16 * (kPlaneWordsMx - 32); m += kMxThreads) {   // circular extension, as mx_wipe_block's
+    const int w = 32 + m % (kPlaneWordsMx - 32);
+    const int r = m / (kPlaneWordsMx - 32);
+    const u32 *pl = shw.mplane[r];
+    const int pos = 32 * w - (w >= 64 ? 2 * kChips : kChips);
+    const int lo = pos >> 5;
+    u32 v = __builtin_amdgcn_alignbit(lo < 31 ? pl[lo + 1] : 0u, pl[lo], (u32)(pos & 31));
+    if (pos + 32 > kChips) {
+      const int k = kChips - pos;
+      v = (v & ((1u << k) - 1u)) | (pl[0] << k);
+    }
+    shw.mplane[r][w] = v;
+  }
+
+  v16f acc[2][kMxTiles];
+  {
+    const float t_i = (float)(2 * (int)sh.ones[0] - 32 * kWords32 + 2 * shw.wsum[0]) * kAccScale;
+    const float t_q = (float)(2 * (int)sh.ones[1] - 32 * kWords32 + 2 * shw.wsum[1]) * kAccScale;
+#pragma unroll
+    for (int j = 0; j < kMxTiles; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        acc[0][j][r] = t_i;
+        acc[1][j][r] = t_q;
+      }
+  }
+  const v4i no_corr = v4i{0, 0, 0, 0};
+  // steps of two halves, as mx_unit: role 0 runs pass p, then the epilogue of the offset pass p - 1 finished; role 1 the
+  // epilogue first, then the pass; one barrier per step, behind which all eight waves build the vector of pass p + 1
+#pragma unroll 1
+  for (int hs = 0; hs <= 2 * kWPasses; hs++) {
+    if ((hs & 1) == 0) {
+      __syncthreads();
+      const int p_vec = (hs >> 1) + 1;
+      if (p_vec == 2)
+        mxw_build_start(shw, 2, 0, tid);
+      else if (p_vec > 2 && p_vec < kWPasses)
+        mxw_build_step(shw, p_vec - 3, p_vec & 1, tid);
+    }
+    const int x = hs - role;
+    const bool active = x >= 0 && x < 2 * kWPasses;
+    const int p = x >> 1;
+    if (active && (x & 1) == 0)
+      mx_pass<true>(sh, p & 1, lane, q0_tile, acc, p == 0 ? kScaleOne : p == 1 ? kScaleFour : p == 2 ? kScaleSixteen : kScaleTwo,
+                    no_corr, false);
+    if (active && (x & 1) && p >= 2)
+      mxw_epilogue(sh, lane, q0_tile, p - 2, acc);
+  }
+  __syncthreads();
+  // ---- one triplet per (search, PRN, Doppler): the eight bit shifts' slots (32 lanes each) meet here --------------------------
+  {
+    const int which = tid >> 8, p = (tid >> 3) & 31, b = tid & 7;
+    const int slot = 32 * set + p;
+    const u32 *row = sh.part[b][p][which];
+    u32 k = 0, t = 0;
+#pragma unroll
+    for (int l = 0; l < 32; l++) {
+      const u32 v = row[(l + tid) & 31];
+      k = v > k ? v : k;
+      t += v;
+    }
+    const size_t idx = ((size_t)search * n_prn + slot) * n_dopp + dopp;
+    if (which == 0) {   // (wave-uniform: waves 0..3; a PRN's eight bit shifts are eight adjacent lanes)
+      const u32 max_val = k >> 11, fine = 8u * (2047u - (k & 2047u)) + (u32)b;
+      unsigned long long key = max_val ? ((unsigned long long)max_val << 14) | (unsigned long long)(16383u - fine) : 0ull;
+      key = mx_max8_u64(key);
+      if (b == 0 && slot < n_prn) {
+        peaks[idx].max_val = (u32)(key >> 14);
+        peaks[idx].phase = key ? 16383u - (u32)(key & 16383u) : 0u;
+      }
+    } else {
+      t += __shfl_xor(t, 1);
+      t += __shfl_xor(t, 2);
+      t += __shfl_xor(t, 4);
+      if (b == 0 && slot < n_prn) {
+        peaks[idx].sum = t;
+        peaks[idx].avr = t / (u32)kSamples;
+      }
+    }
+  }
+}
+
+void launch_acq_mxw(hipStream_t s, const uint8_t *d_if_blocks, int n_search, int stride_blocks, int n_prn, const uint32_t *d_mx_a,
+                    int if_hz, int dopp_min_hz, int dopp_step_hz, int n_dopp, int use_magnitude, gpsx_peak_t *d_peaks)
+{
+  const int n_sets = (n_prn + 31) / 32;
+  hipLaunchKernelGGL(k_acq_mxw, dim3((unsigned)(n_search * n_dopp * n_sets)), dim3(kMxThreads), 0, s, d_if_blocks, stride_blocks,
+                     n_prn, d_mx_a, if_hz, dopp_min_hz, dopp_step_hz, n_dopp, use_magnitude, d_peaks);
+}
+
 }  // namespace gpsx

@@ -23,19 +23,56 @@ def _blocks(n_ms, amp, seed):
     return synth.make_if_static(n_ms, sats, noise_amp=1.0, seed=seed, two_bit=True)
 
 
+def _path(eng, path):
+    from stm32f4_sdr_gps_amd import capi
+    eng.set_acq_path(capi.ACQ_PATH_MATRIX if path == "matrix" else capi.ACQ_PATH_VECTOR)
+    return b"k_acq_mxw" if path == "matrix" else b"k_acq_weighted"
+
+
+@pytest.mark.parametrize("path", ["matrix", "vector"])
 @pytest.mark.parametrize("use_mag", [True, False])
-def test_weighted_grid_matches_its_oracle(eng, oracle, use_mag):
+def test_weighted_grid_matches_its_oracle(eng, oracle, use_mag, path):
     from conftest import oracle_threads
     blocks = _blocks(5, 0.3, 3)
-    for prns, kw in ((np.array([7, 19, 30, 1, 2, 3, 4, 5, 6, 8, 9], np.uint8), dict(n_search=2, dopp_min_hz=-2500, dopp_step_hz=500, n_dopp=3, stride_blocks=2)),
-                     (np.array([19], np.uint8), dict(n_search=3, dopp_min_hz=-2240, dopp_step_hz=250, n_dopp=1, stride_blocks=1)),
-                     (np.arange(1, 17, dtype=np.uint8), dict(n_search=1, dopp_min_hz=1000, dopp_step_hz=500, n_dopp=2, stride_blocks=1))):
-        got = eng.acq_grid_weighted(blocks, prns, use_magnitude=use_mag, **kw)
-        assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_weighted"
-        want = oracle.acq_grid_weighted(blocks, kw["n_search"], prns, kw["dopp_min_hz"], kw["dopp_step_hz"], kw["n_dopp"], use_mag,
-                                        stride_blocks=kw["stride_blocks"], n_threads=oracle_threads())
-        for f in ("max_val", "phase", "sum", "avr"):
-            assert np.array_equal(got[f], want[f]), (len(prns), f, np.argwhere(got[f] != want[f])[:4].tolist())
+    kernel = _path(eng, path)
+    try:
+        for prns, kw in ((np.array([7, 19, 30, 1, 2, 3, 4, 5, 6, 8, 9], np.uint8), dict(n_search=2, dopp_min_hz=-2500, dopp_step_hz=500, n_dopp=3, stride_blocks=2)),
+                         (np.array([19], np.uint8), dict(n_search=3, dopp_min_hz=-2240, dopp_step_hz=250, n_dopp=1, stride_blocks=1)),
+                         (np.arange(1, 17, dtype=np.uint8), dict(n_search=1, dopp_min_hz=1000, dopp_step_hz=500, n_dopp=2, stride_blocks=1)),
+                         # more than one set of 32 PRN slots (the matrix form's cluster), the second one not full
+                         (np.arange(1, 41, dtype=np.uint8), dict(n_search=1, dopp_min_hz=1310, dopp_step_hz=500, n_dopp=1, stride_blocks=1))):
+            got = eng.acq_grid_weighted(blocks, prns, use_magnitude=use_mag, **kw)
+            assert eng.lib.gpsx_last_kernel(eng.h) == kernel
+            want = oracle.acq_grid_weighted(blocks, kw["n_search"], prns, kw["dopp_min_hz"], kw["dopp_step_hz"], kw["n_dopp"], use_mag,
+                                            stride_blocks=kw["stride_blocks"], n_threads=oracle_threads())
+            for f in ("max_val", "phase", "sum", "avr"):
+                assert np.array_equal(got[f], want[f]), (len(prns), f, np.argwhere(got[f] != want[f])[:4].tolist())
+    finally:
+        _path(eng, "matrix")
+
+
+@pytest.mark.parametrize("path", ["matrix", "vector"])
+def test_weighted_grid_on_strong_and_degenerate_captures(eng, oracle, path):
+    """Magnitudes near the top of the range (a clean strong satellite: |I| in the tens of thousands, the exact-root path), an
+    all-one-value capture (every window the same: the recurrence vectors are all zero but at the unmixed samples), and a capture
+    whose magnitude bit is always set."""
+    from conftest import oracle_threads
+    from stm32f4_sdr_gps_amd import synth
+    strong = synth.make_if_static(1, [synth.Sat(7, 1310.0, 4321.0, 4.0, 0.4)], noise_amp=0.05, seed=5, two_bit=True)
+    flat = np.full_like(strong, 0xFF)                      # sign 1, magnitude 1 everywhere
+    sign_only = strong | np.uint8(0xAA)                    # magnitude bit forced to 1: weights +-3
+    kernel = _path(eng, path)
+    try:
+        for blocks in (strong, flat, sign_only):
+            prns = np.array([7, 8], np.uint8)
+            got = eng.acq_grid_weighted(blocks, prns, 1, 810, 500, 2, use_magnitude=True)
+            assert eng.lib.gpsx_last_kernel(eng.h) == kernel
+            want = oracle.acq_grid_weighted(blocks, 1, prns, 810, 500, 2, True, n_threads=oracle_threads())
+            for f in ("max_val", "phase", "sum", "avr"):
+                assert np.array_equal(got[f], want[f]), (f, got[f].tolist(), want[f].tolist())
+        assert got["max_val"].max() > 2896                 # (the last capture: the exact-root path did run)
+    finally:
+        _path(eng, "matrix")
 
 
 def test_weighted_mode_argument_checks_and_the_one_bit_path_is_untouched(eng, oracle):
