@@ -682,6 +682,59 @@ def main():
             letter = {"error": repr(exc)}
             print(f"bench.py: letter-compliant leg failed: {exc!r}", file=sys.stderr, flush=True)
 
+    # EXTENSION, not in the reference (include/gpsx.h gpsx_acq_grid_weighted): the same 32 x 21 x 16368 grid on weighted two-bit
+    # samples (+-1 / +-3), 64 captures per launch, on the matrix cores (k_acq_mxw) -- and, on the first eight captures, the same
+    # records from the vector-ALU kernel (k_acq_weighted); both are pinned to the extension's own oracle in tests/test_gpu_weighted.py
+    weighted = None
+    if world == 1 and n_ms == 1 and not args.no_native:
+        try:
+            w_search = 256
+            w_blocks = synth.cold_start_block(w_search, seed=16, amp_scale=args.amp_scale, two_bit=True)
+            w_prns = np.arange(1, N_PRN + 1, dtype=np.uint8)
+            eng_w = capi.Engine(dev_index, stream=stream.cuda_stream)
+            with torch.cuda.stream(stream):
+                d_w = torch.from_numpy(np.concatenate([w_blocks.reshape(-1), np.zeros(2, np.uint8)])).to(dev)
+                d_wp = torch.zeros((w_search, N_PRN, N_DOPP, 4), dtype=torch.int32, device=dev)
+                d_wv = torch.zeros((8, N_PRN, N_DOPP, 4), dtype=torch.int32, device=dev)
+                gw = capi.AcqWeightedT(w_search, 1, N_PRN, w_prns.ctypes.data_as(C.POINTER(C.c_uint8)), DOPP_MIN, DOPP_STEP, N_DOPP, 1)
+                g8 = capi.AcqWeightedT(8, 1, N_PRN, w_prns.ctypes.data_as(C.POINTER(C.c_uint8)), DOPP_MIN, DOPP_STEP, N_DOPP, 1)
+
+                def w_step(engine, desc, n, out):
+                    rc = engine.lib.gpsx_acq_grid_weighted_dev(engine.h, C.byref(desc), d_w.data_ptr(), n, out.data_ptr())
+                    if rc != 0:
+                        raise RuntimeError(f"gpsx_acq_grid_weighted_dev -> {rc}: {engine.lib.gpsx_last_error(engine.h).decode()}")
+                w_step(eng_w, gw, w_search, d_wp)
+                w_kernel = eng_w.lib.gpsx_last_kernel(eng_w.h).decode()
+                torch.cuda.synchronize()
+                w0, w1 = eng_w.event(), eng_w.event()
+                eng_w.record(w0)
+                for _ in range(8):
+                    w_step(eng_w, gw, w_search, d_wp)
+                eng_w.record(w1)
+                torch.cuda.synchronize()
+                w_ms = eng_w.elapsed_ms(w0, w1) / 8
+                eng_w.set_acq_path(capi.ACQ_PATH_VECTOR)
+                w_step(eng_w, g8, 8, d_wv)
+                v_kernel_w = eng_w.lib.gpsx_last_kernel(eng_w.h).decode()
+                torch.cuda.synchronize()
+                same_records = bool(torch.equal(d_wv, d_wp[:8])) and int(d_wp[..., 0].min()) > 0
+            eng_w.close()
+            w_hyp = w_search * HYP_PER_SEARCH
+            w_flops = w_hyp / 16 * 2 * 18 * 1024 * 2            # 18 MFMA passes per 16 sample offsets, two streams, 1024 chips
+            weighted = {"workload": f"EXTENSION (not in the reference): weighted two-bit (+-1 / +-3) fine grid, {w_search} captures x "
+                                    f"{N_PRN} PRN x {N_DOPP} Doppler x 16368 phases per launch, device-resident",
+                        "value": w_hyp / (w_ms * 1e-3), "unit": "hypotheses/s", "ms_per_launch": w_ms, "kernel": "gpsx::" + w_kernel,
+                        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_FP4_PEAK_TFLOPS,
+                                     "achieved": w_flops / (w_ms * 1e-3) / 1e12, "frac": w_flops / (w_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                                     "basis": "MX-FP4 flops as issued; HIP events around 8 launches"},
+                        "records_identical_to": "gpsx::" + v_kernel_w + " (vector ALU) on the first 8 captures",
+                        "records_identical": same_records}
+            if not same_records:
+                raise AssertionError("the weighted grid's matrix-core records differ from the vector-ALU kernel's")
+        except Exception as exc:   # a secondary leg must not take the headline line with it
+            weighted = {"error": repr(exc)}
+            print(f"bench.py: weighted two-bit leg failed: {exc!r}", file=sys.stderr, flush=True)
+
     # PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
     # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
     # rotation through gpsx_acq_grid_async, so a call's transfers overlap the others' sweeps -- what a host streaming
@@ -991,6 +1044,8 @@ def main():
             line["configs3_one_gpu"] = ten_block
         if letter is not None:
             line["letter_compliant"] = letter
+        if weighted is not None:
+            line["weighted_2bit_extension"] = weighted
         if tracking is not None:
             line["tracking"] = tracking
         if not args.no_cpu_baseline and world == 1:

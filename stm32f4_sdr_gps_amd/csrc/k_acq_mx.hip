@@ -47,7 +47,7 @@
 // at its own sample offset (mx_direct_terms: every quirk term as a start value), results merged through global planes.
 #if !defined(GPSX_LAB) && (defined(WALK_ABL_NO_LOAD) || defined(WALK_ABL_NO_STORE) || defined(GPSX_MX_ABLATIONS) || \
                            defined(GPSX_MX_NO_PIECES) || defined(GPSX_MX_TIMELINE) || defined(MX_BUILD_BEHIND) || defined(GPSX_MX_NT) || \
-                           defined(MX_VARIANT_B) || defined(WALK_ABL_ALIAS))
+                           defined(MX_VARIANT_B) || defined(WALK_ABL_ALIAS) || defined(MXW_ABL))
 #error "timing ablations / instrumented variants of k_acq_mx (some give wrong results) build with -DGPSX_LAB only: tools/build_variant.sh"
 #endif
 #include <cstdlib>
@@ -387,7 +387,7 @@ __device__ __forceinline__ void mx_vector_build_direct(MxShared &sh, int which, 
 // The sched_group_barriers pin that order -- the DS reads first, (8 MFMAs = 260 cycles ahead of their use) -- which the
 // scheduler, short of registers, would otherwise turn into "requested one MFMA before the wait": the LDS is kept busy by
 // the four waves of the other role, a wave that waits for it at every step loses a third of the matrix pipe's time.
-template <int S, int NT>
+template <int S, int NT, u32 SCALE_A = kScaleA>
 __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v4i *ca, v4i (&a)[16], v4i &fi, v4i &fq,
                                              v16f (&acc)[2][NT], u32 scale_b)
 {
@@ -403,8 +403,8 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
   constexpr int j_lo = S - 15 > 0 ? S - 15 : 0, j_hi = S < NT - 1 ? S : NT - 1;
 #pragma unroll
   for (int j = j_lo; j <= j_hi; j++) {
-    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fi), acc[0][j], 4, 4, 0, kScaleA, 0, scale_b);
-    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fq), acc[1][j], 4, 4, 0, kScaleA, 0, scale_b);
+    acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fi), acc[0][j], 4, 4, 0, SCALE_A, 0, scale_b);
+    acc[1][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(widen(a[S - j]), widen(fq), acc[1][j], 4, 4, 0, SCALE_A, 0, scale_b);
   }
   if constexpr (more) {
     __builtin_amdgcn_sched_group_barrier(0x100, S + 1 < 16 ? 5 : 4, 0);   // DS reads
@@ -414,7 +414,7 @@ __device__ __forceinline__ void mx_pass_step(lds_cu32 *wi, lds_cu32 *wq, const v
   fi = fi_next;
   fq = fq_next;
   if constexpr (more)
-    mx_pass_step<S + 1, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
+    mx_pass_step<S + 1, NT, SCALE_A>(wi, wq, ca, a, fi, fq, acc, scale_b);
 }
 
 // The same without a second set of fragment registers (the walk forms, whose prefetched sums leave none): the I fragment of the
@@ -503,7 +503,8 @@ __device__ __forceinline__ void mx_pass2(const MxShared &sh, int lane, int q0_ti
 
 // AHEAD = false (the walk forms): mx_pass_step_inplace
 // NT = q-tiles of this call (q0_tile + 2 j, j < NT): four everywhere but in the byte-phase form, which works in tile pairs
-template <bool AHEAD, int NT>
+// SCALE_A: the A operand's block scale (the weighted extension keeps plain integers in its accumulators: 2^0; AHEAD only)
+template <bool AHEAD, int NT, u32 SCALE_A = kScaleA>
 __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, int q0_tile, v16f (&acc)[2][NT],
                                         u32 scale_b, v4i a_corr, bool with_corr, const u32 *e8_buf = nullptr)
 {
@@ -517,8 +518,9 @@ __device__ __forceinline__ void mx_pass(const MxShared &sh, int buf, int lane, i
   if constexpr (AHEAD) {
     v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
     a[0] = ca[0];
-    mx_pass_step<0, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
+    mx_pass_step<0, NT, SCALE_A>(wi, wq, ca, a, fi, fq, acc, scale_b);
   } else {
+    static_assert(SCALE_A == kScaleA, "the in-place walk is the sign-only grid's");
     v4i fi = lds_frag(wi, 0), fq = lds_frag(wq, 0);
     a[0] = ca[0];
     mx_pass_step_inplace<0, NT>(wi, wq, ca, a, fi, fq, acc, scale_b);
@@ -2154,7 +2156,7 @@ const char *launch_acq_mx(hipStream_t s, const AcqParams &prm, const uint8_t *d_
 //   v(n) in {0, +-1, +-3}: the wiped sample's sign x its magnitude weight; the sixteen samples the carrier NCO never mixes: 0
 //   I(16 q + t0) = sum_c s[c] S_t0[(q + c) mod 1023],  s = 1 - 2 chip,  S_t0[k] = sum of v over the window [16 k + t0, +16)
 //                = T - 2 sum_c chip[c] S_t0[q + c],    T = sum of all v (every sample sits in exactly one window)
-// A = chips (FP4 1.0 at block scale 2^-13, the tables of the sign-only grid), the accumulators start at T / 8192 and take
+// A = chips (FP4 1.0, the tables of the sign-only grid, at block scale 2^0: the accumulators hold plain integers), start value T:
 //   * sample offset 0 in THREE passes: y = -S_0 in [-48, 48] = y0 + 4 y1 + 16 y2 with balanced base-4 digits in [-2, 2]
 //     (|y2| <= 3), the vector carries 2 y_i (FP4-exact: 0, +-2, +-4, +-6) at block scales 2^0, 2^2, 2^4;
 //   * every further offset in one: S_{t0+1}[k] - S_t0[k] = v_t0(k + 1) - v_t0(k) in {0, +-1, +-2, +-3, +-4, +-6} (a difference
@@ -2171,6 +2173,10 @@ struct MxwShared {
   u32 mplane[16][kPlaneWordsMx];    // polyphase magnitude planes, as s.plane
   int wsum[2];                      // sum over the mixed samples of (2 d - 1) m, per stream
 };
+#ifndef MXW_ABL
+#define MXW_ABL 0   // (lab builds: timing ablations -- 1 no epilogue, 2 no vector building, 4 no MFMA pass, 8 raised priority for the
+                    //  passes, 16 no magnitude test in front of the epilogue; wrong results)
+#endif
 constexpr int kWPasses = 18;                 // 3 for the first offset + 15 recurrence steps
 constexpr u32 kScaleTwo = 0x80808080u;       // E8M0 128 = 2^1
 constexpr u32 kScaleFour = 0x81818181u;      // 2^2
@@ -2267,14 +2273,16 @@ __device__ __forceinline__ u32 mxw_root_exact(int i, int q)
   return (u32)r;
 }
 
-// floor(sqrt(E)) for E = I^2 + Q^2 < 2^24 (an integer, exact in f32): v_sqrt_f32 is good to one ulp, at most 2^-12 below 4096,
-// so the truncation of root + 2^-11 is the floor or the integer above it, and the sign of E - r^2 (exact) tells which
+// floor(sqrt(E)) for E = I^2 + Q^2 < 2^24 - 2 (an integer, exact in f32), in eight instructions: v_sqrt_f32 is good to one ulp,
+// at most 2^-12 below 4096, and sqrt(E + 2) - sqrt(E) = 2 / (sqrt(E + 2) + sqrt(E)) > 2^-12 there: the root of E + 2 as the
+// hardware returns it is not below floor(sqrt(E)) =: r and stays below r + 2 -- its truncation is r or r + 1, and
+// (E + 2) - (r + 1)^2 < 2 (exact) tells which.  The + 2 rides in the first multiply-add.
 __device__ __forceinline__ u32 mxw_root_small(float fi, float fq)
 {
-  const float e = __builtin_fmaf(fi, fi, fq * fq);
-  const u32 r = (u32)(__builtin_amdgcn_sqrtf(e) + 0.00048828125f);
+  const float e2 = __builtin_fmaf(fi, fi, __builtin_fmaf(fq, fq, 2.0f));
+  const u32 r = (u32)__builtin_amdgcn_sqrtf(e2);
   const float rf = (float)r;
-  return __builtin_fmaf(-rf, rf, e) < 0.0f ? r - 1u : r;
+  return __builtin_fmaf(-rf, rf, e2) < 2.0f ? r - 1u : r;
 }
 
 // the epilogue of sample offset t0: 64 hypotheses per lane into the slots of bit shift t0 & 7 (byte offset 2 q + (t0 >> 3))
@@ -2289,14 +2297,61 @@ __device__ __forceinline__ void mxw_epilogue_body(MxShared &sh, int lane, int q0
     key_lo[j] = (u32)(2047 - (2 * (32 * (q0_tile + 2 * j) + n) + (t0 >> 3)));
   const bool last_exists = 32 * (q0_tile + 2 * (kMxTiles - 1)) + n < kChips;   // chip offset 1023 (tile 31, lane 31) does not exist
   u32 *slot = &sh.part[t0 & 7][4 * h][0][n];
+  if constexpr (ALL_SMALL) {
+    // two PRNs (eight hypotheses) at a time, stage by stage: eight independent instructions between dependent ones -- a vector
+    // instruction behind the one it depends on waits out its latency, next to the other wave's MFMAs even longer
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      float e2[8], rf[8];
+      u32 root[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        e2[i] = __builtin_fmaf(acc[1][i & 3][r + (i >> 2)], acc[1][i & 3][r + (i >> 2)], 2.0f);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        e2[i] = __builtin_fmaf(acc[0][i & 3][r + (i >> 2)], acc[0][i & 3][r + (i >> 2)], e2[i]);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        rf[i] = __builtin_amdgcn_sqrtf(e2[i]);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        root[i] = (u32)rf[i];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        rf[i] = (float)root[i];
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        rf[i] = __builtin_fmaf(-rf[i], rf[i], e2[i]);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        root[i] = rf[i] < 2.0f ? root[i] - 1u : root[i];
+      root[3] = last_exists ? root[3] : 0u;
+      root[7] = last_exists ? root[7] : 0u;
+      asm volatile("" : "+v"(root[0]), "+v"(root[1]), "+v"(root[2]), "+v"(root[3]), "+v"(root[4]), "+v"(root[5]), "+v"(root[6]), "+v"(root[7]));
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        u32 best = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < kMxTiles; j++) {
+          const u32 key = (root[4 * k + j] << 11) | key_lo[j];
+          best = key > best ? key : best;
+          total += root[4 * k + j];
+        }
+        const int p = ((r + k) & 3) + 8 * ((r + k) >> 2);
+        atomicMax(&slot[p * 64], best);
+        atomicAdd(&slot[p * 64 + 32], total);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     u32 best = 0, total = 0;
 #pragma unroll
     for (int j = 0; j < kMxTiles; j++) {
-      const float fi = acc[0][j][r] * 8192.0f, fq = acc[1][j][r] * 8192.0f;
+      const float fi = acc[0][j][r], fq = acc[1][j][r];     // (plain integers: the A operand's block scale is 2^0 here)
       u32 m;
-      if (ALL_SMALL || small[j])
+      if (small[j])
         m = mxw_root_small(fi, fq);
       else
         m = mxw_root_exact((int)fi, (int)fq);
@@ -2311,23 +2366,36 @@ __device__ __forceinline__ void mxw_epilogue_body(MxShared &sh, int lane, int q0
     atomicAdd(&slot[p * 64 + 32], total);
   }
 }
+// max(m, |a|, |b|) in ONE instruction (the source modifiers of v_max3_f32; written out because fmaxf() on fabsf() compiles to a
+// canonicalising v_max_f32 |x|, |x| per operand in front of the maximum: 3.5 instructions per pair instead of one)
+__device__ __forceinline__ float mxw_max_abs(float m, float a, float b)
+{
+  asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(a), "v"(b));
+  return m;
+}
 __device__ __forceinline__ void mxw_epilogue(MxShared &sh, int lane, int q0_tile, int t0, const v16f (&acc)[2][kMxTiles])
 {
-  bool small[kMxTiles];   // (wave-uniform) every |I|, |Q| of the tile below 2896: I^2 + Q^2 < 2^24
-  bool all_small = true;
+  // (wave-uniform) every |I|, |Q| of the wave's 64 x 64 hypotheses below 2896: I^2 + Q^2 + 2 < 2^24 -- all but the tiles next to a
+  // strong satellite's peak
+  float lim[kMxTiles];
 #pragma unroll
-  for (int j = 0; j < kMxTiles; j++) {
-    float lim = 0.0f;
+  for (int j = 0; j < kMxTiles; j++)
+    lim[j] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; r++)
-      lim = __builtin_fmaxf(lim, __builtin_fmaxf(__builtin_fabsf(acc[0][j][r]), __builtin_fabsf(acc[1][j][r])));
-    small[j] = __builtin_amdgcn_ballot_w64(lim >= 2896.0f * kAccScale) == 0;
-    all_small = all_small && small[j];
-  }
-  if (all_small)
+  for (int r = 0; r < 16; r++)
+#pragma unroll
+    for (int j = 0; j < kMxTiles; j++)   // (four independent chains)
+      lim[j] = mxw_max_abs(lim[j], acc[0][j][r], acc[1][j][r]);
+  const float top = __builtin_fmaxf(__builtin_fmaxf(lim[0], lim[1]), __builtin_fmaxf(lim[2], lim[3]));
+  bool small[kMxTiles];
+  if (__builtin_amdgcn_ballot_w64(top >= 2896.0f) == 0 || (MXW_ABL & 16)) {
     mxw_epilogue_body<true>(sh, lane, q0_tile, t0, acc, small);
-  else
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMxTiles; j++)
+      small[j] = __builtin_amdgcn_ballot_w64(lim[j] >= 2896.0f) == 0;
     mxw_epilogue_body<false>(sh, lane, q0_tile, t0, acc, small);
+  }
 }
 
 }  // namespace
@@ -2428,8 +2496,8 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mxw(const uint8_t *__rest
 
   v16f acc[2][kMxTiles];
   {
-    const float t_i = (float)(2 * (int)sh.ones[0] - 32 * kWords32 + 2 * shw.wsum[0]) * kAccScale;
-    const float t_q = (float)(2 * (int)sh.ones[1] - 32 * kWords32 + 2 * shw.wsum[1]) * kAccScale;
+    const float t_i = (float)(2 * (int)sh.ones[0] - 32 * kWords32 + 2 * shw.wsum[0]);
+    const float t_q = (float)(2 * (int)sh.ones[1] - 32 * kWords32 + 2 * shw.wsum[1]);
 #pragma unroll
     for (int j = 0; j < kMxTiles; j++)
 #pragma unroll
@@ -2448,17 +2516,33 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mxw(const uint8_t *__rest
       const int p_vec = (hs >> 1) + 1;
       if (p_vec == 2)
         mxw_build_start(shw, 2, 0, tid);
-      else if (p_vec > 2 && p_vec < kWPasses)
+      else if (p_vec > 2 && p_vec < kWPasses && !(MXW_ABL & 2))
         mxw_build_step(shw, p_vec - 3, p_vec & 1, tid);
     }
     const int x = hs - role;
     const bool active = x >= 0 && x < 2 * kWPasses;
     const int p = x >> 1;
-    if (active && (x & 1) == 0)
-      mx_pass<true>(sh, p & 1, lane, q0_tile, acc, p == 0 ? kScaleOne : p == 1 ? kScaleFour : p == 2 ? kScaleSixteen : kScaleTwo,
-                    no_corr, false);
-    if (active && (x & 1) && p >= 2)
-      mxw_epilogue(sh, lane, q0_tile, p - 2, acc);
+    if (active && (x & 1) == 0) {
+      if (!(MXW_ABL & 4)) {
+        if (MXW_ABL & 8)
+          __builtin_amdgcn_s_setprio(2);
+        mx_pass<true, kMxTiles, kScaleOne>(sh, p & 1, lane, q0_tile, acc, p == 0 ? kScaleOne : p == 1 ? kScaleFour : p == 2 ? kScaleSixteen : kScaleTwo,
+                      no_corr, false);
+        if (MXW_ABL & 8)
+          __builtin_amdgcn_s_setprio(0);
+      } else
+#pragma unroll
+        for (int j = 0; j < kMxTiles; j++)
+          asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]));
+    }
+    if (active && (x & 1) && p >= 2) {
+      if (!(MXW_ABL & 1)) {
+        mxw_epilogue(sh, lane, q0_tile, p - 2, acc);
+      } else
+#pragma unroll
+        for (int j = 0; j < kMxTiles; j++)
+          asm volatile("" ::"v"(acc[0][j]), "v"(acc[1][j]));
+    }
   }
   __syncthreads();
   // ---- one triplet per (search, PRN, Doppler): the eight bit shifts' slots (32 lanes each) meet here --------------------------

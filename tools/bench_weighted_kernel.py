@@ -18,7 +18,9 @@ def main():
     from stm32f4_sdr_gps_amd import capi, synth
     searches = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    eng = capi.Engine(0)
+    if os.environ.get("GPSX_LIB"):   # A/B runs against another build of the library (tools/build_variant.sh)
+        capi.LIB_PATH = capi.LAB_LIB_PATH = os.environ["GPSX_LIB"]
+    eng = capi.Engine(0, lab=bool(os.environ.get("GPSX_LIB")))
     blocks = synth.cold_start_block(searches, seed=11, amp_scale=0.25, two_bit=True)
     prns = np.arange(1, 33, dtype=np.uint8)
     g = capi.AcqWeightedT(searches, 1, 32, prns.ctypes.data_as(C.POINTER(C.c_uint8)), -5000, 500, 21, 1)
