@@ -89,7 +89,8 @@ int         gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, i
  * bit for bit (tests/test_gpu_parity.py; bench.py's letter_compliant leg compares the key tables of a whole 256-capture launch).
  *   GPSX_ACQ_PATH_MATRIX (default)  the exact MX-FP4 Toeplitz GEMM on the matrix cores (k_acq_mx)
  *   GPSX_ACQ_PATH_VECTOR            bit planes, v_and + v_bcnt polyphase recurrence, wave reductions on the vector ALU
- *                                   (k_acq_poly): no MFMA, about a sixth of the rate */
+ *                                   (k_acq_poly): no MFMA, about a sixth of the rate
+ * The weighted two-bit extension (gpsx_acq_grid_weighted) follows the same switch: k_acq_mxw / k_acq_weighted. */
 #define GPSX_ACQ_PATH_MATRIX 0
 #define GPSX_ACQ_PATH_VECTOR 1
 int gpsx_set_acq_path(gpsx_ctx *ctx, int path);
@@ -258,7 +259,9 @@ int  gpsx_acq_grid_sharded(gpsx_group *group, const gpsx_acq_grid_t *g, const vo
  *   result         per (search, PRN, Doppler bin): max over the 16368 phases of floor(sqrt(I^2 + Q^2)) (exact integers), the first
  *                  phase reaching it (0 .. 16367), the sum over the phases and sum / 16368 -- peaks[n_search][n_prn][n_dopp].
  * One 1 ms block per search (search s reads block s * search_stride_blocks), 4092-byte blocks whatever the context's format.
- * Runs on the vector ALU (v_dot4_i32_i8 on sums of sixteen samples): an extension mode, about 5 x 10^10 hypotheses/s. */
+ * Runs on the matrix cores (k_acq_mxw: the Toeplitz GEMM of the sign-only grid on sums of sixteen weighted samples, MX-FP4 operands,
+ * exact; about 8 x 10^11 hypotheses/s) or, under GPSX_ACQ_PATH_VECTOR, on the vector ALU (k_acq_weighted: v_dot4_i32_i8, about
+ * 4 x 10^10): the same records, bit for bit. */
 #define GPSX_WEIGHTS_SIGN_ONLY      0
 #define GPSX_WEIGHTS_SIGN_MAGNITUDE 1
 typedef struct {
