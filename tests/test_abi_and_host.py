@@ -263,7 +263,9 @@ def test_product_and_lab_builds_and_no_register_spills(lib_path):
     res = build.check_no_scratch()
     mx = {k: v for k, v in res.items() if "k_acq_mx" in k}
     loops = {k: v for k, v in res.items() if "k_track_loop" in k}
-    assert len(mx) == 6 and all(v["scratch_bytes"] == 0 and v["vgprs"] <= 256 for v in mx.values())
+    # six k_acq_mx<MODE> instances and k_acq_mxw (the weighted extension's matrix-core kernel)
+    assert len(mx) == 7 and all(v["scratch_bytes"] == 0 and v["vgprs"] <= 256 for v in mx.values())
+    assert sum("k_acq_mxw" in k for k in mx) == 1
     # the device tracking loops: no spills, and the two xorshift instantiations (the ones that run at scale) at three waves per SIMD
     assert len(loops) == 4 and all(v["scratch_bytes"] == 0 for v in loops.values())
     assert sorted(v["vgprs"] for v in loops.values())[:2] <= [168, 168]
