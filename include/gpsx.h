@@ -260,7 +260,7 @@ int  gpsx_acq_grid_sharded(gpsx_group *group, const gpsx_acq_grid_t *g, const vo
  *                  phase reaching it (0 .. 16367), the sum over the phases and sum / 16368 -- peaks[n_search][n_prn][n_dopp].
  * One 1 ms block per search (search s reads block s * search_stride_blocks), 4092-byte blocks whatever the context's format.
  * Runs on the matrix cores (k_acq_mxw: the Toeplitz GEMM of the sign-only grid on sums of sixteen weighted samples, MX-FP4 operands,
- * exact; about 8 x 10^11 hypotheses/s) or, under GPSX_ACQ_PATH_VECTOR, on the vector ALU (k_acq_weighted: v_dot4_i32_i8, about
+ * exact; about 9 x 10^11 hypotheses/s) or, under GPSX_ACQ_PATH_VECTOR, on the vector ALU (k_acq_weighted: v_dot4_i32_i8, about
  * 4 x 10^10): the same records, bit for bit. */
 #define GPSX_WEIGHTS_SIGN_ONLY      0
 #define GPSX_WEIGHTS_SIGN_MAGNITUDE 1

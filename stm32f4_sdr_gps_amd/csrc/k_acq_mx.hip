@@ -2175,7 +2175,8 @@ struct MxwShared {
 };
 #ifndef MXW_ABL
 #define MXW_ABL 0   // (lab builds: timing ablations -- 1 no epilogue, 2 no vector building, 4 no MFMA pass, 8 raised priority for the
-                    //  passes, 16 no magnitude test in front of the epilogue; wrong results)
+                    //  passes, 16 no magnitude test in front of the epilogue, 32 no pass in waves 4-7, 64 no epilogue in waves 0-3;
+                    //  wrong results)
 #endif
 constexpr int kWPasses = 18;                 // 3 for the first offset + 15 recurrence steps
 constexpr u32 kScaleTwo = 0x80808080u;       // E8M0 128 = 2^1
@@ -2233,13 +2234,6 @@ __device__ __forceinline__ u32 spread16(u32 x)
   x = (x | (x << 2)) & 0x33333333u;
   return (x | (x << 1)) & 0x55555555u;
 }
-// v_t0(i) from the planes, i < 3 * 1023 (the sixteen unmixed samples, i = 1022 mod 1023: 0)
-__device__ __forceinline__ int mxw_plane_val(const u32 *pl, const u32 *mp, int i)
-{
-  const int c = wrap1023(i);
-  const u32 sm = ((pl[c >> 5] >> (c & 31)) & 1u) | (((mp[c >> 5] >> (c & 31)) & 1u) << 1);
-  return c == kChips - 1 ? 0 : mxw_val2(sm);
-}
 __device__ __forceinline__ void mxw_build_step(MxwShared &shw, int t0, int buf, int tid)
 {
   const int iq = tid >> 8, j = tid & 255;
@@ -2252,14 +2246,21 @@ __device__ __forceinline__ void mxw_build_step(MxwShared &shw, int t0, int buf, 
   u32 w2[2];
   w2[0] = (u32)lut[z_lo & 0x3FFu] | ((u32)lut[(z_lo >> 8) & 0x3FFu] << 16);
   w2[1] = (u32)lut[(z_lo >> 16) & 0x3FFu] | ((u32)lut[(z_lo >> 24) | ((z_hi & 3u) << 8)] << 16);
-  // entries 1021, 1022 (dword 127) and their wrap-around copies 2044, 2045 (dword 255) touch the unmixed samples
-  if ((j & 127) >= 126) {
-    const int dword = j | 1;                              // 127 or 255: this thread's high dword (j even) or low dword (j odd)
-    u32 &w = w2[(j & 1) ^ 1];
-    w &= ~0x0FFF0000u;                                    // (1021, 1022 = nibbles 5, 6 of dword 127; 2044, 2045 = 4, 5 of dword 255)
+  // entries 1021, 1022 (dword 127, nibbles 5 and 6) and their wrap-around copies 2044, 2045 (dword 255, nibbles 4 and 5: 1023 is
+  // odd) touch the unmixed samples, v(1022) = 0: they are v(1021) - 0 and 0 - v(0).  Every thread works the two codes out (four
+  // broadcast reads) and patches by selection: a branch here put 300 instructions with dependent LDS reads on two waves' paths
+  {
+    const u32 c1 = fp4_code(mxw_val2(((pl[31] >> 29) & 1u) | (((mp[31] >> 29) & 1u) << 1)));
+    const u32 c2 = fp4_code(-mxw_val2((pl[0] & 1u) | ((mp[0] & 1u) << 1)));
+    const u32 at127 = (c1 << 20) | (c2 << 24), at255 = (c1 << 16) | (c2 << 20);
 #pragma unroll
-    for (int e = 4; e <= 6; e++)
-      w |= fp4_code(mxw_plane_val(pl, mp, 8 * dword + e) - mxw_plane_val(pl, mp, 8 * dword + e + 1)) << (4 * e);
+    for (int k = 0; k < 2; k++) {
+      const int dword = j + k;
+      u32 w = w2[k];
+      w = dword == 127 ? (w & ~0x0FF00000u) | at127 : w;
+      w = dword == 255 ? (w & ~0x00FF0000u) | at255 : w;
+      w2[k] = w;
+    }
   }
   mxw_write_copies(&shw.s.e8[buf][iq][0][j], w2[0], w2[1]);
 }
@@ -2508,25 +2509,32 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mxw(const uint8_t *__rest
   }
   const v4i no_corr = v4i{0, 0, 0, 0};
   // steps of two halves, as mx_unit: role 0 runs pass p, then the epilogue of the offset pass p - 1 finished; role 1 the
-  // epilogue first, then the pass; one barrier per step, behind which all eight waves build the vector of pass p + 1
+  // epilogue first, then the pass; one barrier per step.  The vector of pass p + 1 is built during step p by role 0 alone
+#if MXW_ABL & 256   // (lab: where one workgroup's waves spend their cycles -- barrier, vector building, pass, epilogue)
+  unsigned long long t_bar = 0, t_build = 0, t_pass = 0, t_epi = 0;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#define MXW_T(acc_var) do { const unsigned long long now = __builtin_readcyclecounter(); acc_var += now - t_last; t_last = now; } while (0)
+#else
+#define MXW_T(acc_var) do { } while (0)
+#endif
 #pragma unroll 1
   for (int hs = 0; hs <= 2 * kWPasses; hs++) {
+#if MXW_ABL & 256
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
     if ((hs & 1) == 0) {
       __syncthreads();
-      const int p_vec = (hs >> 1) + 1;
-      if (p_vec == 2)
-        mxw_build_start(shw, 2, 0, tid);
-      else if (p_vec > 2 && p_vec < kWPasses && !(MXW_ABL & 2))
-        mxw_build_step(shw, p_vec - 3, p_vec & 1, tid);
+      MXW_T(t_bar);
     }
+    MXW_T(t_build);
     const int x = hs - role;
     const bool active = x >= 0 && x < 2 * kWPasses;
     const int p = x >> 1;
     if (active && (x & 1) == 0) {
-      if (!(MXW_ABL & 4)) {
+      if (!(MXW_ABL & 4) && !((MXW_ABL & 32) && role)) {
         if (MXW_ABL & 8)
           __builtin_amdgcn_s_setprio(2);
-        mx_pass<true, kMxTiles, kScaleOne>(sh, p & 1, lane, q0_tile, acc, p == 0 ? kScaleOne : p == 1 ? kScaleFour : p == 2 ? kScaleSixteen : kScaleTwo,
+        mx_pass<true, kMxTiles, (MXW_ABL & 128) ? kScaleA : kScaleOne>(sh, p & 1, lane, q0_tile, acc, p == 0 ? kScaleOne : p == 1 ? kScaleFour : p == 2 ? kScaleSixteen : kScaleTwo,
                       no_corr, false);
         if (MXW_ABL & 8)
           __builtin_amdgcn_s_setprio(0);
@@ -2535,15 +2543,35 @@ __global__ __launch_bounds__(kMxThreads, 1) void k_acq_mxw(const uint8_t *__rest
         for (int j = 0; j < kMxTiles; j++)
           asm volatile("" : "+v"(acc[0][j]), "+v"(acc[1][j]));
     }
+    MXW_T(t_pass);
     if (active && (x & 1) && p >= 2) {
-      if (!(MXW_ABL & 1)) {
+      if (!(MXW_ABL & 1) && !((MXW_ABL & 64) && !role)) {
         mxw_epilogue(sh, lane, q0_tile, p - 2, acc);
       } else
 #pragma unroll
         for (int j = 0; j < kMxTiles; j++)
           asm volatile("" ::"v"(acc[0][j]), "v"(acc[1][j]));
     }
+    MXW_T(t_epi);
+    // the vector of the NEXT step's pass, by the waves of role 0 alone, behind their epilogue: they are the ones that wait at the
+    // step's barrier (role 1's epilogue runs beside a pass and takes half as long again); the buffer was last read in the
+    // previous step
+    if (role == 0 && (hs & 1)) {
+      const int p_vec = (hs >> 1) + 1;
+      if (p_vec == 2) {
+        mxw_build_start(shw, 2, 0, tid);
+        mxw_build_start(shw, 2, 0, tid + 256);
+      } else if (p_vec > 2 && p_vec < kWPasses && !(MXW_ABL & 2)) {
+        mxw_build_step(shw, p_vec - 3, p_vec & 1, tid);
+        mxw_build_step(shw, p_vec - 3, p_vec & 1, tid + 256);
+      }
+    }
   }
+#if MXW_ABL & 256
+  if (blockIdx.x == 1000 && lane == 0)
+    printf("wave %d: barrier %llu build %llu pass %llu epilogue %llu, loop %llu cycles\n", wave, t_bar, t_build, t_pass, t_epi,
+           __builtin_readcyclecounter() - t_begin);
+#endif
   __syncthreads();
   // ---- one triplet per (search, PRN, Doppler): the eight bit shifts' slots (32 lanes each) meet here --------------------------
   {
