@@ -47,7 +47,7 @@
 // at its own sample offset (mx_direct_terms: every quirk term as a start value), results merged through global planes.
 #if !defined(GPSX_LAB) && (defined(WALK_ABL_NO_LOAD) || defined(WALK_ABL_NO_STORE) || defined(GPSX_MX_ABLATIONS) || \
                            defined(GPSX_MX_NO_PIECES) || defined(GPSX_MX_TIMELINE) || defined(MX_BUILD_BEHIND) || defined(GPSX_MX_NT) || \
-                           defined(MX_VARIANT_B) || defined(WALK_ABL_ALIAS) || defined(MXW_ABL))
+                           defined(MX_VARIANT_B) || defined(WALK_ABL_ALIAS) || defined(MXW_ABL) || defined(GPSX_MX_CYCLES))
 #error "timing ablations / instrumented variants of k_acq_mx (some give wrong results) build with -DGPSX_LAB only: tools/build_variant.sh"
 #endif
 #include <cstdlib>
@@ -1472,11 +1472,22 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
     // offset p - 2, then pass p -- one wave of a SIMD on the matrix pipe while the other has the vector ALU, with nothing
     // but their own pace between the halves: ONE barrier per step, where all eight waves build the vector of pass p + 1
     // into the buffer that both roles read during step p - 1.
+#ifdef GPSX_MX_CYCLES   // (lab: where workgroup 1000's waves spend their cycles -- barrier, vector building, pass, epilogue)
+    unsigned long long cy_bar = 0, cy_build = 0, cy_pass = 0, cy_epi = 0;
+    const unsigned long long cy_begin = __builtin_readcyclecounter();
+#define MX_CY(acc_var) do { const unsigned long long now = __builtin_readcyclecounter(); acc_var += now - cy_last; cy_last = now; } while (0)
+#else
+#define MX_CY(acc_var) do { } while (0)
+#endif
 #pragma unroll 1
     for (int hs = (ex & 256) ? 2 * n_pass + 1 : 0; hs <= 2 * n_pass; hs++) {   // (timing ablation 256: no steps at all)
+#ifdef GPSX_MX_CYCLES
+      unsigned long long cy_last = __builtin_readcyclecounter();
+#endif
       MX_TL1();
       if ((hs & 1) == 0)
         __syncthreads();
+      MX_CY(cy_bar);
       MX_TL1();
       // The vector of the next step: built behind the barrier by everybody (single-block forms), or behind this step's epilogue
       // by the role that just finished one (walk forms: each role's threads own one stream of the vector -- threads 0..255 =
@@ -1499,6 +1510,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         }
       }
       MX_TL1();
+      MX_CY(cy_build);
       int lane_s = lane;         // (walk forms: opaque per half step, see tid_p -- record addresses are recomputed, not spilled)
       if constexpr (MULTI)
         asm volatile("" : "+v"(lane_s));
@@ -1529,6 +1541,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         }
       }
       MX_TL1();
+      MX_CY(cy_pass);
       if (STORE) {
         if (active && (x & 1) && p >= 1) {
           uint16_t *plane0 = reinterpret_cast<uint16_t *>(energy) +
@@ -1543,6 +1556,7 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         else
           mx_epilogue<MULTI, true, S16>(sh, lane_s, q0_tile, p - 1, acc, group_mask, e_wave, zero_recs, pre, ms_first, witness);
       }
+      MX_CY(cy_epi);
       if (kBuildBehindEpilogue && (x & 1) != 0) {
         const int p_vec = (hs >> 1) + 1;
         if (p_vec >= 2 && p_vec < n_pass && !(ex & 8)) {
@@ -1553,6 +1567,11 @@ __device__ __forceinline__ void mx_unit(MxShared &sh, const AcqParams &prm, int 
         }
       }
     }
+#ifdef GPSX_MX_CYCLES
+    if (blockIdx.x == 1000 && lane == 0 && ms == 0)
+      printf("mode %d wave %d: barrier %llu build %llu pass %llu epilogue %llu, loop %llu cycles\n", MODE, wave, cy_bar, cy_build, cy_pass,
+             cy_epi, __builtin_readcyclecounter() - cy_begin);
+#endif
   }
   if (STORE)
     return;   // k_acq_vals_search sums the blocks and searches
