@@ -75,6 +75,26 @@ def test_weighted_grid_on_strong_and_degenerate_captures(eng, oracle, path):
         _path(eng, "matrix")
 
 
+def test_weighted_grid_over_the_root_s_input_range(eng, oracle):
+    """The matrix-core kernel's fast root (floor(sqrt(E)) from the hardware root of E + 2, E < 2^24) and its exact fallback share
+    a border at |I|, |Q| = 2896: satellites from far below the noise to far above it put peak magnitudes on both sides of it and
+    side-lobe magnitudes all over the fast path's range -- every sum has to match the oracle's (one root off by one shows)."""
+    from conftest import oracle_threads
+    from stm32f4_sdr_gps_amd import synth
+    prns = np.array([7, 19, 30, 2], np.uint8)
+    tops = []
+    for amp in (0.02, 0.05, 0.1, 0.2, 0.4, 0.8, 1.6):
+        sats = [synth.Sat(7, 1310.0, 4321.0, amp, 0.4), synth.Sat(19, 1290.0, 12007.0, amp * 0.7, 2.0), synth.Sat(30, 1350.0, 13000.0, amp * 0.4, 4.0)]
+        blocks = synth.make_if_static(1, sats, noise_amp=1.0, seed=int(amp * 1000), two_bit=True)
+        got = eng.acq_grid_weighted(blocks, prns, 1, 1310, 40, 2, use_magnitude=True)
+        assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mxw"
+        want = oracle.acq_grid_weighted(blocks, 1, prns, 1310, 40, 2, True, n_threads=oracle_threads())
+        for f in ("max_val", "phase", "sum", "avr"):
+            assert np.array_equal(got[f], want[f]), (amp, f, got[f].tolist(), want[f].tolist())
+        tops.append(int(got["max_val"].max()))
+    assert min(tops) < 2896 < max(tops), tops
+
+
 def test_weighted_mode_argument_checks_and_the_one_bit_path_is_untouched(eng, oracle):
     from stm32f4_sdr_gps_amd import capi
     blocks = _blocks(2, 0.3, 3)
