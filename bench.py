@@ -67,6 +67,143 @@ LANE_OPS_PER_HYP_MIN_MODEL_MX = 10.25                # the kernel's own formulat
                                                      # MFMAs' own issue slots, 17 x 136 x 8 per 8192 lane-hypotheses = 2.25
 
 
+def _valu_class_rates():
+    """Issue rates of the vector-ALU instruction classes the polyphase kernel is made of, as MICRO-BENCHMARKED on an MI355X
+    (tools/microbench/valu_rates.hip -> tools/valu_class_rates.py -> profiles/valu_class_rates.json, T lane-ops/s at the clock
+    the chip sustains under that load): the v_and_b32 + accumulating v_bcnt_u32_b32 pair of the bit-plane correlation (the
+    v_and issues in 2 cycles, the pair runs above the 4-cycle model) and the 4-cycle class everything else belongs to.
+    None without the file: the caller prices against the 4-cycle model then and says so."""
+    path = os.path.join(ROOT, "profiles", "valu_class_rates.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def _poly_valu_roofline(issued_per_hyp, rate_hyp_s, counter_source):
+    """The vector-ALU kernel's fraction of its issue ceiling: the time its ISSUED instruction stream (SQ_INSTS_VALU x 64 lanes per
+    hypothesis, from the committed PMC summary of this kernel at this launch shape) would take at the micro-benchmarked issue
+    rates of its instruction classes -- 128 lane-ops per hypothesis of v_and + accumulating v_bcnt (2 streams x 32 words x 2:
+    the polyphase bit-plane correlation, EXPERIMENTS.md "4.1b"), the rest in the 4-cycle class -- over the time it took."""
+    if not issued_per_hyp:
+        return {"bound": "valu-int-issue", "frac": None, "counter_source": None,
+                "note": "no committed SQ_INSTS_VALU for this kernel at this launch shape (profiles/kernel_counters.json)"}
+    rates = _valu_class_rates()
+    pair_ops = min(128.0, issued_per_hyp)
+    if rates:
+        r_pair, r_four = rates["and_bcnt_pair_tlane_ops"], rates["four_cycle_class_tlane_ops"]
+        basis = "micro-benchmarked class rates (" + rates.get("source", "profiles/valu_class_rates.json") + ")"
+    else:
+        r_pair = r_four = VALU_INT_PEAK_TOPS
+        basis = "the 4-cycle issue model (no micro-benchmarked class rates in profiles/): and-class ops beat it, the fraction can exceed 1"
+    t_peak = (pair_ops / r_pair + (issued_per_hyp - pair_ops) / r_four) * 1e-12        # s per hypothesis at the issue ceiling
+    peak = issued_per_hyp / t_peak / 1e12                                               # T lane-ops/s of THIS mix
+    ach = issued_per_hyp * rate_hyp_s / 1e12
+    return {"bound": "valu-int-issue", "achieved": ach, "peak": peak, "unit": "Tlane-op/s", "frac": ach / peak,
+            "lane_ops_per_hyp_issued": issued_per_hyp, "lane_ops_per_hyp_and_bcnt": pair_ops,
+            "peak_basis": basis, "counter_source": counter_source,
+            "lane_ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
+            "lane_ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF}
+
+
+def _poly_counters(searches, kernel=None):
+    """(issued lane-ops per hypothesis, source, entry) of the polyphase kernel from profiles/kernel_counters.json: the entry of this
+    launch shape if there is one, else any one-block entry (the count is linear in the captures)."""
+    kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    if not os.path.exists(kc_file):
+        return None, None, None
+    with open(kc_file) as f:
+        ents = [e for e in json.load(f) if e.get("kernel", "").startswith("k_acq_poly") and e.get("SQ_INSTS_VALU")
+                and e.get("n_ms") == 1 and (kernel is None or e["kernel"] == kernel)]
+    if not ents:
+        return None, None, None
+    ents.sort(key=lambda e: (e["searches_per_launch"] == searches, e.get("source", "")))
+    ent = ents[-1]
+    return ent["SQ_INSTS_VALU"] * 64.0 / (ent["searches_per_launch"] * HYP_PER_SEARCH), ent.get("source"), ent
+
+
+def _kernel_counters(kernel, searches, n_ms):
+    """The entry of profiles/kernel_counters.json (tools/summarize_profile.py) for this kernel and launch shape, or None."""
+    kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    if not os.path.exists(kc_file):
+        return None
+    found = None
+    with open(kc_file) as f:
+        for ent in json.load(f):
+            if (ent.get("kernel") == kernel and ent.get("searches_per_launch") == searches and ent.get("n_ms") == n_ms
+                    and ent.get("world", 1) == 1):
+                found = ent
+    return found
+
+
+def _profiled_mean(roof, counters, amount, peak, scale):
+    """`frac` := amount / the MEAN launch of the committed rocprofv3 kernel trace of this kernel at this launch shape
+    (profiles/<tag>_kernel_stats.csv, AverageNs) -- the figure anybody can recompute from profiles/ -- with this run's own
+    HIP-event figure kept beside it as frac_live.  `amount` in flops or bytes per launch, `scale` 1e12 or 1e9."""
+    roof["frac_live"], roof["achieved_live"] = roof["frac"], roof["achieved"]
+    roof["frac_basis"] = "live: HIP events around this run's launches (no committed kernel trace of this kernel and launch shape)"
+    if counters and counters.get("kernel_trace_avg_ns"):
+        mean_ns = counters["kernel_trace_avg_ns"]
+        roof["profiled_kernel_ms_mean"] = mean_ns * 1e-6
+        roof["profiled_launches"] = counters.get("kernel_trace_calls")
+        roof["profiled_kernel_ms_median_min_max"] = [(counters.get(k) or 0) * 1e-6 or None for k in
+                                                     ("kernel_trace_median_ns", "kernel_trace_min_ns", "kernel_trace_max_ns")]
+        roof["frac_profiled_mean"] = amount / (mean_ns * 1e-9) / scale / peak
+        roof["frac"] = roof["frac_profiled_mean"]
+        roof["achieved"] = roof["frac"] * peak
+        roof["frac_basis"] = ("mean launch of the committed rocprofv3 kernel trace (" +
+                              str(counters.get("trace_source") or counters.get("source")) + "); frac_live = this run's HIP events")
+    return roof
+
+
+def _mx_roofline(hyp_per_launch, launch_ms, counters, clk_khz):
+    """k_acq_mx<0>, one block per search: the GEMM on the matrix cores is the dominant operation -- algorithmic FP4 flops per
+    launch against the dense MX-FP4 peak."""
+    flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
+    ach = flops / (launch_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / MFMA_FP4_PEAK_TFLOPS, "flops_per_hyp": MFMA_FLOPS_PER_HYP, "dtype": "MX-FP4 (E2M1) x MX-FP4 -> f32",
+            "mfma_busy_frac": (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (launch_ms * 1e-3 * clk_khz * 1e3))
+                              if counters and counters.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
+            "counter_source": counters.get("source") if counters else None}
+    _profiled_mean(roof, counters, flops, MFMA_FP4_PEAK_TFLOPS, 1e12)
+    if counters and counters.get("gpu_cycles_per_launch") and counters.get("SQ_VALU_MFMA_BUSY_CYCLES") and counters.get("kernel_trace_avg_ns"):
+        # the profiled launch: shader cycles actually spent (the clock follows the power budget) -- the share of
+        # them the matrix pipe was busy, and the clock they imply; `frac` above is against the 2.4 GHz peak
+        roof["profiled_clock_ghz"] = counters["gpu_cycles_per_launch"] / counters["kernel_trace_avg_ns"]
+        roof["mfma_busy_frac_of_profiled_cycles"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / counters["gpu_cycles_per_launch"]
+    return roof
+
+
+def _walk_roofline(kernel, hyp_per_launch, n_ms, launch_ms, counters):
+    """k_acq_mx<3> / <1>, non-coherent integration over n_ms blocks: the running sums of the 16368 x 32 x 21 hypotheses of a
+    search do not fit on chip, they make a round trip through HBM per block -- 2 B read + 2 B written per hypothesis and block
+    as 16-bit records (k_acq_mx<3>; the 24-bit records of k_acq_mx<1> are 3 + 3 B), except the first block (nothing to read)
+    and the last (nothing to write).  Returns (the HBM block, the matrix-pipe block of the same launch)."""
+    rec_bytes = 4.0 if kernel.endswith("<3>") else 6.0
+    alg_bytes = hyp_per_launch * rec_bytes * (n_ms - 1) / n_ms
+    ach = alg_bytes / (launch_ms * 1e-3) / 1e9
+    flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
+    mfma_block = {"bound": "mfma", "achieved": flops / (launch_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
+                  "unit": "TFLOP/s", "frac": flops / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS}
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "bytes_per_hyp_block": rec_bytes * (n_ms - 1) / n_ms, "algorithmic_bytes": alg_bytes,
+            "counter_source": counters.get("source") if counters else None}
+    _profiled_mean(roof, counters, alg_bytes, HBM_PEAK_GBS, 1e9)
+    _profiled_mean(mfma_block, counters, flops, MFMA_FP4_PEAK_TFLOPS, 1e12)
+    traffic = counters.get("hbm_bytes_per_launch") if counters else None
+    if traffic:
+        # what the memory system moved (rocprofv3 FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) against
+        # the formulation's own record bytes, and against the bytes ANY formulation must move (SURVEY.md 8(d): the captures in,
+        # one 8-byte key per (search, PRN, Doppler) out)
+        n_search = hyp_per_launch / (n_ms * HYP_PER_SEARCH)
+        compulsory = n_search * n_ms * 4092.0 + n_search * N_PRN * N_DOPP * 8.0
+        roof.update({"traffic": traffic, "traffic_gbs": traffic / (launch_ms * 1e-3) / 1e9,
+                     "traffic_over_algorithmic": traffic / alg_bytes, "compulsory_bytes": compulsory,
+                     "traffic_over_compulsory": traffic / compulsory})
+    return roof, mfma_block
+
+
 def _ref_prn_slice(ref, blk, prn_list, deadline):
     """All 21 Doppler bins x 8 bit shifts x 2046 offsets for each PRN of the slice, with the reference's own calls."""
     done = 0
@@ -160,6 +297,7 @@ def tracking_closed_loop(ms=1200):
     literal = mod.closed_loop(256, 10000, 0.12, 0, literal=True, realtime_thread=True)
     config5_host = {k: literal[k] for k in keep + ("signals_in_stream", "ms", "paced_at_1ms", "realtime_thread",
                                                    "code_and_carrier_lock_in_the_reference_on_this_stream", "not_locked")}
+    config5_host["every_steady_step_under_1ms"] = config5_host.pop("real_time")   # (a latency reading, not a real-time claim)
     config5_host["mode"] = ("loops on the HOST behind every correlator launch (gps_tracking_process_batch, the bit-exact mode): one "
                             "host round trip per millisecond, deadline 1 ms per step -- best effort on a shared host: a thread "
                             "another tenant preempts for milliseconds misses a step")
@@ -185,7 +323,7 @@ def tracking_closed_loop(ms=1200):
                       "1 ms at that count or at any smaller one",
             "value": best, "device_loop": device, "larger_counts_that_met_every_deadline_after_a_smaller_one_missed": isolated,
             "largest_count_with_p99_under_1ms": max(by_p99) if by_p99 else None,
-            "config5": _config5_figure(device, config5_host), "config5_host_mode": config5_host,
+            "config5": _config5_figure(device, config5_host), "config5_host_mode_latency": config5_host,
             "one_signal_in_32_never_locks": "PRN 1 at delay 0 is handed over with found_code_phase 0; the reference's pre-tracking "
                                             "accepts a settled phase only if it is non-zero (tracking.c gps_pre_track_process, "
                                             "`if (max_phase_value)`), so that channel stays in GPS_PRE_TRACK_RUN for ever -- in the "
@@ -202,18 +340,19 @@ def tracking_closed_loop(ms=1200):
 
 
 def _config5_figure(device, host):
-    """BASELINE.json configs[4] (256 channels, 10 s, sustained real time): the figure is the DEVICE loop's run of SURVEY's literal
-    config 5 -- since round 5 the complete mode (the reference's traces byte for byte, data polarity and bit edges on the
-    device, tests/test_gpu_track_mux.py / test_gpu_track_loop.py): 20 ms of stream per launch, real time = every launch of the
-    steady half is back before the next 20 ms of samples exist.  The host-mode run of the same stream stays in the line as
-    config5_host_mode.  Falls back to the host mode's run if the device leg failed."""
+    """BASELINE.json configs[4] (256 channels, 10 s, sustained real time) has ONE real-time figure in the line: the DEVICE loop's
+    run of SURVEY's literal config 5 -- since round 5 the complete mode (the reference's traces byte for byte, data polarity and
+    bit edges on the device, tests/test_gpu_track_mux.py / test_gpu_track_loop.py): K ms of stream per launch, real time = every
+    launch of the steady half is back before the next K ms of samples exist (`launches_over_deadline` of `deadline_us`; no
+    per-millisecond key: a launch is K ms).  The host-mode run of the same stream (one host round trip per millisecond on a
+    shared, non-real-time host) stays in bench_detail.json as a latency distribution, `config5_host_mode_latency`; it is not a
+    real-time claim.  Falls back to it, and says so, only if the device leg did not run."""
     lit = (device or {}).get("config5") if isinstance(device, dict) else None
     if not lit or "real_time" not in lit:
-        return dict(host, figure_from="host mode (the device-loop leg did not run)")
+        return dict(host, loops="host (gps_tracking_process_batch)", figure_from="host mode: the device-loop leg did not run")
     out = dict(lit)
-    out["steps_over_1ms"] = lit["launches_over_deadline"]     # (a launch over its K ms = K steps over their millisecond)
-    out["mode"] = ("loops on the DEVICE (k_track_loop, GPSX_SCHED_EVERY_MS as the literal config 5 serves its channels), "
-                   f"{lit['ms_per_launch']} ms of stream per launch, word layer on the host; deadline = the launch's own "
+    out["loops"] = "device (k_track_loop, GPSX_SCHED_EVERY_MS)"
+    out["mode"] = (f"{lit['ms_per_launch']} ms of stream per launch, word layer on the host; deadline = the launch's own "
                    f"{lit['ms_per_launch']} ms")
     return out
 
@@ -385,6 +524,7 @@ def _parity_sample(keys, sign_blocks_of, n_search, n_ms):
 
 
 def main():
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -404,6 +544,10 @@ def main():
                     help="sample format of the captures in HBM: 2bit = MAX2769-style sign/magnitude pairs, 4092 bytes per ms, "
                          "unpacked to the sign plane in LDS inside the kernels (the reference's correlator never looks at "
                          "the magnitude bit either); 1bit = the 2046-byte sign stream the firmware's SPI delivers")
+    ap.add_argument("--acq-path", choices=["matrix", "vector"], default="matrix",
+                    help="matrix (default): the MX-FP4 Toeplitz GEMM kernels; vector: north_star's literal form, the polyphase "
+                         "XOR/popcount kernel on the vector ALU (gpsx_set_acq_path(GPSX_ACQ_PATH_VECTOR)) as the HEADLINE kernel -- "
+                         "what tools/profile_bench.sh profiles that kernel with")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true",
                     help="skip the pcie_inclusive leg (profiling runs: its two concurrent contexts stretch the kernel durations "
@@ -458,6 +602,8 @@ def main():
 
     stream = torch.cuda.Stream(device=dev)
     eng = capi.Engine(dev_index, stream=stream.cuda_stream)
+    if args.acq_path == "vector":
+        eng.set_acq_path(capi.ACQ_PATH_VECTOR)
     dev_name, cus, clk_khz = eng.device_info()
     # who takes part in the collective, for the driver to check against --gpus: every rank's device as the communicator sees it
     comm = None
@@ -613,8 +759,12 @@ def main():
                                      "unsharded, no collective" % n_search,
                          "value": n_search * 10 * HYP_PER_SEARCH / (ten_ms * 1e-3), "unit": "hypotheses/s (per 1 ms block)",
                          "ms_per_step": ten_ms, "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
+                         "roofline": None, "roofline_mfma": None,
                          "note": "the N = 1 point of the `--gpus N` series (whose lines are configs[3], weak scaling): divide their "
                                  "`value` by N x this one"}
+            k10 = ten_block["kernel"][len("gpsx::"):]
+            ten_block["roofline"], ten_block["roofline_mfma"] = _walk_roofline(
+                k10, n_search * 10 * HYP_PER_SEARCH, 10, ten_ms, _kernel_counters(k10, n_search, 10))
         except Exception as exc:   # a secondary leg must not take the headline line with it
             ten_block = {"error": repr(exc)}
             print(f"bench.py: ten-block leg failed: {exc!r}", file=sys.stderr, flush=True)
@@ -654,28 +804,11 @@ def main():
                 same_keys = bool(torch.equal(v_keys, m_keys)) and int(v_keys.min()) > 0
             eng_v.close()
             v_rate = n_search * HYP_PER_SEARCH / (v_ms * 1e-3)
-            issued_per_hyp, src = None, None
-            kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
-            if os.path.exists(kc_file):
-                with open(kc_file) as f:
-                    for ent in json.load(f):
-                        if ent.get("kernel", "").startswith("k_acq_poly") and ent.get("SQ_INSTS_VALU") and ent.get("n_ms") == 1:
-                            issued_per_hyp = ent["SQ_INSTS_VALU"] * 64.0 / (ent["searches_per_launch"] * HYP_PER_SEARCH)
-                            src = ent.get("source")
+            issued_per_hyp, src, _ = _poly_counters(args.searches, v_kernel)
             letter = {"workload": "the headline launch (same captures, same grid) on the vector ALU: no MFMA",
                       "value": v_rate, "unit": "hypotheses/s", "ms_per_launch": v_ms, "kernel": "gpsx::" + v_kernel,
                       "keys_identical_to_the_matrix_core_path": same_keys,
-                      "roofline_valu": {"bound": "valu-int-issue", "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
-                                        "lane_ops_per_hyp_issued": issued_per_hyp, "counter_source": src,
-                                        "achieved": (issued_per_hyp * v_rate / 1e12) if issued_per_hyp else None,
-                                        "frac": (issued_per_hyp * v_rate / 1e12 / VALU_INT_PEAK_TOPS) if issued_per_hyp else None,
-                                        "lane_ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
-                                        "lane_ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF,
-                                        "note": "issued lane-ops per hypothesis from the committed PMC summary of this kernel (a 64-capture "
-                                                "launch; the count is linear in the captures) x this run's rate.  The reference's own "
-                                                "formulation (1024 xor + 1024 popcount per hypothesis) is 2048 lane-ops: the polyphase "
-                                                "recurrence does the same sums in a tenth of the operations, so 2048 x rate is not a "
-                                                "fraction of this kernel's roofline"}}
+                      "roofline_valu": _poly_valu_roofline(issued_per_hyp, v_rate, src)}
             if not same_keys:
                 raise AssertionError("the vector-ALU path's key table differs from the matrix-core path's")
         except Exception as exc:   # a secondary leg must not take the headline line with it
@@ -886,108 +1019,58 @@ def main():
         hyp_per_launch = n_search * n_ms * HYP_PER_SEARCH / world   # per GPU
         kernel = headline_kernel
         # counters of this kernel and launch shape, from the committed rocprofv3 PMC summaries (tools/summarize_profile.py)
-        counters = None
-        kc_file = os.path.join(ROOT, "profiles", "kernel_counters.json")
-        if os.path.exists(kc_file):
-            with open(kc_file) as f:
-                for ent in json.load(f):
-                    if (ent.get("kernel") == kernel and ent.get("searches_per_launch") == args.searches
-                            and ent.get("n_ms") == n_ms and ent.get("world", 1) == 1):
-                        counters = ent
+        counters = _kernel_counters(kernel, args.searches, n_ms)
         is_mx = kernel.startswith("k_acq_mx")
         valu = None
-        if counters and counters.get("SQ_INSTS_VALU"):
+        if is_mx and counters and counters.get("SQ_INSTS_VALU"):
             issued = counters["SQ_INSTS_VALU"] * 64.0                       # lane-ops per launch
             ach = issued / (launch_ms * 1e-3) / 1e12
-            min_model = LANE_OPS_PER_HYP_MIN_MODEL_MX if is_mx else LANE_OPS_PER_HYP_MIN_MODEL
             valu = {"bound": "valu-issue", "achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
                     "frac": ach / VALU_INT_PEAK_TOPS,
                     "ops_per_hyp_issued": issued / hyp_per_launch,
-                    "ops_per_hyp_min_model": min_model,
-                    "useful_frac": min_model * hyp_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
+                    "ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL_MX,
+                    "useful_frac": LANE_OPS_PER_HYP_MIN_MODEL_MX * hyp_per_launch / (launch_ms * 1e-3) / 1e12 / VALU_INT_PEAK_TOPS,
                     "counter_source": counters.get("source"),
-                    "note": "issued vector-ALU lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
-                            "time) against one wave64 op per 4 cycles per SIMD (256 CU x 64 lanes/clk x 2.4 GHz); a few op "
-                            "classes (and, add, f32 mul/fma) issue in 2 cycles (profiles/r02_valu_rates_microbench.txt), so "
-                            "a mix of them can read slightly above 1"}
+                    "note": "issued vector-ALU lane-ops/s beside the matrix pipe (SQ_INSTS_VALU of the committed PMC summary x 64 / "
+                            "this run's launch time) against the 4-cycle issue model, 256 CU x 64 lanes/clk x 2.4 GHz"}
         mfma_block = None
         if is_mx and n_ms > 1:
-            # Non-coherent integration: the running sums of the 16368 x 32 x 21 hypotheses of a search do not fit on chip,
-            # they make a round trip through HBM per block -- 2 B read + 2 B written per hypothesis and block as 16-bit
-            # records (k_acq_mx<3>; the 24-bit records of k_acq_mx<1>, the form that redoes a cluster whose sums outgrew
-            # them, are 3 + 3 B), except the first block (nothing to read) and the last (nothing to write)
-            rec_bytes = 4.0 if kernel.endswith("<3>") else 6.0
-            alg_bytes = hyp_per_launch * rec_bytes * (n_ms - 1) / n_ms
-            ach = alg_bytes / (launch_ms * 1e-3) / 1e9
-            flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
-            mfma_block = {"bound": "mfma", "achieved": flops / (launch_ms * 1e-3) / 1e12, "peak": MFMA_FP4_PEAK_TFLOPS,
-                          "unit": "TFLOP/s", "frac": flops / (launch_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS}
-            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "bytes_per_hyp_block": rec_bytes * (n_ms - 1) / n_ms,
-                    "counter_source": counters.get("source") if counters else None}
+            roof, mfma_block = _walk_roofline(kernel, hyp_per_launch, n_ms, launch_ms, counters)
         elif is_mx:
-            # the GEMM on the matrix cores is the dominant operation of this kernel: algorithmic FP4 flops / launch time
-            # against the dense MX-FP4 peak; the vector-ALU side (epilogue, vector building) is priced beside it
-            flops = MFMA_FLOPS_PER_HYP * hyp_per_launch
-            ach = flops / (launch_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / MFMA_FP4_PEAK_TFLOPS, "flops_per_hyp": MFMA_FLOPS_PER_HYP, "dtype": "MX-FP4 (E2M1) x MX-FP4 -> f32",
-                    "mfma_busy_frac": (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (launch_ms * 1e-3 * clk_khz * 1e3))
-                                      if counters and counters.get("SQ_VALU_MFMA_BUSY_CYCLES") else None,
-                    "counter_source": counters.get("source") if counters else None}
-            roof["frac_live"] = roof["frac"]           # this run: HIP events on the engine's stream around the K launches
-            if counters and counters.get("kernel_trace_avg_ns"):
-                # the committed rocprofv3 kernel trace of the same command (profiles/<tag>_kernel_stats.csv): the profiled run
-                # clocks a few per cent lower, so its fraction is the smaller one -- both are reported, neither is hidden
-                # (the MEDIAN launch of the trace where the summary has it: one slow launch of twenty moves the mean by 3 %;
-                #  mean, min and max are in the line beside it)
-                prof_ns = counters.get("kernel_trace_median_ns") or counters["kernel_trace_avg_ns"]
-                roof["profiled_kernel_ms"] = prof_ns * 1e-6
-                roof["profiled_kernel_ms_mean_min_max"] = [counters["kernel_trace_avg_ns"] * 1e-6,
-                                                           (counters.get("kernel_trace_min_ns") or 0) * 1e-6 or None,
-                                                           (counters.get("kernel_trace_max_ns") or 0) * 1e-6 or None]
-                roof["frac_profiled"] = flops / (prof_ns * 1e-9) / 1e12 / MFMA_FP4_PEAK_TFLOPS
-                roof["frac_profiled_basis"] = "median launch of the committed rocprofv3 kernel trace" if counters.get("kernel_trace_median_ns") \
-                    else "mean launch of the committed rocprofv3 kernel trace"
-                roof["frac_profiled_mean"] = flops / (counters["kernel_trace_avg_ns"] * 1e-9) / 1e12 / MFMA_FP4_PEAK_TFLOPS
-            if counters and counters.get("gpu_cycles_per_launch") and counters.get("SQ_VALU_MFMA_BUSY_CYCLES"):
-                # the profiled launch: shader cycles actually spent (the clock follows the power budget) -- the share of
-                # them the matrix pipe was busy, and the clock they imply; `frac` above is against the 2.4 GHz peak
-                roof["profiled_clock_ghz"] = counters["gpu_cycles_per_launch"] / counters["kernel_trace_avg_ns"]
-                roof["mfma_busy_frac_of_profiled_cycles"] = (counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 /
-                                                             counters["gpu_cycles_per_launch"])
-        elif valu is not None:
-            roof = dict(valu)
-            roof["bound"] = "valu-int-issue"
-            valu = None
+            roof = _mx_roofline(hyp_per_launch, launch_ms, counters, clk_khz)
         else:
-            # no committed counters for this kernel / shape: price the formulation's own lower bound instead (<= issued)
-            ach = LANE_OPS_PER_HYP_MIN_MODEL * hyp_per_launch / (launch_ms * 1e-3) / 1e12
-            roof = {"bound": "valu-int-issue", "achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s",
-                    "frac": ach / VALU_INT_PEAK_TOPS, "ops_per_hyp_issued": None,
-                    "ops_per_hyp_min_model": LANE_OPS_PER_HYP_MIN_MODEL,
-                    "ops_per_hyp_reference_formulation": LANE_OPS_PER_HYP_REF, "counter_source": None}
+            issued_per_hyp, src, _ = _poly_counters(args.searches, kernel)
+            roof = _poly_valu_roofline(issued_per_hyp, hyp_per_launch / (launch_ms * 1e-3), src)
+            if roof.get("frac") is None:
+                # no committed counters for this kernel: price the formulation's own lower bound instead (<= issued)
+                ach = LANE_OPS_PER_HYP_MIN_MODEL * hyp_per_launch / (launch_ms * 1e-3) / 1e12
+                roof.update({"achieved": ach, "peak": VALU_INT_PEAK_TOPS, "unit": "Tlane-op/s", "frac": ach / VALU_INT_PEAK_TOPS,
+                             "peak_basis": "the formulation's minimum lane-ops per hypothesis against the 4-cycle issue model"})
         traffic = counters.get("hbm_bytes_per_launch") if counters else None
+        if not (is_mx and n_ms > 1):
+            # one block per search: the bytes any formulation moves per launch -- captures in, one 16-byte peak record per (search,
+            # PRN, Doppler, bit shift) and one 8-byte key per (search, PRN, Doppler) out -- and what rocprofv3 counted (FETCH_SIZE +
+            # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes)
+            per_search = (4092.0 if two_bit else 2046.0) + N_PRN * N_DOPP * (8 * 16 + 8)
+            alg_bytes = per_search * n_search / world
+            roof.update({"traffic": traffic, "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                         "algorithmic_bytes": alg_bytes,
+                         "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                         "traffic_frac_of_hbm_peak": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None})
         roof.update({
-            # what the chip's memory system actually moved per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, corrected as
-            # MI355X_MICROARCH.md prescribes), as a rate over this run's launch time and against the HBM peak
-            "traffic": traffic,
-            "traffic_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
-            "traffic_frac_of_hbm_peak": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "reference_equivalent_stream_gbs": hyp_per_launch * BYTES_PER_HYP / (launch_ms * 1e-3) / 1e9,
             "kernel": "gpsx::" + kernel,
             "kernel_ms": launch_ms,
             "note": ("the captures stay in LDS and the correlations run as an MX-FP4 Toeplitz GEMM on the matrix cores; what binds "
                      "the multi-block form most is the running sums' round trip through HBM (16-bit records: 4 B per hypothesis "
-                     "and block, first and last block 2 B): achieved = those algorithmic bytes / this run's launch time against "
-                     "8 TB/s; `traffic` is what rocprofv3 counted; the matrix pipe's share of the same launch is roofline_mfma" if (is_mx and n_ms > 1) else
+                     "and block, first and last block 2 B): achieved = those bytes / launch time against 8 TB/s; `traffic` is what "
+                     "rocprofv3 counted; the matrix pipe's share of the same launch is roofline_mfma" if (is_mx and n_ms > 1) else
                      "operands stay in LDS, HBM traffic is ~0 by construction.  The correlations run as an MX-FP4 Toeplitz GEMM "
                      "on the matrix cores: achieved = algorithmic flops (17 passes x 2 streams x 2*32*1024*1024 per (search, "
-                     "Doppler) pair) / this run's launch time, peak = dense FP4; the vector ALU (clip, square, root, search) "
+                     "Doppler) pair) / launch time, peak = dense FP4; the vector ALU (clip, square, root, search) "
                      "runs beside it, see roofline_valu" if is_mx else
-                     "operands stay in LDS, HBM traffic is ~0 by construction: the binding resource is integer VALU issue. "
-                     "achieved = issued lane-ops/s (SQ_INSTS_VALU of the committed PMC summary x 64 / this run's launch "
-                     "time); peak = 256 CU x 64 lanes/clk x 2.4 GHz (micro-benchmarked)") +
+                     "operands stay in LDS, HBM traffic is ~0 by construction: the binding resource is integer VALU issue, priced "
+                     "at the micro-benchmarked issue rates of the kernel's instruction classes") +
                     "; reference_equivalent_stream_gbs is 6138 B/hypothesis as the reference re-reads its operands -- "
                     "information, not a fraction of anything",
         })
@@ -1025,6 +1108,10 @@ def main():
             "device": {"name": dev_name, "compute_units": cus, "clock_khz": clk_khz},
         }
         if pcie is not None:
+            # SURVEY.md 8(d)(i)'s wording of the metric (host-pinned captures -> H2D -> sweep -> D2H of peaks and keys).  The bench
+            # contract fixes `value` as the device-resident rate ("inputs already resident in HBM when the timed region starts ...
+            # the PCIe-inclusive rate is never `value`"), so the survey's figure travels beside it under its own name
+            line["value_pcie_inclusive"] = pcie
             line["pcie_inclusive"] = {"value": pcie, "unit": "hypotheses/s", "serial": pcie_serial,
                                       "frac_of_value": pcie / value,
                                       "note": "SURVEY.md 8(d)'s wording of the metric: pinned host buffers, H2D captures + "
@@ -1054,7 +1141,12 @@ def main():
             except Exception as exc:   # (the reported baseline: its failure is reported, the line still goes out)
                 line["cpu_baseline"] = {"error": repr(exc)}
             line["cpu_host"] = {"logical_cpus": os.cpu_count()}
-        out_line = json.dumps(line)
+        from stm32f4_sdr_gps_amd import benchline
+        line["bench_wall_s"] = time.perf_counter() - t_start
+        line["fits_in_driver_run"] = bool(line["bench_wall_s"] < 300.0)      # "a K/W that finish within minutes"
+        line["detail"] = "bench_detail.json"
+        benchline.write_detail(line, ROOT)
+        out_line = benchline.render_safe(line)     # compact, <= 4 KB, strict JSON, contract keys present
     else:
         out_line = None
 

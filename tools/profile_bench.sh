@@ -8,7 +8,10 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 EXTRA=${BENCH_ARGS:-}   # e.g. BENCH_ARGS="--n-ms 10" for the non-coherent configuration
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-tracking --no-pcie --no-native $EXTRA"
+# the trace runs the driver's own step counts (bench.py's defaults, 50 + 5) unless TRACE_ARGS says otherwise: its MEAN launch is
+# what bench.py prices roofline.frac from
+TRACE_ARGS=${TRACE_ARGS:-"--steps 50 --warmup 5"}
+BENCH="python $REPO/bench.py $TRACE_ARGS --no-cpu-baseline --no-tracking --no-pcie --no-native $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 SMALL="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking --no-pcie --no-native $EXTRA"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $SMALL > $OUT/pmc_fetch.log 2>&1

@@ -37,8 +37,9 @@ def main(tag="r02", searches=256, n_ms=1, pattern=None):
     rows = [r for r in rows if (pattern in r["Name"] if pattern else "gpsx::k_" in r["Name"])]
     top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
     full_name, kernel = top["Name"], short_name(top["Name"])
-    summary = {"tag": tag, "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tracking $BENCH_ARGS (one "
-                                       "rocprofv3 --pmc pass per counter group, --kernel-trace only); kernel trace: --steps 20",
+    summary = {"tag": tag, "command": "kernel trace: rocprofv3 --kernel-trace --stats -- python bench.py $TRACE_ARGS (default: the driver's "
+                                       "own --steps 50 --warmup 5) --no-cpu-baseline --no-tracking --no-pcie --no-native $BENCH_ARGS; counters: "
+                                       "the same with --steps 3 --warmup 1, one rocprofv3 --pmc pass per counter group, --kernel-trace only",
                "kernel": kernel, "kernel_full_name": full_name, "searches_per_launch": searches, "n_ms": n_ms,
                "kernel_trace_avg_ns": float(top["AverageNs"]), "kernel_trace_calls": int(top["Calls"]),
                "kernel_trace_min_ns": float(top["MinNs"]), "kernel_trace_max_ns": float(top["MaxNs"]),
@@ -78,6 +79,13 @@ def main(tag="r02", searches=256, n_ms=1, pattern=None):
         summary["hbm_traffic"] = {"hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_corrected": fetch_b,
                                   "write_bytes": write_b, "fetch_kib_raw": c["FETCH_SIZE"], "write_kib_raw": c["WRITE_SIZE"]}
         entry["hbm_bytes_per_launch"] = fetch_b + write_b
+    # the kernel trace's own figures: what bench.py's roofline.frac is computed from (mean launch of THIS csv)
+    entry["kernel_trace_avg_ns"] = summary["kernel_trace_avg_ns"]
+    entry["kernel_trace_calls"] = summary["kernel_trace_calls"]
+    entry["trace_source"] = f"profiles/{tag}_kernel_stats.csv"
+    for k in ("kernel_trace_median_ns", "kernel_trace_min_ns", "kernel_trace_max_ns"):
+        if k in summary:
+            entry[k] = summary[k]
     if "SQ_INSTS_VALU" in c:
         entry["SQ_INSTS_VALU"] = c["SQ_INSTS_VALU"]
         hyp = searches * n_ms * 32 * 21 * 16368
