@@ -80,6 +80,8 @@ def load_library(lab: bool | None = None) -> C.CDLL:
     if lab is None:
         lab = os.environ.get("GPSX_USE_LAB_LIBRARY") == "1"
     path = LAB_LIB_PATH if lab else LIB_PATH
+    if os.environ.get("GPSX_LIB_PATH") and not lab:
+        path = os.environ["GPSX_LIB_PATH"]      # another build of the product sources, e.g. lib/libgpsx_asan.so (tools/run_sanitizers.sh)
     if not os.path.exists(path):
         raise GpsxError(f"{path} is missing: run `python -m stm32f4_sdr_gps_amd.build` (needs hipcc)")
     lib = C.CDLL(path)

@@ -448,7 +448,10 @@ void sdrobs2obsd(gps_ch_t *channels, int ns, obsd_t *out)
     out[i].P[0] = ch.obs_data.pseudorange_m;
     out[i].L[0] = 0;
     out[i].D[0] = (float)ch.tracking_data.if_freq_offset_hz;
-    out[i].SNR[0] = (unsigned char)((unsigned char)(ch.tracking_data.snr_value + 20.0f) * 4);
+    // the reference converts the float straight to unsigned char (rtklib_common.c:86), which is undefined below 0 -- a channel
+    // whose SNR estimate is under -20 dB (UBSan: -3.69568 on the config-2 trace).  What x86 does with it -- truncate to a 32-bit
+    // integer, keep the low byte -- is written out here, so the byte is the reference's and the conversion is defined
+    out[i].SNR[0] = (unsigned char)((unsigned char)(int)(ch.tracking_data.snr_value + 20.0f) * 4);
     out[i].LLI[0] = 0;
     out[i].code[0] = 1;   // CODE_L1C
   }

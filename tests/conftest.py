@@ -47,6 +47,8 @@ def golden_dir():
 
 @pytest.fixture(scope="session")
 def lib_path():
-    """Path of the built product library (hipcc cross-compiles without a GPU)."""
+    """Path of the built product library (hipcc cross-compiles without a GPU) -- or, under tools/run_sanitizers.sh, of the
+    sanitizer build of the same sources that $GPSX_LIB_PATH names (capi.load_library honours the same variable)."""
     from stm32f4_sdr_gps_amd import build
-    return build.build()
+    built = build.build()
+    return os.environ.get("GPSX_LIB_PATH") or built

@@ -198,7 +198,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import pvt_chain as pc
 from pvt_types import geodetic_to_ecef
 from stm32f4_sdr_gps_amd import build
-lib = C.CDLL(build.build())
+lib = C.CDLL(os.environ.get("GPSX_LIB_PATH") or build.build())
 lib.gps_tracking_words_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
 rx = geodetic_to_ecef(48.1374, 11.5755, 520.0)
 n, K, n_ms = 40, 20, 54000
