@@ -24,7 +24,10 @@
 extern "C" {
 #endif
 
-#define GPSX_VERSION            100        /* 0.1.0 */
+#define GPSX_VERSION            110        /* 0.1.1: gpsx_loop_state_t is 120 bytes (96 up to 0.1.0), flag bit 7 = "served" is new and
+                                            * gps_tracking_words_batch skips flag bytes without it, the product library reads no
+                                            * $GPSX_ACQ_* / $GPSX_TRACK_WAVE_FROM knobs (lib/libgpsx_lab.so does).  A host built against an
+                                            * older header must not run on this library: call gpsx_abi_check once at start-up. */
 #define GPSX_BYTES_PER_MS       2046       /* PM/config.h:26-27: 16368 one-bit samples                    */
 #define GPSX_PHASES_BYTE        2046       /* code-phase hypotheses at byte (0.5 chip) granularity         */
 #define GPSX_PHASES_FINE        16368      /* byte offset x 8 replica bit shifts (PM/GPS/tracking.c:23)    */
@@ -82,6 +85,11 @@ const char *gpsx_strerror(int code);
 /* name of the dominant kernel the last gpsx_acq_grid* call launched (which form of the grid kernel the size picked) */
 const char *gpsx_last_kernel(const gpsx_ctx *ctx);
 int         gpsx_version(void);
+/* The ABI handshake: pass the header's GPSX_VERSION and the sizes the host was COMPILED with,
+ *   gpsx_abi_check(GPSX_VERSION, sizeof(gpsx_loop_state_t), sizeof(gpsx_acq_grid_t), sizeof(gpsx_peak_t))
+ * GPSX_OK when the library was built from the same layout; GPSX_EINVAL when not (a host that strides d_state by another
+ * sizeof(gpsx_loop_state_t) would corrupt device memory without any error).  Needs no context. */
+int         gpsx_abi_check(int header_version, size_t sizeof_loop_state, size_t sizeof_acq_grid, size_t sizeof_peak);
 /* name / CU count / clock of the device behind the context (for bench reports) */
 int         gpsx_device_info(const gpsx_ctx *ctx, char *name, size_t name_len, int *compute_units, int *clock_khz);
 
@@ -420,7 +428,10 @@ int gpsx_loop_set_schedule(gpsx_ctx *ctx, int schedule);
  *       jumps (tests/test_gpu_track_loop.py: the 64-channel trace with its 21 jumps).  A launch whose channels want to jump is
  *       run twice for those channels (they report, the host draws, they are replayed from the launch's input state); launches
  *       are limited to 320 ms and gpsx_track_loop_dev WAITS for its kernels in this mode.  rand() is process-global: the
- *       caller seeds it (and see INTEGRATION.md on the ROCm runtime's own draws when code objects load). */
+ *       caller seeds it (and see INTEGRATION.md on the ROCm runtime's own draws when code objects load).
+ *       A channel has ONE candidate slot per launch (its detector needs 324 ms to fill again, a launch is at most 320): should
+ *       a replay not settle in four passes, or a channel report twice inside one launch, the call returns GPSX_EIO and
+ *       d_state, flags and trace of that call are UNDEFINED -- restore the states from the caller's copy or drop the channels. */
 #define GPSX_DRAWS_XORSHIFT 0
 #define GPSX_DRAWS_LIBC     1
 int gpsx_loop_set_draws(gpsx_ctx *ctx, int draws);

@@ -345,7 +345,10 @@ void gpsx_loop_state_to_channel(const gpsx_loop_state_t *in, gps_ch_t *ch);
  * (flags [n_blocks][n_ch], first block at tick first_tick) to gps_nav_data_words_detection with each bit's own tick and
  * keeps the records' bit-edge time current (and period_sync_ok_flag as of the channel's last completed bit or located edge:
  * the bit synchroniser itself lives on the device); returns how many channels changed their inv_polarity_flag (listed in
- * changed_opt up to max_changed -- hand them to gpsx_loop_set_polarity).  Host code. */
+ * changed_opt up to max_changed -- hand them to gpsx_loop_set_polarity).  Host code.
+ * ONLY flag bytes with bit 7 ("served": the schedule gave this channel this millisecond, set by gpsx_track_loop from library
+ * version 110 on) are looked at; a flag buffer from an older producer, without bit 7, is skipped byte for byte -- check
+ * gpsx_abi_check / gpsx_version when flags and word layer may come from different builds. */
 int gps_tracking_words_batch(gps_ch_t *channel, int n_ch, const uint8_t *flags, int n_blocks, uint32_t first_tick,
                              int *changed_opt, int max_changed);
 

@@ -103,6 +103,16 @@ extern "C" {
 
 int gpsx_version(void) { return GPSX_VERSION; }
 
+int gpsx_abi_check(int header_version, size_t sizeof_loop_state, size_t sizeof_acq_grid, size_t sizeof_peak)
+{
+  // same minor series and the same record sizes: what a host strides device arrays and descriptor tables by
+  if (header_version / 10 != GPSX_VERSION / 10)
+    return GPSX_EINVAL;
+  if (sizeof_loop_state != sizeof(gpsx_loop_state_t) || sizeof_acq_grid != sizeof(gpsx_acq_grid_t) || sizeof_peak != sizeof(gpsx_peak_t))
+    return GPSX_EINVAL;
+  return GPSX_OK;
+}
+
 const char *gpsx_strerror(int code)
 {
   switch (code) {
@@ -238,8 +248,10 @@ void gpsx_destroy(gpsx_ctx *ctx)
   }
   if (ctx->h_bad_prn)
     (void)hipHostFree(ctx->h_bad_prn);
-  if (ctx->h_loop_n_events)
-    (void)hipHostFree(ctx->h_loop_n_events);
+  if (ctx->d_loop_n_events)
+    (void)hipFree(ctx->d_loop_n_events);
+  if (ctx->d_loop_cand)
+    (void)hipFree(ctx->d_loop_cand);
   if (ctx->d_weighted_prns) (void)hipFree(ctx->d_weighted_prns);
   if (ctx->d_loop_reseeds) (void)hipFree(ctx->d_loop_reseeds);
   if (ctx->d_loop_events) (void)hipFree(ctx->d_loop_events);
@@ -1222,31 +1234,37 @@ int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_b
     if (ctx->d_loop_reseeds) (void)hipFree(ctx->d_loop_reseeds);
     if (ctx->d_loop_events) (void)hipFree(ctx->d_loop_events);
     if (ctx->d_loop_chmap) (void)hipFree(ctx->d_loop_chmap);
-    ctx->d_loop_reseeds = nullptr; ctx->d_loop_events = nullptr; ctx->d_loop_chmap = nullptr;
+    if (ctx->d_loop_cand) (void)hipFree(ctx->d_loop_cand);
+    ctx->d_loop_reseeds = nullptr; ctx->d_loop_events = nullptr; ctx->d_loop_chmap = nullptr; ctx->d_loop_cand = nullptr;
     ctx->loop_draws_capacity = 0;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_reseeds, (size_t)n_ch * sizeof(gpsx_loop_reseed_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_events, (size_t)n_ch * sizeof(gpsx_loop_event_t)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_chmap, (size_t)n_ch * sizeof(int)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_cand, (size_t)n_ch * sizeof(gpsx_loop_reseed_t)));
     ctx->loop_draws_capacity = n_ch;
   }
-  if (!ctx->h_loop_n_events) {
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_loop_n_events, sizeof(uint32_t), hipHostMallocMapped));
-    HIPCHK(ctx, hipHostGetDevicePointer((void **)&ctx->d_loop_n_events, ctx->h_loop_n_events, 0));
-  }
+  // the event counter lives in DEVICE memory (the kernel bumps it with an ordinary device atomic: nothing here depends on PCIe
+  // atomics or on fine-grained coherence of host-mapped pages) and comes back with one small copy per pass
+  if (!ctx->d_loop_n_events)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_loop_n_events, sizeof(uint32_t)));
   HIPCHK(ctx, hipMemsetAsync(ctx->d_loop_reseeds, 0xFF, (size_t)n_ch * sizeof(gpsx_loop_reseed_t), ctx->stream));   // ms = -1: none
-  *ctx->h_loop_n_events = 0;
+  HIPCHK(ctx, hipMemsetAsync(ctx->d_loop_n_events, 0, sizeof(uint32_t), ctx->stream));
   launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick,
                     ctx->loop_schedule, word_sync, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, d_bad_prn, nullptr, 0,
                     ctx->d_loop_reseeds, ctx->d_loop_events, ctx->d_loop_n_events);
   LAUNCHCHK(ctx, "k_track_loop");
+  uint32_t n = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_loop_n_events, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<gpsx_loop_event_t> ev;
   std::vector<gpsx_loop_reseed_t> cand;
   std::vector<int> chans;
-  for (int pass = 0; *ctx->h_loop_n_events; pass++) {
-    const uint32_t n = *ctx->h_loop_n_events;
+  std::vector<int> jumped;      // channels that already hold a candidate in this call, sorted
+  for (int pass = 0; n; pass++) {
+    // After GPSX_EIO the states, flags and traces of this call are UNDEFINED (a replay pass may have run on part of the
+    // channels): the caller restores d_state from its own copy or drops the channels (include/gpsx.h).
     if (pass >= 4 || n > (uint32_t)n_ch)
-      return fail(ctx, GPSX_EIO, "GPSX_DRAWS_LIBC: the false-lock replay does not settle");
+      return fail(ctx, GPSX_EIO, "GPSX_DRAWS_LIBC: the false-lock replay does not settle (states of this call are undefined)");
     ev.resize(n);
     HIPCHK(ctx, hipMemcpyAsync(ev.data(), ctx->d_loop_events, n * sizeof(gpsx_loop_event_t), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1255,8 +1273,14 @@ int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_b
     });
     cand.resize(n);
     chans.resize(n);
-
     for (uint32_t i = 0; i < n; i++) {
+      // ONE reseed slot per channel and launch: a channel's false-lock counter needs 81 four-millisecond groups to fill again,
+      // and a launch is at most 320 ms (checked above) -- a second report of one channel inside a call breaks that invariant
+      // and would overwrite the first candidate, so it is refused rather than replayed wrongly
+      const auto at = std::lower_bound(jumped.begin(), jumped.end(), (int)ev[i].channel);
+      if (at != jumped.end() && *at == (int)ev[i].channel)
+        return fail(ctx, GPSX_EIO, "GPSX_DRAWS_LIBC: a channel reported a second false-lock jump inside one launch (states of this call are undefined)");
+      jumped.insert(at, (int)ev[i].channel);
       int16_t delta, candidate;
       do {   // tracking.c:313-324, its types
         const uint16_t r = (uint16_t)(std::rand() % 500);   // ACQ_SEARCH_STEP_HZ
@@ -1265,17 +1289,18 @@ int run_track_loop(gpsx_ctx *ctx, const uint8_t *d_if, size_t blk_bytes, int n_b
       } while (std::abs((int)delta) < 200);
       cand[i] = gpsx_loop_reseed_t{ev[i].ms, candidate, ev[i].ms_from};
       chans[i] = ev[i].channel;
-      HIPCHK(ctx, hipMemcpyAsync(ctx->d_loop_reseeds + ev[i].channel, &cand[i], sizeof(gpsx_loop_reseed_t), hipMemcpyHostToDevice,
-                                 ctx->stream));
     }
+    // the pass's candidates and channel list in two uploads, scattered to the channels' slots on the device
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_loop_cand, cand.data(), n * sizeof(gpsx_loop_reseed_t), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_loop_chmap, chans.data(), n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *ctx->h_loop_n_events = 0;
+    launch_loop_scatter_reseeds(ctx->stream, ctx->d_loop_reseeds, ctx->d_loop_chmap, ctx->d_loop_cand, (int)n);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_loop_n_events, 0, sizeof(uint32_t), ctx->stream));
     launch_track_loop(ctx->stream, d_if, (uint32_t)blk_bytes, n_blocks, ctx->if_format, ctx->if_hz, d_state, n_ch, first_tick,
                       ctx->loop_schedule, word_sync, ctx->d_bits_all, ctx->d_trk_rep, d_flags, d_trace, d_bad_prn, ctx->d_loop_chmap,
                       (int)n, ctx->d_loop_reseeds, ctx->d_loop_events, ctx->d_loop_n_events);
     LAUNCHCHK(ctx, "k_track_loop");
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_loop_n_events, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (cand / chans stay alive until here: the uploads above have completed)
   }
   return GPSX_OK;
 }

@@ -58,7 +58,8 @@ struct gpsx_ctx {
   gpsx::gpsx_loop_event_t *d_loop_events = nullptr;
   int *d_loop_chmap = nullptr;
   int loop_draws_capacity = 0;
-  uint32_t *h_loop_n_events = nullptr, *d_loop_n_events = nullptr;
+  uint32_t *d_loop_n_events = nullptr;          // the kernel's event counter: DEVICE memory (copied back with the event list)
+  gpsx::gpsx_loop_reseed_t *d_loop_cand = nullptr;    // the candidates of one replay pass, uploaded in one piece
   int if_hz = GPSX_IF_HZ;             // gpsx_config_t.if_hz
   int algo = gpsx::kAlgoMx;                // $GPSX_ACQ_ALGO = mx (default: the matrix-core kernel, at every launch size) | poly |
                                            // dot8 | sad, for A/B measurements and the parity tests of the alternative kernels

@@ -152,6 +152,7 @@ void launch_acq_mxw(hipStream_t s, const uint8_t *d_if_blocks, int n_search, int
 //  millisecond of the slot it stopped in: its earlier slots of the launch were stored when they ended -- the replay starts there)
 struct gpsx_loop_event_t { int32_t channel, ms, if_freq_i16, found_freq_hz, ms_from; };
 struct gpsx_loop_reseed_t { int32_t ms, candidate, ms_from; };   // ms < 0: none
+void launch_loop_scatter_reseeds(hipStream_t s, gpsx_loop_reseed_t *d_table, const int *d_channels, const gpsx_loop_reseed_t *d_cand, int n);
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, int word_sync,
                        const uint32_t *d_chipbits, const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace,

@@ -4,6 +4,9 @@
 // s_atanf.c / e_atan2f.c: argument reduction to four intervals, an 11-term odd polynomial in float arithmetic); it is
 // faithfully, not correctly, rounded -- 4.8 % of the quotients I/Q the loops feed it come out one ulp away from the
 // correctly rounded value -- so a device loop that wants the reference's bits has to do the reference's float operations.
+// The HOST mode's loops (csrc/gpsx_steps.cpp) call these as well, not the installed libm: glibc 2.41 and later ship correctly
+// rounded CORE-MATH arctangents, and a host on such a glibc would otherwise leave the reference build's (and the device loops')
+// trajectory at the ulp level.  The bits in question are therefore those of the reference as built on glibc <= 2.40.
 // Restated from the published algorithm; tests/test_libm_restatement.py compiles this header for the host and compares it
 // with the C library bit for bit (every 7th float for atanf, a grid of integer pairs for atan2f).  Float arithmetic only,
 // no contraction (the whole library is built with -ffp-contract=off), correctly rounded division.
@@ -16,6 +19,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define GPSX_HD __host__ __device__ __forceinline__
 #else
 #include <math.h>

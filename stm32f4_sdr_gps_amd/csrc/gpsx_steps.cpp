@@ -24,6 +24,7 @@
 
 #include "../../include/gpsx_compat.h"
 #include "gpsx_compat_internal.hpp"
+#include "gpsx_libm.hpp"   // the reference build's float arctangents (glibc <= 2.40 = fdlibm), whatever libm this host has
 
 namespace {
 
@@ -525,7 +526,7 @@ void pll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP)
     return;
   float phase_err;   // in units of pi
   if (IP > 0)
-    phase_err = (float)((double)atan2f((float)QP, (float)IP) / kPi);
+    phase_err = (float)((double)gpsx_libm::atan2f_fdlibm((float)QP, (float)IP) / kPi);
   else  // the reference calls the double-precision atan2 here (tracking.c:184)
     phase_err = (float)(atan2((double)(float)-QP, (double)(float)-IP) / kPi);
   float step = phase_err - t.pll_code_err;
@@ -607,12 +608,12 @@ void fll_update(gps_ch_t &ch, uint8_t index, int16_t IP, int16_t QP, SlotState *
     return;
   }
   const int16_t oldI = t.fll_old_i, oldQ = t.fll_old_q;
-  const float now = (IP == 0) ? (float)(kPi / 2) : atanf((float)QP / (float)IP);
+  const float now = (IP == 0) ? (float)(kPi / 2) : gpsx_libm::atanf_fdlibm((float)QP / (float)IP);
   float before;
   if (slot && slot->fll_now_valid && slot->fll_now_i == oldI && slot->fll_now_q == oldQ)
     before = slot->fll_now;
   else
-    before = (oldI == 0) ? (float)(kPi / 2) : atanf((float)oldQ / (float)oldI);
+    before = (oldI == 0) ? (float)(kPi / 2) : gpsx_libm::atanf_fdlibm((float)oldQ / (float)oldI);
   if (slot) {
     slot->fll_now = now;
     slot->fll_now_i = IP;

@@ -224,13 +224,11 @@ int launch_acq_weighted(hipStream_t s, const uint8_t *d_if_blocks, int n_search,
                         const uint8_t *d_chips_all, const uint8_t *d_prns, int if_hz, int dopp_min_hz, int dopp_step_hz, int n_dopp,
                         int use_magnitude, gpsx_peak_t *d_peaks)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_acq_weighted), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(WShared)) != hipSuccess)
-      return -1;
-    attr_set = true;
-  }
+  // the attribute belongs to the CURRENT device's copy of the function: set before every launch (a table write in the runtime, no
+  // device work) -- a process-wide "done" flag would leave the second device of a group without it, and would be a data race
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_acq_weighted), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sizeof(WShared)) != hipSuccess)
+    return -1;
   const int n_groups = (n_prn + kWG - 1) / kWG;
   hipLaunchKernelGGL(k_acq_weighted, dim3((unsigned)(n_search * n_dopp * n_groups)), dim3(kWThreads), sizeof(WShared), s, d_if_blocks,
                      stride_blocks, n_prn, d_chips_all, d_prns, if_hz, dopp_min_hz, dopp_step_hz, n_dopp, use_magnitude, d_peaks);

@@ -693,6 +693,21 @@ void launch_loop_set_polarity(hipStream_t s, gpsx_loop_state_t *d_st, const int 
     hipLaunchKernelGGL(k_loop_set_polarity, dim3((n + 255) / 256), dim3(256), 0, s, d_st, d_channels, d_values, n);
 }
 
+// GPSX_DRAWS_LIBC: the host's candidates for the channels that reported a false lock, one upload, scattered to their slots
+__global__ void k_loop_scatter_reseeds(gpsx_loop_reseed_t *__restrict__ table, const int *__restrict__ channels,
+                                       const gpsx_loop_reseed_t *__restrict__ cand, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    table[channels[i]] = cand[i];
+}
+
+void launch_loop_scatter_reseeds(hipStream_t s, gpsx_loop_reseed_t *d_table, const int *d_channels, const gpsx_loop_reseed_t *d_cand, int n)
+{
+  if (n > 0)
+    hipLaunchKernelGGL(k_loop_scatter_reseeds, dim3((n + 255) / 256), dim3(256), 0, s, d_table, d_channels, d_cand, n);
+}
+
 void launch_track_loop(hipStream_t s, const uint8_t *d_if_blocks, uint32_t block_stride, int n_blocks, int if_format, int if_hz,
                        gpsx_loop_state_t *d_st, int n_ch, uint32_t first_tick, int schedule, int word_sync,
                        const uint32_t *d_chipbits, const uint32_t *d_trk_rep, uint8_t *d_flags, gpsx_loop_trace_t *d_trace,

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 FS_HZ = 16_368_000
@@ -73,17 +75,39 @@ def read_if_file(path: str, two_bit: bool = False, max_ms: int | None = None) ->
     return raw[:n * per_ms].reshape(n, per_ms)
 
 
+def _n_threads() -> int:
+    return max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def _ms_chunks(n_ms: int, batch: int):
+    return [(m0, min(n_ms, m0 + batch)) for m0 in range(0, n_ms, batch)]
+
+
+def noise_generator(seed: int, first_sample: int) -> np.random.Generator:
+    """The stream's noise generator positioned at sample `first_sample`: PCG64(seed) advanced by one draw per sample (a float64
+    uniform consumes exactly one 64-bit output), so that any millisecond range can be synthesised on its own -- by any thread --
+    and comes out sample-identical to a sequential run from millisecond 0."""
+    bg = np.random.PCG64(seed)
+    if first_sample:
+        bg.advance(first_sample)
+    return np.random.Generator(bg)
+
+
 def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, start_ms: int = 0,
             two_bit: bool = False, mag_threshold: float = 0.6) -> np.ndarray:
     """Return uint8 array [n_ms, 2046] of packed 1-bit samples, or [n_ms, 4092] of sign/magnitude pairs if two_bit
-    (magnitude bit = |x| > mag_threshold)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+    (magnitude bit = |x| > mag_threshold).  Synthesised in batches of 8 ms on the cores this process may use; the samples do not
+    depend on the batching or the thread count (elementwise float64 arithmetic, noise by position: noise_generator)."""
     out = np.zeros((n_ms, 4092 if two_bit else BYTES_PER_MS), np.uint8)
     codes = {s.prn: (1.0 - 2.0 * ca_code(s.prn).astype(np.float64)) for s in sats}
     n0 = np.arange(SAMPLES_PER_MS, dtype=np.float64)
-    for ms in range(n_ms):
-        n = n0 + float((start_ms + ms) * SAMPLES_PER_MS)
-        x = rng.uniform(-noise_amp, noise_amp, SAMPLES_PER_MS) if noise_amp > 0 else np.zeros(SAMPLES_PER_MS)
+
+    def chunk(rng_):
+        m0, m1 = rng_
+        rng = noise_generator(seed, m0 * SAMPLES_PER_MS)
+        base = np.array([float((start_ms + ms) * SAMPLES_PER_MS) for ms in range(m0, m1)])
+        n = n0[None, :] + base[:, None]
+        x = rng.uniform(-noise_amp, noise_amp, n.shape) if noise_amp > 0 else np.zeros(n.shape)
         for s in sats:
             chip = np.floor((n - s.delay_samples) / 16.0).astype(np.int64) % CHIPS
             d = 1.0
@@ -94,9 +118,21 @@ def make_if(n_ms: int, sats: list[Sat], noise_amp: float = 1.0, seed: int = 7, s
             x = x + s.amp * d * codes[s.prn][chip] * np.cos(ph)
         bits = (x >= 0).astype(np.uint8)
         if two_bit:
-            out[ms] = pack_2bit(bits, (np.abs(x) > mag_threshold).astype(np.uint8))
+            mag = (np.abs(x) > mag_threshold).astype(np.uint8)
+            for i in range(m1 - m0):
+                out[m0 + i] = pack_2bit(bits[i], mag[i])
         else:
-            out[ms] = np.packbits(bits, bitorder="little")
+            out[m0:m1] = np.packbits(bits, axis=1, bitorder="little")
+
+    chunks = _ms_chunks(n_ms, 8)
+    threads = _n_threads()
+    if threads == 1 or len(chunks) == 1:
+        for c in chunks:
+            chunk(c)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(chunk, chunks))
     return out
 
 
@@ -217,17 +253,27 @@ def lnav_bits(n_bits: int, first_bit: int, seed: int) -> np.ndarray:
     return np.array(bits[first_bit:first_bit + n_bits], np.uint8)
 
 
+_lnav_streams: dict = {}
+
+
 def four_sv_with_lnav(n_ms: int, seed: int = 7) -> np.ndarray:
     """The 4-SV table carrying parity-correct LNAV subframes (different payload and subframe timing per satellite;
     satellites 2 and 4 with the opposite data polarity), for the word layer: preamble search, parity, polarity
-    detection, subframe assembly and time stamp."""
+    detection, subframe assembly and time stamp.  The last stream made is kept (read-only): the GPU suite asks for the
+    same 15 s several times."""
+    if (n_ms, seed) in _lnav_streams:
+        return _lnav_streams[(n_ms, seed)]
     n_bits = n_ms // 20 + 2
     first = (37, 161, 250, 96)
     flip = (0, 1, 0, 1)
     bits = [(1.0 - 2.0 * (lnav_bits(n_bits, first[k], seed + 2000 + k) ^ flip[k]).astype(np.float64)) for k in range(4)]
     sats = [Sat(5, 912.5, 1600.0, 0.6, 0.3, bits[0]), Sat(14, 4037.0, 4000.0, 0.6, 1.1, bits[1]),
             Sat(20, -1025.0, 9000.0, 0.6, 2.5, bits[2]), Sat(30, 2018.0, 13000.0, 0.6, 4.0, bits[3])]
-    return make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+    stream = make_if(n_ms, sats, noise_amp=1.0, seed=seed)
+    stream.setflags(write=False)
+    _lnav_streams.clear()
+    _lnav_streams[(n_ms, seed)] = stream
+    return stream
 
 
 def cold_start_block(n_ms: int = 1, seed: int = 11, amp_scale: float = 1.0, two_bit: bool = False) -> np.ndarray:

@@ -26,8 +26,15 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def oracle():
+    """The CPU oracle.  Its LARGE grid sweeps (ten-block searches, multi-search batches: tens of seconds of CPU each, 300 s of
+    the GPU suite in round 5) are answered from tests/golden/f11_grids/ -- this oracle's own outputs for exactly those input
+    bytes, generated in the build container (oracle/gen_golden_grids.py) -- unless the call says live=True or
+    $GPSX_ORACLE_LIVE=1; everything smaller is computed live, so every kernel form keeps live-oracle cases."""
     from oracle import pyoracle
-    return pyoracle.Oracle()
+    orc = pyoracle.Oracle()
+    if os.environ.get("GPSX_ORACLE_LIVE") != "1":
+        orc.grid_fixtures = os.path.join(ROOT, "tests", "golden", "f11_grids")
+    return orc
 
 
 @pytest.fixture(scope="session")

@@ -224,7 +224,6 @@ def make_if_from_orbits(n_ms, sats, rx, tow0, amp=0.6, noise_amp=1.0, seed=7, na
     satellites).  Also returns per satellite the Doppler (Hz) and code delay (samples into a block) at the first block."""
     from stm32f4_sdr_gps_amd import synth
     assert tow0 % 6 == 0
-    rng = np.random.Generator(np.random.PCG64(seed))
     t_edges = tow0 + np.arange(n_ms + 1) * 1e-3
     per_sat = []
     k0 = int(tow0) // 6 - 1                                   # one subframe earlier: signals in flight at tow0
@@ -238,16 +237,23 @@ def make_if_from_orbits(n_ms, sats, rx, tow0, amp=0.6, noise_amp=1.0, seed=7, na
     t_in_ms = frac * 1e-3
     quarter = (np.arange(synth.SAMPLES_PER_MS) % 4) * 0.25     # IF / fs = 1/4 cycle per sample, exactly
     out = np.zeros((n_ms, synth.BYTES_PER_MS), np.uint8)
-    for m in range(n_ms):
-        x = rng.uniform(-noise_amp, noise_amp, synth.SAMPLES_PER_MS)
+
+    def chunk(m0m1):      # a run of milliseconds as [ms, sample] arrays: the same float64 arithmetic per sample whatever the
+        m0, m1 = m0m1     # chunking (noise by position), large enough operations for the threads to run side by side
+        x = synth.noise_generator(seed, m0 * synth.SAMPLES_PER_MS).uniform(-noise_amp, noise_amp, (m1 - m0, synth.SAMPLES_PER_MS))
+        ms = np.array([m * 1e-3 for m in range(m0, m1)])[:, None]
         for tau, dts, bits, code in per_sat:
-            lag = tau[m] + (tau[m + 1] - tau[m]) * frac - dts[m]       # reception time minus the satellite clock's reading
-            t_sv = (m * 1e-3 + t_in_ms) - lag                          # ... relative to tow0, seconds
+            lag = tau[m0:m1, None] + (tau[m0 + 1:m1 + 1] - tau[m0:m1])[:, None] * frac[None, :] - dts[m0:m1, None]   # reception time minus the satellite clock's reading
+            t_sv = (ms + t_in_ms[None, :]) - lag                       # ... relative to tow0, seconds
             chip = np.floor(np.mod(t_sv, 1e-3) * 1.023e6).astype(np.int64) % synth.CHIPS
             bit = np.floor(t_sv / 0.02).astype(np.int64) + 300        # the stream began one subframe before tow0
-            cyc = quarter - F_L1 * lag
+            cyc = quarter[None, :] - F_L1 * lag
             x = x + amp * bits[bit] * code[chip] * np.cos(2.0 * math.pi * (cyc - np.floor(cyc)))
-        out[m] = np.packbits(x >= 0, bitorder="little")
+        out[m0:m1] = np.packbits(x >= 0, axis=1, bitorder="little")
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(synth._n_threads()) as ex:
+        list(ex.map(chunk, synth._ms_chunks(n_ms, 8)))
     first = []
     for tau, dts, _, _ in per_sat:
         doppler = -F_L1 * ((tau[1] - dts[1]) - (tau[0] - dts[0])) / 1e-3

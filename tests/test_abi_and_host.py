@@ -274,3 +274,25 @@ def test_product_and_lab_builds_and_no_register_spills(lib_path):
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DGPSX_MX_NO_PIECES", src],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "GPSX_LAB" in r.stderr
+
+
+def test_abi_handshake_accepts_this_header_and_refuses_another_layout(lib_path):
+    """gpsx_abi_check (include/gpsx.h): the header's version and record sizes a host was compiled with against the library's.
+    The sizes come from a C probe compiled against include/gpsx.h here; 96 bytes was gpsx_loop_state_t up to version 100."""
+    import re
+    import tempfile
+    lib = ctypes.CDLL(lib_path)
+    lib.gpsx_abi_check.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t]
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "probe.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include "gpsx.h"\nint main(void){printf("%d %zu %zu %zu\\n", GPSX_VERSION, '
+                    'sizeof(gpsx_loop_state_t), sizeof(gpsx_acq_grid_t), sizeof(gpsx_peak_t));return 0;}\n')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(tmp, "probe")])
+        ver, s_loop, s_grid, s_peak = (int(x) for x in subprocess.check_output([os.path.join(tmp, "probe")], text=True).split())
+    assert ver == lib.gpsx_version() == 110 and s_loop == 120 and s_peak == 16
+    assert int(re.search(r"#define GPSX_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "gpsx.h")).read()).group(1)) == ver
+    assert lib.gpsx_abi_check(ver, s_loop, s_grid, s_peak) == 0
+    assert lib.gpsx_abi_check(100, 96, s_grid, s_peak) == -22          # a host built against the round-4 header
+    assert lib.gpsx_abi_check(ver, 96, s_grid, s_peak) == -22
+    assert lib.gpsx_abi_check(ver, s_loop, s_grid + 8, s_peak) == -22

@@ -282,7 +282,7 @@ def test_acq_grid_full_cold_start_grid_vs_oracle(eng, oracle):
     prns = np.arange(1, 33, dtype=np.uint8)
     peaks, keys = eng.acq_grid(blk, prns, dopp_min_hz=-5000, dopp_step_hz=500, n_dopp=21)
     assert eng.lib.gpsx_last_kernel(eng.h) == b"k_acq_mx<5>"       # a lone capture: 21 clusters as 42 workgroups (split form)
-    want = oracle.acq_grid(blk, 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
+    want = oracle.acq_grid(blk, 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS, live=True)
     for f in ("max_val", "phase", "sum", "avr"):
         assert np.array_equal(peaks[0][f], want[f]), f
     # packed keys: energy and lowest fine phase of the best bit shift
@@ -909,16 +909,18 @@ def _alt_oracle(oracle, stream, case):
         n_ms, stride = kw.get("n_ms", 1), kw.get("search_stride_blocks", kw.get("n_ms", 1))
         start, stop = kw.get("win", (0, 2046))
         pk = np.zeros((kw["n_search"], len(_ALT_PRNS), kw["n_dopp"], 8), capi_peak_dtype())
-        for s_ in range(kw["n_search"]):
-            blocks = stream[s_ * stride:s_ * stride + n_ms]
-            for p, prn in enumerate(_ALT_PRNS):
-                chips = oracle.ca_code(int(prn))
-                for d in range(kw["n_dopp"]):
-                    for b in range(8):
-                        one = oracle.search_job(blocks, n_ms, chips, float(IF_HZ + kw["dopp_min_hz"] + d * kw["dopp_step_hz"]), b,
-                                                start, stop)
-                        one = one[0] if isinstance(one, tuple) else one
-                        pk[s_, p, d, b] = (one["max_val"], one["phase"], one["sum"], one["avr"])
+        from concurrent.futures import ThreadPoolExecutor
+        codes = [oracle.ca_code(int(prn)) for prn in _ALT_PRNS]
+
+        def job(idx):       # one windowed search of the oracle (ctypes releases the GIL: the jobs run on ORC_THREADS cores)
+            s_, p, d, b = idx
+            one = oracle.search_job(stream[s_ * stride:s_ * stride + n_ms], n_ms, codes[p],
+                                    float(IF_HZ + kw["dopp_min_hz"] + d * kw["dopp_step_hz"]), b, start, stop)
+            one = one[0] if isinstance(one, tuple) else one
+            return idx, (one["max_val"], one["phase"], one["sum"], one["avr"])
+        with ThreadPoolExecutor(ORC_THREADS) as ex:
+            for idx, rec in ex.map(job, list(np.ndindex(kw["n_search"], len(_ALT_PRNS), kw["n_dopp"], 8))):
+                pk[idx] = rec
         fine = 8 * pk["phase"].astype(np.int64) + np.arange(8)[None, None, None, :]
         keys = ((pk["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=3)
         _alt_want[case] = (pk, keys)
@@ -1095,8 +1097,8 @@ def test_bench_size_batch_equals_single_capture_launches_and_finds_the_satellite
         for i in (0, 1, 17, 40, 63, 130, 255):
             pk1, keys1 = e.acq_grid(blocks2[i:i + 1], prns, n_search=1, **kw)
             assert np.array_equal(pk1[0], pk[i]) and np.array_equal(keys1[0], keys[i]), i
-        for i in (0, 131, 255):
-            want = oracle.acq_grid(blocks1[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS)
+        for i in (0, 131, 255):     # (capture 131 against the oracle computed live, the other two against its committed fixtures)
+            want = oracle.acq_grid(blocks1[i:i + 1], 1, prns, -5000, 500, 21, 8, n_threads=ORC_THREADS, live=(i == 131))
             for f in ("max_val", "phase", "sum", "avr"):
                 assert np.array_equal(pk[i][f], want[f]), (i, f)
         assert (keys >> 14).min() > 0                              # every (capture, PRN, Doppler) search produced a peak

@@ -6,6 +6,8 @@ rounded logarithm) is allowed its stated 0.3 % of one-ulp differences."""
 import os
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 PROGRAM = r"""
@@ -49,6 +51,15 @@ int main()
 """
 
 
+def _glibc_version():
+    import ctypes
+    f = ctypes.CDLL(None).gnu_get_libc_version
+    f.restype = ctypes.c_char_p
+    return tuple(int(x) for x in f().decode().split(".")[:2])
+
+
+@pytest.mark.skipif(_glibc_version() > (2, 40), reason="glibc 2.41+ ships correctly rounded CORE-MATH atanf / atan2f: the installed "
+                    "libm is no longer the reference build's fdlibm (the library calls its own restatement on host and device)")
 def test_float_arctangents_are_the_c_librarys_bit_for_bit(tmp_path):
     src = tmp_path / "libm_check.cpp"
     src.write_text(PROGRAM)
