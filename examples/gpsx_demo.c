@@ -82,6 +82,11 @@ int main(int argc, char **argv)
       for (int i = 0; i < GPS_SAT_CNT; i++)
         tracking += gps_channels[i].tracking_data.state == GPS_TRACKING_RUN;
       if (tracking == GPS_SAT_CNT) {          /* a cycle starts and every channel tracks: the loops move to the device */
+        /* this host strides d_state by ITS sizeof(gpsx_loop_state_t): refuse a library built from another layout */
+        if (gpsx_abi_check(GPSX_VERSION, sizeof(gpsx_loop_state_t), sizeof(gpsx_acq_grid_t), sizeof(gpsx_peak_t)) != GPSX_OK) {
+          fprintf(stderr, "libgpsx.so (version %d) does not match the header this host was built with (%d)\n", gpsx_version(), GPSX_VERSION);
+          return 1;
+        }
         if (gpsx_create(&gx, 0, NULL) != GPSX_OK || gpsx_malloc(gx, (void **)&d_state, sizeof st) != GPSX_OK ||
             gpsx_loop_set_schedule(gx, GPSX_SCHED_MUX17) != GPSX_OK)
           return 1;
