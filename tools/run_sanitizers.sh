@@ -18,7 +18,7 @@ for KIND in ${SAN_KINDS:-asan ubsan tsan}; do
   rm -f gpurun_out/san_$KIND.report.*
   if [ $KIND = asan ]; then
     PRE="$RT/libclang_rt.asan-x86_64.so"
-    export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=0:log_path=$ROOT/gpurun_out/san_asan.report:protect_shadow_gap=0"
+    export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=0:log_path=$ROOT/gpurun_out/san_asan.report:protect_shadow_gap=0:allocator_may_return_null=1"
   elif [ $KIND = ubsan ]; then
     PRE="$RT/libclang_rt.ubsan_standalone-x86_64.so"
     export UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0:log_path=$ROOT/gpurun_out/san_ubsan.report"
@@ -28,7 +28,10 @@ for KIND in ${SAN_KINDS:-asan ubsan tsan}; do
   fi
   ( echo "== $KIND: $(date -u +%FT%TZ)  library lib/libgpsx_$KIND.so  preload $PRE"
     if [ "$MODE" = gpu ]; then
-      GPSX_LIB_PATH=$ROOT/stm32f4_sdr_gps_amd/lib/libgpsx_$KIND.so LD_PRELOAD=$PRE python -m pytest $CPU_TESTS $GPU_TESTS -q -x -p no:cacheprovider 2>&1 | tail -15
+      # (one test starts a python of its own that dlopens the library WITHOUT the preload: the TSan / ASan runtimes cannot be
+      #  loaded late -- "cannot allocate memory in static TLS block" -- so it is left to the UBSan and plain runs)
+      SKIP=""; [ $KIND != ubsan ] && SKIP="--deselect tests/test_gpu_steps.py::test_batched_step_under_an_overridden_time_source_calls_it_once_from_the_calling_thread"
+      GPSX_LIB_PATH=$ROOT/stm32f4_sdr_gps_amd/lib/libgpsx_$KIND.so LD_PRELOAD=$PRE python -m pytest $CPU_TESTS $GPU_TESTS $SKIP -q -p no:cacheprovider 2>&1 | tail -15
       echo "== $KIND: worker-pool soak (tools/soak_step_pool.py 20000 2048)"
       GPSX_LIB_PATH=$ROOT/stm32f4_sdr_gps_amd/lib/libgpsx_$KIND.so LD_PRELOAD=$PRE timeout 600 python tools/soak_step_pool.py 20000 2048 2>&1 | tail -5
     else
