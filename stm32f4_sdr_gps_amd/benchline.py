@@ -104,8 +104,8 @@ def compact(detail):
             t = {"value": trk.get("value"), "unit": "channels (E/P/L step p99 < 1 ms)"}
             cl = trk.get("closed_loop") if isinstance(trk.get("closed_loop"), dict) else {}
             dl = cl.get("device_loop") if isinstance(cl.get("device_loop"), dict) else {}
-            if cl.get("value") is not None:
-                t["closed_loop_host_mode"] = cl["value"]
+            # (the host-mode ladder -- one host round trip per millisecond on a shared host: a latency reading that moves with
+            #  the other tenants -- stays in the detail file; the line carries the device loop's counts)
             if dl.get("value") is not None:
                 t["device_loop"] = dl["value"]
             if isinstance(dl.get("mux17"), dict) and dl["mux17"].get("value") is not None:

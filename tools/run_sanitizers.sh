@@ -15,10 +15,15 @@ GPU_TESTS="tests/test_gpu_steps.py tests/test_gpu_pvt_chain.py tests/test_gpu_tr
 for KIND in ${SAN_KINDS:-asan ubsan tsan}; do
   make -C stm32f4_sdr_gps_amd/csrc san SAN=$KIND -j4 > gpurun_out/san_${KIND}_build.log 2>&1 || { echo "$KIND: BUILD FAILED"; tail -5 gpurun_out/san_${KIND}_build.log; continue; }
   LOG=gpurun_out/san_$KIND.log
+  if [ $KIND = asan ] && [ "$MODE" = gpu ]; then
+    # ASan cannot share a process with the HIP runtime here: its HSA interceptors abort on the runtime's first pool allocation
+    # (and with allocator_may_return_null the runtime itself segfaults) -- ASan covers the host-only suites (cpu mode)
+    echo "asan: skipped in gpu mode (the ASan runtime's HSA interceptors do not survive this HIP runtime); run the cpu mode"; continue
+  fi
   rm -f gpurun_out/san_$KIND.report.*
   if [ $KIND = asan ]; then
     PRE="$RT/libclang_rt.asan-x86_64.so"
-    export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=0:log_path=$ROOT/gpurun_out/san_asan.report:protect_shadow_gap=0:allocator_may_return_null=1"
+    export ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=0:log_path=$ROOT/gpurun_out/san_asan.report:protect_shadow_gap=0"
   elif [ $KIND = ubsan ]; then
     PRE="$RT/libclang_rt.ubsan_standalone-x86_64.so"
     export UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0:log_path=$ROOT/gpurun_out/san_ubsan.report"
