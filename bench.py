@@ -1085,10 +1085,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
-            "dtype": "u1 samples; MX-FP4 operands, exact f32 accumulation (integers < 2^24)" if is_mx else "u1 (bit planes; u32 popcount accumulators)",
-            "data": f"synthetic (6 SVs, amplitude scale {args.amp_scale}, U(-1,1) noise, seed 11, synth.make_if_static -- the exact-integer "
-                    f"stream model of round 4 on, not sample-identical to the make_if stream of rounds 1-3; "
-                    f"{'4092-byte 2-bit' if two_bit else '2046-byte 1-bit'} blocks)",
+            "dtype": "u1 (MX-FP4 operands, exact f32 accumulation)" if is_mx else "u1 (bit planes, u32 popcount accumulators)",
+            "data": f"synthetic: 6 SVs x {args.amp_scale} amplitude, U(-1,1) noise, seed 11, {'2-bit' if two_bit else '1-bit'} IF",
+            "data_note": "synth.make_if_static -- the exact-integer stream model of round 4 on, not sample-identical to the make_if stream "
+                         f"of rounds 1-3; {'4092-byte 2-bit' if two_bit else '2046-byte 1-bit'} blocks",
             "config": {
                 "workload": ("cold-start acquisition grid: 32 PRN x 21 Doppler (+-5 kHz @ 500 Hz) x 16368 code phases, "
                              f"1 ms coherent, 16.368 Msps {'2-bit sign/magnitude' if two_bit else '1-bit'} IF "
@@ -1100,7 +1100,7 @@ def main():
                 "blocks_per_search": n_ms,
                 "parallelism": f"(search, Doppler, 8-PRN group) units as {world} contiguous runs, one per rank; one "
                                "all-reduce(MAX) of packed peak keys over RCCL" if world > 1 else "single GPU",
-                "inputs": "resident in HBM when the timed region starts; results left in HBM (pcie_inclusive: host to host)",
+                "inputs": "resident in HBM; results left in HBM",
             },
             "roofline": roof,
             **({"roofline_valu": valu} if valu is not None else {}),
