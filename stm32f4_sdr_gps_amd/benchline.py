@@ -64,7 +64,7 @@ def compact(detail):
     roof = d.get("roofline") or {}
     line["roofline"] = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_basis", "frac_live", "frac_profiled_mean",
                                     "kernel", "kernel_ms", "profiled_kernel_ms_mean", "profiled_launches", "traffic",
-                                    "traffic_gbs", "algorithmic_bytes", "traffic_over_algorithmic", "mfma_busy_frac",
+                                    "traffic_gbs", "traffic_frac_of_hbm_peak", "algorithmic_bytes", "traffic_over_algorithmic", "mfma_busy_frac",
                                     "counter_source"))
     for k in ("roofline_valu", "roofline_mfma"):
         if isinstance(d.get(k), dict):
