@@ -523,6 +523,253 @@ def _parity_sample(keys, sign_blocks_of, n_search, n_ms):
             "seconds": time.perf_counter() - t0}
 
 
+def leg_native_grid(B):
+    """The reference's OWN search grid on the same captures (SURVEY.md 8(d) "also report"): 32 PRN x 29 Doppler bins (+-7 kHz at
+    500 Hz, PM/GPS/acquisition.c:285-289) x 2046 byte-granular code phases, replica bit shift 0 -- k_acq_mx<4>."""
+    (args, eng, capi, synth, torch, C, stream, dev, dev_index, prns, n_search, n_ms, two_bit, dev_blocks, d_if, d_peaks, key_bufs, g) = (
+        B.args, B.eng, B.capi, B.synth, B.torch, B.C, B.stream, B.dev, B.dev_index, B.prns, B.n_search, B.n_ms, B.two_bit, B.dev_blocks,
+        B.d_if, B.d_peaks, B.key_bufs, B.g)
+    native = None
+    try:
+        gn = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=-7000, dopp_step_hz=500,
+                           n_dopp=29, phase_mode=capi.PHASES_BYTE)
+        with torch.cuda.stream(stream):
+            native_keys = torch.zeros((n_search, N_PRN, 29), dtype=torch.int64, device=dev)   # (29 bins: its own table)
+            assert d_peaks.numel() * 4 >= n_search * N_PRN * 29 * capi.PEAK_DTYPE.itemsize
+
+            def native_step():
+                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(gn), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
+                                               native_keys.data_ptr(), None, None, None)
+                if rc != 0:
+                    raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
+            for _ in range(3):
+                native_step()
+            torch.cuda.synchronize()
+            n0, n1 = eng.event(), eng.event()
+            eng.record(n0)
+            for _ in range(20):
+                native_step()
+            eng.record(n1)
+            torch.cuda.synchronize()
+            n_ms_launch = eng.elapsed_ms(n0, n1) / 20
+        n_hyp = n_search * N_PRN * 29 * 2046
+        n_flops = 4 * 2 * 2.0 * 32 * 1024 * 1024 * n_search * 29   # four FP4 GEMM passes x 2 streams per (capture, bin)
+        native = {"workload": "32 PRN x 29 Doppler x 2046 byte phases per capture, %d captures per launch" % n_search,
+                  "value": n_hyp / (n_ms_launch * 1e-3), "unit": "hypotheses/s", "ms_per_launch": n_ms_launch,
+                  "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
+                  "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 10000.0,
+                               "achieved": n_flops / (n_ms_launch * 1e-3) / 1e12, "frac": n_flops / (n_ms_launch * 1e-3) / 1e16}}
+    except Exception as exc:   # a secondary leg must not take the headline line with it
+        native = {"error": repr(exc)}
+        print(f"bench.py: native-grid leg failed: {exc!r}", file=sys.stderr, flush=True)
+    return native
+
+
+def leg_ten_block(B):
+    """The N = 1 point of the series `--gpus N` (N > 1) runs: BASELINE.json configs[3], 10 ms non-coherent integration, here on
+    ONE GPU, unsharded, no collective -- what the multi-GPU lines' `value` is to be divided by (N x this), since this script's
+    own N = 1 default is configs[2].  Search s integrates blocks s .. s + 9 of the resident captures (cyclically extended)."""
+    (args, eng, capi, synth, torch, C, stream, dev, dev_index, prns, n_search, n_ms, two_bit, dev_blocks, d_if, d_peaks, key_bufs, g) = (
+        B.args, B.eng, B.capi, B.synth, B.torch, B.C, B.stream, B.dev, B.dev_index, B.prns, B.n_search, B.n_ms, B.two_bit, B.dev_blocks,
+        B.d_if, B.d_peaks, B.key_bufs, B.g)
+    ten_block = None
+    try:
+        with torch.cuda.stream(stream):
+            per_block = dev_blocks.reshape(n_search, -1)
+            d_if10 = torch.from_numpy(np.concatenate([per_block, per_block[:9]]).reshape(-1)).to(dev)
+            g10 = eng.grid_desc(prns, n_search=n_search, n_ms=10, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+                                dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046))
+
+            def ten_step():
+                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g10), d_if10.data_ptr(), n_search + 9, d_peaks.data_ptr(),
+                                               key_bufs[0].data_ptr(), None, None, None)
+                if rc != 0:
+                    raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
+            for _ in range(2):
+                ten_step()
+            torch.cuda.synchronize()
+            t0e, t1e = eng.event(), eng.event()
+            eng.record(t0e)
+            for _ in range(5):
+                ten_step()
+            eng.record(t1e)
+            torch.cuda.synchronize()
+            ten_ms = eng.elapsed_ms(t0e, t1e) / 5
+        ten_block = {"workload": "BASELINE.json configs[3] on one GPU: %d searches x 10 blocks, 32 PRN x 21 Doppler x 16368 phases, "
+                                 "unsharded, no collective" % n_search,
+                     "value": n_search * 10 * HYP_PER_SEARCH / (ten_ms * 1e-3), "unit": "hypotheses/s (per 1 ms block)",
+                     "ms_per_step": ten_ms, "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
+                     "roofline": None, "roofline_mfma": None,
+                     "note": "the N = 1 point of the `--gpus N` series (whose lines are configs[3], weak scaling): divide their "
+                             "`value` by N x this one"}
+        k10 = ten_block["kernel"][len("gpsx::"):]
+        ten_block["roofline"], ten_block["roofline_mfma"] = _walk_roofline(
+            k10, n_search * 10 * HYP_PER_SEARCH, 10, ten_ms, _kernel_counters(k10, n_search, 10))
+    except Exception as exc:   # a secondary leg must not take the headline line with it
+        ten_block = {"error": repr(exc)}
+        print(f"bench.py: ten-block leg failed: {exc!r}", file=sys.stderr, flush=True)
+    return ten_block
+
+
+def leg_letter_compliant(B):
+    """north_star's letter: "wavefront reductions for the I/Q sums, no MFMA".  The default path above is the exact MX-FP4 Toeplitz
+    GEMM on the matrix cores; this leg times the SAME launch (same captures, same grid, same outputs, bit for bit) on the
+    library's vector-ALU form of the grid -- the polyphase popcount kernel, gpsx_set_acq_path(GPSX_ACQ_PATH_VECTOR) --
+    so that both have a driver-timed number in the same line."""
+    (args, eng, capi, synth, torch, C, stream, dev, dev_index, prns, n_search, n_ms, two_bit, dev_blocks, d_if, d_peaks, key_bufs, g) = (
+        B.args, B.eng, B.capi, B.synth, B.torch, B.C, B.stream, B.dev, B.dev_index, B.prns, B.n_search, B.n_ms, B.two_bit, B.dev_blocks,
+        B.d_if, B.d_peaks, B.key_bufs, B.g)
+    letter = None
+    try:
+        eng_v = capi.Engine(dev_index, stream=stream.cuda_stream)
+        eng_v.set_acq_path(capi.ACQ_PATH_VECTOR)
+        if two_bit:
+            eng_v.set_if_format(capi.IF_2BIT_SM)
+        with torch.cuda.stream(stream):
+            v_keys, m_keys = torch.zeros_like(key_bufs[0]), torch.zeros_like(key_bufs[0])
+            rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
+                                           m_keys.data_ptr(), None, None, None)     # the matrix-core path's table, afresh
+            assert rc == 0
+
+            def valu_step():
+                rc = eng_v.lib.gpsx_acq_grid_dev(eng_v.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
+                                                 v_keys.data_ptr(), None, None, None)
+                if rc != 0:
+                    raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng_v.lib.gpsx_last_error(eng_v.h).decode()}")
+            valu_step()
+            torch.cuda.synchronize()
+            v0, v1 = eng_v.event(), eng_v.event()
+            eng_v.record(v0)
+            for _ in range(4):
+                valu_step()
+            eng_v.record(v1)
+            torch.cuda.synchronize()
+            v_ms = eng_v.elapsed_ms(v0, v1) / 4
+            v_kernel = eng_v.lib.gpsx_last_kernel(eng_v.h).decode()
+            same_keys = bool(torch.equal(v_keys, m_keys)) and int(v_keys.min()) > 0
+        eng_v.close()
+        v_rate = n_search * HYP_PER_SEARCH / (v_ms * 1e-3)
+        issued_per_hyp, src, _ = _poly_counters(args.searches, v_kernel)
+        letter = {"workload": "the headline launch (same captures, same grid) on the vector ALU: no MFMA",
+                  "value": v_rate, "unit": "hypotheses/s", "ms_per_launch": v_ms, "kernel": "gpsx::" + v_kernel,
+                  "keys_identical_to_the_matrix_core_path": same_keys,
+                  "roofline_valu": _poly_valu_roofline(issued_per_hyp, v_rate, src)}
+        if not same_keys:
+            raise AssertionError("the vector-ALU path's key table differs from the matrix-core path's")
+    except Exception as exc:   # a secondary leg must not take the headline line with it
+        letter = {"error": repr(exc)}
+        print(f"bench.py: letter-compliant leg failed: {exc!r}", file=sys.stderr, flush=True)
+    return letter
+
+
+def leg_weighted_extension(B):
+    """EXTENSION, not in the reference (include/gpsx.h gpsx_acq_grid_weighted): the same 32 x 21 x 16368 grid on weighted two-bit
+    samples (+-1 / +-3), 64 captures per launch, on the matrix cores (k_acq_mxw) -- and, on the first eight captures, the same
+    records from the vector-ALU kernel (k_acq_weighted); both are pinned to the extension's own oracle in tests/test_gpu_weighted.py"""
+    (args, eng, capi, synth, torch, C, stream, dev, dev_index, prns, n_search, n_ms, two_bit, dev_blocks, d_if, d_peaks, key_bufs, g) = (
+        B.args, B.eng, B.capi, B.synth, B.torch, B.C, B.stream, B.dev, B.dev_index, B.prns, B.n_search, B.n_ms, B.two_bit, B.dev_blocks,
+        B.d_if, B.d_peaks, B.key_bufs, B.g)
+    weighted = None
+    try:
+        w_search = 256
+        w_blocks = synth.cold_start_block(w_search, seed=16, amp_scale=args.amp_scale, two_bit=True)
+        w_prns = np.arange(1, N_PRN + 1, dtype=np.uint8)
+        eng_w = capi.Engine(dev_index, stream=stream.cuda_stream)
+        with torch.cuda.stream(stream):
+            d_w = torch.from_numpy(np.concatenate([w_blocks.reshape(-1), np.zeros(2, np.uint8)])).to(dev)
+            d_wp = torch.zeros((w_search, N_PRN, N_DOPP, 4), dtype=torch.int32, device=dev)
+            d_wv = torch.zeros((8, N_PRN, N_DOPP, 4), dtype=torch.int32, device=dev)
+            gw = capi.AcqWeightedT(w_search, 1, N_PRN, w_prns.ctypes.data_as(C.POINTER(C.c_uint8)), DOPP_MIN, DOPP_STEP, N_DOPP, 1)
+            g8 = capi.AcqWeightedT(8, 1, N_PRN, w_prns.ctypes.data_as(C.POINTER(C.c_uint8)), DOPP_MIN, DOPP_STEP, N_DOPP, 1)
+
+            def w_step(engine, desc, n, out):
+                rc = engine.lib.gpsx_acq_grid_weighted_dev(engine.h, C.byref(desc), d_w.data_ptr(), n, out.data_ptr())
+                if rc != 0:
+                    raise RuntimeError(f"gpsx_acq_grid_weighted_dev -> {rc}: {engine.lib.gpsx_last_error(engine.h).decode()}")
+            w_step(eng_w, gw, w_search, d_wp)
+            w_kernel = eng_w.lib.gpsx_last_kernel(eng_w.h).decode()
+            torch.cuda.synchronize()
+            w0, w1 = eng_w.event(), eng_w.event()
+            eng_w.record(w0)
+            for _ in range(8):
+                w_step(eng_w, gw, w_search, d_wp)
+            eng_w.record(w1)
+            torch.cuda.synchronize()
+            w_ms = eng_w.elapsed_ms(w0, w1) / 8
+            eng_w.set_acq_path(capi.ACQ_PATH_VECTOR)
+            w_step(eng_w, g8, 8, d_wv)
+            v_kernel_w = eng_w.lib.gpsx_last_kernel(eng_w.h).decode()
+            torch.cuda.synchronize()
+            same_records = bool(torch.equal(d_wv, d_wp[:8])) and int(d_wp[..., 0].min()) > 0
+        eng_w.close()
+        w_hyp = w_search * HYP_PER_SEARCH
+        w_flops = w_hyp / 16 * 2 * 18 * 1024 * 2            # 18 MFMA passes per 16 sample offsets, two streams, 1024 chips
+        weighted = {"workload": f"EXTENSION (not in the reference): weighted two-bit (+-1 / +-3) fine grid, {w_search} captures x "
+                                f"{N_PRN} PRN x {N_DOPP} Doppler x 16368 phases per launch, device-resident",
+                    "value": w_hyp / (w_ms * 1e-3), "unit": "hypotheses/s", "ms_per_launch": w_ms, "kernel": "gpsx::" + w_kernel,
+                    "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_FP4_PEAK_TFLOPS,
+                                 "achieved": w_flops / (w_ms * 1e-3) / 1e12, "frac": w_flops / (w_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
+                                 "basis": "MX-FP4 flops as issued; HIP events around 8 launches"},
+                    "records_identical_to": "gpsx::" + v_kernel_w + " (vector ALU) on the first 8 captures",
+                    "records_identical": same_records}
+        if not same_records:
+            raise AssertionError("the weighted grid's matrix-core records differ from the vector-ALU kernel's")
+    except Exception as exc:   # a secondary leg must not take the headline line with it
+        weighted = {"error": repr(exc)}
+        print(f"bench.py: weighted two-bit leg failed: {exc!r}", file=sys.stderr, flush=True)
+    return weighted
+
+
+def leg_pcie_inclusive(B):
+    """PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
+    memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
+    rotation through gpsx_acq_grid_async, so a call's transfers overlap the others' sweeps -- what a host streaming
+    captures through the engine does (tools/pcie_probe.py: 1 / 2 / 3 / 4 contexts = 0.98 / 1.02 / 1.13 / 1.18 x 10^12).  `serial` is the one-context, synchronous gpsx_acq_grid() loop of round 1."""
+    (args, eng, capi, synth, torch, C, stream, dev, dev_index, prns, n_search, n_ms, two_bit, dev_blocks, d_if, d_peaks, key_bufs, g) = (
+        B.args, B.eng, B.capi, B.synth, B.torch, B.C, B.stream, B.dev, B.dev_index, B.prns, B.n_search, B.n_ms, B.two_bit, B.dev_blocks,
+        B.d_if, B.d_peaks, B.key_bufs, B.g)
+    g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+                       dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
+    engs = [capi.Engine(dev_index) for _ in range(4)]           # own non-blocking streams
+    affinity = os.sched_getaffinity(0)
+    engs[0].bind_thread_to_device()      # the feeding thread and the pinned pages it touches first: the GPU's socket
+    pins = []
+    for e2 in engs:
+        if two_bit:
+            e2.set_if_format(capi.IF_2BIT_SM)
+        # torch only provides the pinned pages
+        pin_pk = torch.zeros(n_search * N_PRN * N_DOPP * 8 * capi.PEAK_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+        pin_keys = torch.zeros(n_search * N_PRN * N_DOPP, dtype=torch.int64).pin_memory()
+        pin_if = torch.from_numpy(dev_blocks.reshape(-1).copy()).pin_memory()
+        pins.append((pin_if, pin_pk, pin_keys))
+    reps = 12
+
+    def pcie_loop(n_ctx):
+        warm = max(6, 2 * n_ctx)        # every context's first calls (tables, scratch arena, first DMA into its pinned pages)
+        for i in range(reps + warm):
+            if i == warm:
+                for e2 in engs[:n_ctx]:
+                    e2.synchronize()
+                tp = time.perf_counter()
+            e2 = engs[i % n_ctx]
+            pin_if, pin_pk, pin_keys = pins[i % n_ctx]
+            e2.synchronize()            # the buffers of this context's previous call are the caller's again
+            rc = e2.lib.gpsx_acq_grid_async(e2.h, C.byref(g1), pin_if.data_ptr(), n_search, pin_pk.data_ptr(),
+                                            pin_keys.data_ptr())
+            assert rc == 0, e2.lib.gpsx_last_error(e2.h)
+        for e2 in engs[:n_ctx]:
+            e2.synchronize()
+        return reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
+
+    pcie_serial = pcie_loop(1)
+    pcie = pcie_loop(4)
+    assert all(torch.equal(pins[0][2], p[2]) for p in pins[1:]) and int(pins[0][2].min()) > 0   # every context's key table
+    for e2 in engs:
+        e2.close()
+    os.sched_setaffinity(0, affinity)
+    return pcie, pcie_serial
+
+
 def main():
     t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
@@ -691,187 +938,28 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed_s = float(elapsed.item())
 
-    # The reference's OWN search grid on the same captures (SURVEY.md 8(d) "also report"): 32 PRN x 29 Doppler bins (+-7 kHz at
-    # 500 Hz, PM/GPS/acquisition.c:285-289) x 2046 byte-granular code phases, replica bit shift 0 -- k_acq_mx<4>.
+    # the secondary legs (N = 1 only; each in a function of its own, each catching its own failure: a secondary leg must
+    # not take the headline line with it)
+    import types
+    B = types.SimpleNamespace(args=args, eng=eng, capi=capi, synth=synth, torch=torch, C=C, stream=stream, dev=dev, dev_index=dev_index,
+                              prns=prns, n_search=n_search, n_ms=n_ms, two_bit=two_bit, dev_blocks=dev_blocks, d_if=d_if, d_peaks=d_peaks,
+                              key_bufs=key_bufs, g=g)
     native = None
     if world == 1 and n_ms == 1 and not args.no_native:
-        try:
-            gn = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=-7000, dopp_step_hz=500,
-                               n_dopp=29, phase_mode=capi.PHASES_BYTE)
-            with torch.cuda.stream(stream):
-                native_keys = torch.zeros((n_search, N_PRN, 29), dtype=torch.int64, device=dev)   # (29 bins: its own table)
-                assert d_peaks.numel() * 4 >= n_search * N_PRN * 29 * capi.PEAK_DTYPE.itemsize
+        native = leg_native_grid(B)
 
-                def native_step():
-                    rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(gn), d_if.data_ptr(), n_search, d_peaks.data_ptr(),
-                                                   native_keys.data_ptr(), None, None, None)
-                    if rc != 0:
-                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
-                for _ in range(3):
-                    native_step()
-                torch.cuda.synchronize()
-                n0, n1 = eng.event(), eng.event()
-                eng.record(n0)
-                for _ in range(20):
-                    native_step()
-                eng.record(n1)
-                torch.cuda.synchronize()
-                n_ms_launch = eng.elapsed_ms(n0, n1) / 20
-            n_hyp = n_search * N_PRN * 29 * 2046
-            n_flops = 4 * 2 * 2.0 * 32 * 1024 * 1024 * n_search * 29   # four FP4 GEMM passes x 2 streams per (capture, bin)
-            native = {"workload": "32 PRN x 29 Doppler x 2046 byte phases per capture, %d captures per launch" % n_search,
-                      "value": n_hyp / (n_ms_launch * 1e-3), "unit": "hypotheses/s", "ms_per_launch": n_ms_launch,
-                      "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
-                      "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": 10000.0,
-                                   "achieved": n_flops / (n_ms_launch * 1e-3) / 1e12, "frac": n_flops / (n_ms_launch * 1e-3) / 1e16}}
-        except Exception as exc:   # a secondary leg must not take the headline line with it
-            native = {"error": repr(exc)}
-            print(f"bench.py: native-grid leg failed: {exc!r}", file=sys.stderr, flush=True)
-
-    # The N = 1 point of the series `--gpus N` (N > 1) runs: BASELINE.json configs[3], 10 ms non-coherent integration, here on
-    # ONE GPU, unsharded, no collective -- what the multi-GPU lines' `value` is to be divided by (N x this), since this script's
-    # own N = 1 default is configs[2].  Search s integrates blocks s .. s + 9 of the resident captures (cyclically extended).
     ten_block = None
     if world == 1 and n_ms == 1 and not args.no_native:
-        try:
-            with torch.cuda.stream(stream):
-                per_block = dev_blocks.reshape(n_search, -1)
-                d_if10 = torch.from_numpy(np.concatenate([per_block, per_block[:9]]).reshape(-1)).to(dev)
-                g10 = eng.grid_desc(prns, n_search=n_search, n_ms=10, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
-                                    dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046))
+        ten_block = leg_ten_block(B)
 
-                def ten_step():
-                    rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g10), d_if10.data_ptr(), n_search + 9, d_peaks.data_ptr(),
-                                                   key_bufs[0].data_ptr(), None, None, None)
-                    if rc != 0:
-                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
-                for _ in range(2):
-                    ten_step()
-                torch.cuda.synchronize()
-                t0e, t1e = eng.event(), eng.event()
-                eng.record(t0e)
-                for _ in range(5):
-                    ten_step()
-                eng.record(t1e)
-                torch.cuda.synchronize()
-                ten_ms = eng.elapsed_ms(t0e, t1e) / 5
-            ten_block = {"workload": "BASELINE.json configs[3] on one GPU: %d searches x 10 blocks, 32 PRN x 21 Doppler x 16368 phases, "
-                                     "unsharded, no collective" % n_search,
-                         "value": n_search * 10 * HYP_PER_SEARCH / (ten_ms * 1e-3), "unit": "hypotheses/s (per 1 ms block)",
-                         "ms_per_step": ten_ms, "kernel": "gpsx::" + eng.lib.gpsx_last_kernel(eng.h).decode(),
-                         "roofline": None, "roofline_mfma": None,
-                         "note": "the N = 1 point of the `--gpus N` series (whose lines are configs[3], weak scaling): divide their "
-                                 "`value` by N x this one"}
-            k10 = ten_block["kernel"][len("gpsx::"):]
-            ten_block["roofline"], ten_block["roofline_mfma"] = _walk_roofline(
-                k10, n_search * 10 * HYP_PER_SEARCH, 10, ten_ms, _kernel_counters(k10, n_search, 10))
-        except Exception as exc:   # a secondary leg must not take the headline line with it
-            ten_block = {"error": repr(exc)}
-            print(f"bench.py: ten-block leg failed: {exc!r}", file=sys.stderr, flush=True)
-
-    # north_star's letter: "wavefront reductions for the I/Q sums, no MFMA".  The default path above is the exact MX-FP4 Toeplitz
-    # GEMM on the matrix cores; this leg times the SAME launch (same captures, same grid, same outputs, bit for bit) on the
-    # library's vector-ALU form of the grid -- the polyphase popcount kernel, gpsx_set_acq_path(GPSX_ACQ_PATH_VECTOR) --
-    # so that both have a driver-timed number in the same line.
     letter = None
     if world == 1 and n_ms == 1 and not args.no_native:
-        try:
-            eng_v = capi.Engine(dev_index, stream=stream.cuda_stream)
-            eng_v.set_acq_path(capi.ACQ_PATH_VECTOR)
-            if two_bit:
-                eng_v.set_if_format(capi.IF_2BIT_SM)
-            with torch.cuda.stream(stream):
-                v_keys, m_keys = torch.zeros_like(key_bufs[0]), torch.zeros_like(key_bufs[0])
-                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
-                                               m_keys.data_ptr(), None, None, None)     # the matrix-core path's table, afresh
-                assert rc == 0
+        letter = leg_letter_compliant(B)
 
-                def valu_step():
-                    rc = eng_v.lib.gpsx_acq_grid_dev(eng_v.h, C.byref(g), d_if.data_ptr(), n_search * n_ms, d_peaks.data_ptr(),
-                                                     v_keys.data_ptr(), None, None, None)
-                    if rc != 0:
-                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng_v.lib.gpsx_last_error(eng_v.h).decode()}")
-                valu_step()
-                torch.cuda.synchronize()
-                v0, v1 = eng_v.event(), eng_v.event()
-                eng_v.record(v0)
-                for _ in range(4):
-                    valu_step()
-                eng_v.record(v1)
-                torch.cuda.synchronize()
-                v_ms = eng_v.elapsed_ms(v0, v1) / 4
-                v_kernel = eng_v.lib.gpsx_last_kernel(eng_v.h).decode()
-                same_keys = bool(torch.equal(v_keys, m_keys)) and int(v_keys.min()) > 0
-            eng_v.close()
-            v_rate = n_search * HYP_PER_SEARCH / (v_ms * 1e-3)
-            issued_per_hyp, src, _ = _poly_counters(args.searches, v_kernel)
-            letter = {"workload": "the headline launch (same captures, same grid) on the vector ALU: no MFMA",
-                      "value": v_rate, "unit": "hypotheses/s", "ms_per_launch": v_ms, "kernel": "gpsx::" + v_kernel,
-                      "keys_identical_to_the_matrix_core_path": same_keys,
-                      "roofline_valu": _poly_valu_roofline(issued_per_hyp, v_rate, src)}
-            if not same_keys:
-                raise AssertionError("the vector-ALU path's key table differs from the matrix-core path's")
-        except Exception as exc:   # a secondary leg must not take the headline line with it
-            letter = {"error": repr(exc)}
-            print(f"bench.py: letter-compliant leg failed: {exc!r}", file=sys.stderr, flush=True)
-
-    # EXTENSION, not in the reference (include/gpsx.h gpsx_acq_grid_weighted): the same 32 x 21 x 16368 grid on weighted two-bit
-    # samples (+-1 / +-3), 64 captures per launch, on the matrix cores (k_acq_mxw) -- and, on the first eight captures, the same
-    # records from the vector-ALU kernel (k_acq_weighted); both are pinned to the extension's own oracle in tests/test_gpu_weighted.py
     weighted = None
     if world == 1 and n_ms == 1 and not args.no_native:
-        try:
-            w_search = 256
-            w_blocks = synth.cold_start_block(w_search, seed=16, amp_scale=args.amp_scale, two_bit=True)
-            w_prns = np.arange(1, N_PRN + 1, dtype=np.uint8)
-            eng_w = capi.Engine(dev_index, stream=stream.cuda_stream)
-            with torch.cuda.stream(stream):
-                d_w = torch.from_numpy(np.concatenate([w_blocks.reshape(-1), np.zeros(2, np.uint8)])).to(dev)
-                d_wp = torch.zeros((w_search, N_PRN, N_DOPP, 4), dtype=torch.int32, device=dev)
-                d_wv = torch.zeros((8, N_PRN, N_DOPP, 4), dtype=torch.int32, device=dev)
-                gw = capi.AcqWeightedT(w_search, 1, N_PRN, w_prns.ctypes.data_as(C.POINTER(C.c_uint8)), DOPP_MIN, DOPP_STEP, N_DOPP, 1)
-                g8 = capi.AcqWeightedT(8, 1, N_PRN, w_prns.ctypes.data_as(C.POINTER(C.c_uint8)), DOPP_MIN, DOPP_STEP, N_DOPP, 1)
+        weighted = leg_weighted_extension(B)
 
-                def w_step(engine, desc, n, out):
-                    rc = engine.lib.gpsx_acq_grid_weighted_dev(engine.h, C.byref(desc), d_w.data_ptr(), n, out.data_ptr())
-                    if rc != 0:
-                        raise RuntimeError(f"gpsx_acq_grid_weighted_dev -> {rc}: {engine.lib.gpsx_last_error(engine.h).decode()}")
-                w_step(eng_w, gw, w_search, d_wp)
-                w_kernel = eng_w.lib.gpsx_last_kernel(eng_w.h).decode()
-                torch.cuda.synchronize()
-                w0, w1 = eng_w.event(), eng_w.event()
-                eng_w.record(w0)
-                for _ in range(8):
-                    w_step(eng_w, gw, w_search, d_wp)
-                eng_w.record(w1)
-                torch.cuda.synchronize()
-                w_ms = eng_w.elapsed_ms(w0, w1) / 8
-                eng_w.set_acq_path(capi.ACQ_PATH_VECTOR)
-                w_step(eng_w, g8, 8, d_wv)
-                v_kernel_w = eng_w.lib.gpsx_last_kernel(eng_w.h).decode()
-                torch.cuda.synchronize()
-                same_records = bool(torch.equal(d_wv, d_wp[:8])) and int(d_wp[..., 0].min()) > 0
-            eng_w.close()
-            w_hyp = w_search * HYP_PER_SEARCH
-            w_flops = w_hyp / 16 * 2 * 18 * 1024 * 2            # 18 MFMA passes per 16 sample offsets, two streams, 1024 chips
-            weighted = {"workload": f"EXTENSION (not in the reference): weighted two-bit (+-1 / +-3) fine grid, {w_search} captures x "
-                                    f"{N_PRN} PRN x {N_DOPP} Doppler x 16368 phases per launch, device-resident",
-                        "value": w_hyp / (w_ms * 1e-3), "unit": "hypotheses/s", "ms_per_launch": w_ms, "kernel": "gpsx::" + w_kernel,
-                        "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_FP4_PEAK_TFLOPS,
-                                     "achieved": w_flops / (w_ms * 1e-3) / 1e12, "frac": w_flops / (w_ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TFLOPS,
-                                     "basis": "MX-FP4 flops as issued; HIP events around 8 launches"},
-                        "records_identical_to": "gpsx::" + v_kernel_w + " (vector ALU) on the first 8 captures",
-                        "records_identical": same_records}
-            if not same_records:
-                raise AssertionError("the weighted grid's matrix-core records differ from the vector-ALU kernel's")
-        except Exception as exc:   # a secondary leg must not take the headline line with it
-            weighted = {"error": repr(exc)}
-            print(f"bench.py: weighted two-bit leg failed: {exc!r}", file=sys.stderr, flush=True)
-
-    # PCIe-inclusive rate of the host-buffer entry point, the metric as SURVEY.md 8(d) words it: captures in pinned host
-    # memory -> H2D -> sweep -> D2H of peaks and keys into pinned host memory.  Four contexts (four streams) take the calls in
-    # rotation through gpsx_acq_grid_async, so a call's transfers overlap the others' sweeps -- what a host streaming
-    # captures through the engine does (tools/pcie_probe.py: 1 / 2 / 3 / 4 contexts = 0.98 / 1.02 / 1.13 / 1.18 x 10^12).  `serial` is the one-context, synchronous gpsx_acq_grid() loop of round 1.
     # the secondary metric first: the legs below leave ~100 MB of page-locked host memory and four contexts' worth of
     # state behind, and the tracking step measured after them is 60 us slower
     tracking = None
@@ -882,47 +970,9 @@ def main():
             tracking = {"error": repr(exc)}
             print(f"bench.py: tracking leg failed: {exc!r}", file=sys.stderr, flush=True)
 
-    pcie = None
+    pcie = pcie_serial = None
     if world == 1 and n_ms == 1 and not args.no_pcie:
-        g1 = eng.grid_desc(prns, n_search=n_search, n_ms=1, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
-                           dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE)
-        engs = [capi.Engine(dev_index) for _ in range(4)]           # own non-blocking streams
-        affinity = os.sched_getaffinity(0)
-        engs[0].bind_thread_to_device()      # the feeding thread and the pinned pages it touches first: the GPU's socket
-        pins = []
-        for e2 in engs:
-            if two_bit:
-                e2.set_if_format(capi.IF_2BIT_SM)
-            # torch only provides the pinned pages
-            pin_pk = torch.zeros(n_search * N_PRN * N_DOPP * 8 * capi.PEAK_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-            pin_keys = torch.zeros(n_search * N_PRN * N_DOPP, dtype=torch.int64).pin_memory()
-            pin_if = torch.from_numpy(dev_blocks.reshape(-1).copy()).pin_memory()
-            pins.append((pin_if, pin_pk, pin_keys))
-        reps = 12
-
-        def pcie_loop(n_ctx):
-            warm = max(6, 2 * n_ctx)        # every context's first calls (tables, scratch arena, first DMA into its pinned pages)
-            for i in range(reps + warm):
-                if i == warm:
-                    for e2 in engs[:n_ctx]:
-                        e2.synchronize()
-                    tp = time.perf_counter()
-                e2 = engs[i % n_ctx]
-                pin_if, pin_pk, pin_keys = pins[i % n_ctx]
-                e2.synchronize()            # the buffers of this context's previous call are the caller's again
-                rc = e2.lib.gpsx_acq_grid_async(e2.h, C.byref(g1), pin_if.data_ptr(), n_search, pin_pk.data_ptr(),
-                                                pin_keys.data_ptr())
-                assert rc == 0, e2.lib.gpsx_last_error(e2.h)
-            for e2 in engs[:n_ctx]:
-                e2.synchronize()
-            return reps * n_search * HYP_PER_SEARCH / (time.perf_counter() - tp)
-
-        pcie_serial = pcie_loop(1)
-        pcie = pcie_loop(4)
-        assert all(torch.equal(pins[0][2], p[2]) for p in pins[1:]) and int(pins[0][2].min()) > 0   # every context's key table
-        for e2 in engs:
-            e2.close()
-        os.sched_setaffinity(0, affinity)
+        pcie, pcie_serial = leg_pcie_inclusive(B)
 
     # sanity outside the timed region: the merged key table must hold the six synthetic satellites' peaks
     d_keys = key_bufs[(step_no[0] - 1) & 1]
