@@ -132,3 +132,28 @@ def test_eight_ranks_on_one_device(tmp_path, oracle):
         fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
         assert np.array_equal(keys[s_][np.ix_(prns.astype(int) - 1, [0, 5, 10, 15, 20])],
                               ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)), scaling
+
+
+def test_single_gpu_line_is_compact_strict_and_carries_every_leg(tmp_path):
+    """`python bench.py` as the driver runs it at N = 1 (smaller batch, fewer steps, tracking ladders off): the LAST stdout line is
+    the compact record -- under 4 KB, strict JSON, the contract's keys, `roofline` and `cpu_baseline`, one entry per secondary
+    leg, none of them an error -- and the full record is in bench_detail.json beside the script."""
+    from stm32f4_sdr_gps_amd import benchline
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--searches", "16",
+                          "--no-tracking", "--cpu-budget-s", "2"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    last = [l for l in res.stdout.splitlines() if l.strip()][-1]
+    line = benchline.check(last)                       # size, strict JSON, contract keys, roofline keys
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["config"]["blocks_per_search"] == 1
+    assert line["config"]["hypotheses_per_step"] == 16 * 32 * 21 * 16368 and line["value"] > 1e9
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] <= 1 and line["roofline"]["kernel"].startswith("gpsx::k_acq_mx")
+    assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 1e5 and line["cpu_baseline"]["cores"] == 1
+    assert line["value_pcie_inclusive"] > 1e9
+    for leg in ("native_grid", "configs3_one_gpu", "letter_compliant", "weighted_2bit_extension"):
+        assert "error" not in line[leg] and line[leg]["value"] > 1e9, (leg, line[leg])
+    assert line["configs3_one_gpu"]["bound"] == "hbm" and line["letter_compliant"]["keys_identical_to_the_matrix_core_path"] is True
+    assert line["letter_compliant"]["kernel"].startswith("gpsx::k_acq_poly") and 0 < line["letter_compliant"]["frac"] <= 1
+    detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-5) and "note" in detail["roofline"]
+    assert detail["configs3_one_gpu"]["roofline"]["algorithmic_bytes"] > 0 and detail["pcie_inclusive"]["serial"] > 1e9
