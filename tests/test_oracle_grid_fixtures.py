@@ -7,7 +7,6 @@ import glob
 import os
 
 import numpy as np
-import pytest
 
 from oracle import pyoracle
 
