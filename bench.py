@@ -11,14 +11,17 @@ over a batch of `--searches` independent captures per GPU, inputs already reside
 from and returned to pinned host buffers (SURVEY.md 8(d)'s wording of the metric: H2D + launch + D2H) is reported
 beside it as `pcie_inclusive`.
 
-N > 1 (torchrun, one rank per GPU; BASELINE.json configs[3]): the same grid with 10 ms NON-COHERENT integration
-(--n-ms defaults to 10 there, 1 at N = 1; hypotheses are counted per 1 ms block, SURVEY.md 8(d) "Config 4").  The job
-holds N x searches ten-block searches; the (search, 8-PRN group, Doppler) units -- 84 per search -- are dealt to the
-ranks in contiguous runs of equal length (per-GPU work is constant: weak scaling) and ONE all-reduce(MAX) of the packed
-(energy, phase) key table over RCCL merges the peaks -- the only collective on the path.  `single_search` adds
-configs[3]'s literal shape: ONE ten-block search sharded over the N ranks, latency per search; `per_gpu_unsharded` is
-one GPU's own share at the same configuration without sharding or collective (N x it is what the job's `value` is to be
-held against: the N = 1 default of this script is configs[2], a different workload).
+N > 1 (torchrun, one rank per GPU): the SAME workload -- north_star's "all-PRN cold-start sweep shards the PRN x Doppler hypothesis
+grid across the GPUs of one node with a single RCCL all-reduce".  The job holds N x searches captures; their (search, 8-PRN group,
+Doppler) units -- 84 per search -- are dealt to the ranks in contiguous runs of equal length (per-GPU work is what the N = 1 run
+does: weak scaling from N = 1 on; --scaling strong keeps the job's size instead) and ONE all-reduce(MAX) of the packed (energy,
+phase) key table over RCCL merges the peaks -- the only collective on the path, issued under the next step's kernel.  Beside the
+headline the N > 1 line carries BASELINE.json configs[3] -- the same grid with 10 ms NON-COHERENT integration, sharded and
+all-reduced the same way, `searches` ten-block searches per GPU (`configs3_sharded`; its N = 1 point is the N = 1 line's
+`configs3_one_gpu`; hypotheses are counted per 1 ms block, SURVEY.md 8(d) "Config 4") --, configs[3]'s literal shape, ONE
+ten-block search over the N ranks, as a latency (`single_search`), and `per_gpu_unsharded`, one GPU's own share without sharding
+or collective.  `--n-ms 10` makes configs[3] the headline workload at any N (rounds 1-5 ran N > 1 that way by default: the N = 1
+and N > 1 lines then measured different workloads, and a scaling curve read off them was not one).
 
 Prints one JSON line on rank 0.  `roofline` prices the resource of the kernel that ran (gpsx_last_kernel):
   k_acq_mx<0> (default, n_ms = 1): the correlations are an MX-FP4 GEMM on the matrix cores, operands in LDS, HBM traffic
@@ -785,8 +788,9 @@ def main():
                          "noise like a live antenna; 1.0 is the strong test signal, whose long runs of saturated block sums "
                          "take the kernel's exact-correction pass far more often (reported in profiles/ as the slow case)")
     ap.add_argument("--n-ms", type=int, default=None,
-                    help="blocks integrated non-coherently per search; default 1 at --gpus 1 (BASELINE.json configs[2]) and "
-                         "10 at --gpus N > 1 (configs[3]); hypotheses are counted per block, as SURVEY.md 8(d) config 4 does")
+                    help="blocks integrated non-coherently per search; default 1 at every --gpus N (BASELINE.json configs[2], the "
+                         "configuration the metric is quoted on; N > 1 runs report configs[3] -- ten blocks -- beside it as "
+                         "`configs3_sharded`); --n-ms 10 makes configs[3] the headline; hypotheses are counted per block")
     ap.add_argument("--if-format", choices=["2bit", "1bit"], default="2bit",
                     help="sample format of the captures in HBM: 2bit = MAX2769-style sign/magnitude pairs, 4092 bytes per ms, "
                          "unpacked to the sign plane in LDS inside the kernels (the reference's correlator never looks at "
@@ -810,7 +814,7 @@ def main():
                     help="N > 1: skip rank 0's check of the merged key table against the CPU oracle (outside the timed region)")
     args = ap.parse_args()
     if args.n_ms is None:
-        args.n_ms = 1 if args.gpus == 1 else 10
+        args.n_ms = 1          # the SAME workload at every N (per-GPU work fixed as N grows: weak scaling from N = 1 on)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)      # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run; does not return
 
@@ -1007,8 +1011,9 @@ def main():
     # BASELINE.json configs[3] as written: ONE ten-block cold-start search, its 84 (PRN group, Doppler) units dealt to the
     # N ranks, one all-reduce(MAX) of 672 keys; latency per search (outside the headline's timed region)
     single = None
-    if use_dist and n_ms > 1:
-        g_one = eng.grid_desc(prns, n_search=1, n_ms=n_ms, search_stride_blocks=n_ms, dopp_min_hz=DOPP_MIN,
+    one_ms = n_ms if n_ms > 1 else 10          # (the headline's own block count, or configs[3]'s ten when the headline is one block)
+    if use_dist and n_search * n_ms >= one_ms:
+        g_one = eng.grid_desc(prns, n_search=1, n_ms=one_ms, search_stride_blocks=one_ms, dopp_min_hz=DOPP_MIN,
                               dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046),
                               shard=(rank, world))
         with torch.cuda.stream(stream):
@@ -1019,7 +1024,7 @@ def main():
                     torch.cuda.synchronize()
                     dist.barrier()
                     ts = time.perf_counter()
-                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_one), d_if.data_ptr(), n_ms, d_peaks.data_ptr(),
+                rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g_one), d_if.data_ptr(), one_ms, d_peaks.data_ptr(),
                                                one_keys.data_ptr(), None, None, None)
                 assert rc == 0
                 dist.all_reduce(one_keys, op=dist.ReduceOp.MAX)
@@ -1028,9 +1033,54 @@ def main():
             dt1 = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
         dist.all_reduce(dt1, op=dist.ReduceOp.MAX)
         single = {"ms_per_search": float(dt1.item()) / reps1 * 1e3,
-                  "value": reps1 * n_ms * HYP_PER_SEARCH / float(dt1.item()), "unit": "hypotheses/s",
-                  "note": f"one {n_ms}-block search (32 PRN x 21 Doppler x 16368 phases) sharded over {world} ranks, "
+                  "value": reps1 * one_ms * HYP_PER_SEARCH / float(dt1.item()), "unit": "hypotheses/s",
+                  "note": f"one {one_ms}-block search (32 PRN x 21 Doppler x 16368 phases) sharded over {world} ranks, "
                           "its 84 units as N contiguous runs, all-reduce(MAX) of 672 keys, synchronised per search"}
+
+    # N > 1 with the one-block headline: BASELINE.json configs[3] -- ten-block searches, the grid sharded over the N ranks, one
+    # all-reduce(MAX) of the keys per step -- timed beside it with the headline's protocol (barrier + synchronize on both sides,
+    # slowest rank): `searches` ten-block searches PER GPU (search s integrates blocks s .. s + 9 of the resident captures,
+    # cyclically extended: the N = 1 line's `configs3_one_gpu` is this leg's N = 1 point)
+    ten_sharded = None
+    if use_dist and n_ms == 1 and n_search >= 10 and not args.no_native:
+        try:
+            per_block = dev_blocks.reshape(n_search, -1)
+            g10 = eng.grid_desc(prns, n_search=n_search, n_ms=10, search_stride_blocks=1, dopp_min_hz=DOPP_MIN,
+                                dopp_step_hz=DOPP_STEP, n_dopp=N_DOPP, phase_mode=capi.PHASES_FINE, win=(0, 2046), shard=(rank, world))
+            reps10 = max(2, min(args.steps, 5))
+            with torch.cuda.stream(stream):
+                d_if10 = torch.from_numpy(np.concatenate([per_block, per_block[:9]]).reshape(-1)).to(dev)
+                keys10 = torch.zeros((n_search, N_PRN, N_DOPP), dtype=torch.int64, device=dev)
+                for i in range(reps10 + 2):
+                    if i == 2:
+                        torch.cuda.synchronize()
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        t10 = time.perf_counter()
+                    rc = eng.lib.gpsx_acq_grid_dev(eng.h, C.byref(g10), d_if10.data_ptr(), n_search + 9, d_peaks.data_ptr(),
+                                                   keys10.data_ptr(), None, None, None)
+                    if rc != 0:
+                        raise RuntimeError(f"gpsx_acq_grid_dev -> {rc}: {eng.lib.gpsx_last_error(eng.h).decode()}")
+                    dist.all_reduce(keys10, op=dist.ReduceOp.MAX)
+                k10 = eng.lib.gpsx_last_kernel(eng.h).decode()
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                dt10 = torch.tensor([time.perf_counter() - t10], dtype=torch.float64, device=dev)
+            dist.all_reduce(dt10, op=dist.ReduceOp.MAX)
+            ten_ms = float(dt10.item()) / reps10 * 1e3
+            ten_sharded = {"workload": "BASELINE.json configs[3]: %d ten-block searches (%d per GPU), 32 PRN x 21 Doppler x 16368 phases, "
+                                       "units sharded over %d ranks, one all-reduce(MAX) of the keys per step" % (n_search, n_search // world, world),
+                           "value": n_search * 10 * HYP_PER_SEARCH / (ten_ms * 1e-3), "unit": "hypotheses/s (per 1 ms block)",
+                           "ms_per_step": ten_ms, "steps": reps10, "kernel": "gpsx::" + k10}
+            ten_sharded["roofline"], ten_sharded["roofline_mfma"] = _walk_roofline(
+                k10, n_search * 10 * HYP_PER_SEARCH / world, 10, ten_ms, _kernel_counters(k10, args.searches, 10))
+            assert int(keys10.min()) > 0, "the ten-block sharded sweep left empty keys"
+        except AssertionError:
+            raise
+        except Exception as exc:   # a secondary leg must not take the headline line with it -- but every rank must fail alike
+            ten_sharded = {"error": repr(exc)}
+            print(f"bench.py: sharded ten-block leg failed on rank {rank}: {exc!r}", file=sys.stderr, flush=True)
 
     # N > 1: this rank's own share of the work as ONE GPU would run it -- `searches` captures x n_ms blocks, unsharded, no
     # collective -- so that the sharded, all-reduced job can be compared with N x a single GPU at the SAME configuration
@@ -1173,6 +1223,8 @@ def main():
             line["parity"] = parity
         if single is not None:
             line["single_search"] = single
+        if ten_sharded is not None:
+            line["configs3_sharded"] = ten_sharded
         if local_ref is not None:
             line["per_gpu_unsharded"] = local_ref
         if native is not None:

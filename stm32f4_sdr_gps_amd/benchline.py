@@ -94,6 +94,7 @@ def compact(detail):
 
     leg("native_grid", ("value", "ms_per_launch", "kernel"), "roofline")
     leg("configs3_one_gpu", ("value", "ms_per_step", "kernel"), "roofline")
+    leg("configs3_sharded", ("value", "ms_per_step", "kernel"), "roofline")
     leg("letter_compliant", ("value", "ms_per_launch", "kernel", "keys_identical_to_the_matrix_core_path"), "roofline_valu")
     leg("weighted_2bit_extension", ("value", "ms_per_launch"), "roofline")
     trk = d.get("tracking")

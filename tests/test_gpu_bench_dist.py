@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n_ms, searches, port, ms_mode, algo", [(10, 1, 29571, "blocks", ""), (1, 4, 29572, "", ""),
                                                                 (10, 4, 29573, "walk", "poly"), (10, 5, 29574, "", "")])
 def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode, algo, tmp_path, oracle):
-    """n_ms = 10 is what the driver's N > 1 runs execute (BASELINE.json configs[3]; bench.py's default there), in both
+    """n_ms = 10 is BASELINE.json configs[3] (`--n-ms 10`; the default N > 1 run reports it as `configs3_sharded` beside the
+    one-block headline: test_default_multi_gpu_run_is_the_single_gpu_workload_sharded), in both
     forms: the polyphase kernel with a workgroup per (unit, block) (what a lone search takes), the polyphase kernel walking
     its blocks, and -- what the 256-searches-per-GPU runs take -- the matrix-core kernel walking them (default dispatch,
     5 searches per rank); n_ms = 1 is the coherent grid on the matrix cores.  GPSX_BENCH_VERIFY compares the merged key table with
@@ -33,7 +34,7 @@ def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode,
         env["GPSX_USE_LAB_LIBRARY"] = "1"       # forced kernel forms: the lab build of the library reads those knobs
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--searches", str(searches), "--no-cpu-baseline"] + (["--n-ms", "1"] if n_ms == 1 else [])
+           "--warmup", "1", "--searches", str(searches), "--no-cpu-baseline", "--n-ms", str(n_ms)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "VERIFY sharded == unsharded" in res.stdout
@@ -73,7 +74,7 @@ def test_plain_python_launch_two_ranks(scaling, port, tmp_path, oracle):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--searches", "6",
-           "--scaling", scaling, "--no-cpu-baseline"]
+           "--scaling", scaling, "--no-cpu-baseline", "--n-ms", "10"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     assert "VERIFY sharded == unsharded" in res.stdout
@@ -114,7 +115,7 @@ def test_eight_ranks_on_one_device(tmp_path, oracle):
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--searches", str(searches),
-               "--scaling", scaling, "--no-cpu-baseline"]
+               "--scaling", scaling, "--no-cpu-baseline", "--n-ms", "10"]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
         assert res.returncode == 0, res.stderr[-2000:]
         assert "VERIFY sharded == unsharded" in res.stdout
@@ -160,3 +161,56 @@ def test_single_gpu_line_is_compact_strict_and_carries_every_leg(tmp_path):
     detail = json.load(open(os.path.join(ROOT, "bench_detail.json")))
     assert detail["value"] == pytest.approx(line["value"], rel=1e-5) and "note" in detail["roofline"]
     assert detail["configs3_one_gpu"]["roofline"]["algorithmic_bytes"] > 0 and detail["pcie_inclusive"]["serial"] > 1e9
+
+
+def test_default_multi_gpu_run_is_the_single_gpu_workload_sharded(tmp_path, oracle):
+    """`bench.py --gpus 2` with no --n-ms, as the driver launches it: the SAME workload as N = 1 (BASELINE.json configs[2], one block
+    per search, `searches` captures PER GPU: per-GPU work fixed as N grows), its units sharded, one all-reduce(MAX) of the keys per
+    step; configs[3] (ten-block searches, sharded, all-reduced) rides beside it as `configs3_sharded` and north_star's literal
+    point (ONE ten-block search over the N ranks) as `single_search`.  The merged table = the unsharded sweep (GPSX_BENCH_VERIFY),
+    and one search of each rank's half against the oracle, every key."""
+    import numpy as np
+    from stm32f4_sdr_gps_amd import benchline, synth
+    dump = str(tmp_path / "merged_keys.npy")
+    env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1", GPSX_BENCH_DUMP_KEYS=dump)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--searches", "12", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "VERIFY sharded == unsharded" in res.stdout
+    line = benchline.check([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["blocks_per_search"] == 1
+    assert "configs[2]" in line["config"]["workload"]                       # the N = 1 line's workload, word for word
+    assert line["config"]["searches_per_gpu_per_step"] == 12 and line["config"]["hypotheses_per_step"] == 24 * 32 * 21 * 16368
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] <= 1
+    assert line["communicator"]["rccl_ranks"] == 2 and line["parity"]["parity_checked"] is True
+    assert line["per_gpu_unsharded"]["value"] > 1e9
+    ten = line["configs3_sharded"]
+    assert "error" not in ten and ten["value"] > 1e9 and ten["bound"] == "hbm" and ten["kernel"].startswith("gpsx::k_acq_")
+    assert line["single_search"]["ms_per_search"] > 0
+    keys = np.load(dump)
+    assert keys.shape == (24, 32, 21)
+    blocks = synth.cold_start_block(24, seed=11, amp_scale=0.25)
+    prns = np.arange(1, 33, dtype=np.uint8)
+    for s_ in (3, 20):                                                       # one search of each rank's run of units
+        want = oracle.acq_grid(blocks[s_:s_ + 1], 1, prns, -5000, 500, 21, 8, n_threads=max(4, min(32, len(os.sched_getaffinity(0)))), live=True)
+        fine = 8 * want["phase"].astype(np.int64) + np.arange(8)[None, None, :]
+        assert np.array_equal(keys[s_], ((want["max_val"].astype(np.int64) << 14) | (16383 - fine)).max(axis=2)), s_
+
+
+def test_eight_ranks_default_workload(tmp_path):
+    """The driver's 8-GPU launch shape with no --n-ms: eight ranks on device 0 over gloo, two captures per rank of the N = 1
+    workload, the ten-block leg sharded over the eight ranks beside it; merged table = unsharded sweep, oracle sample inside the run."""
+    from stm32f4_sdr_gps_amd import benchline
+    env = dict(os.environ, GPSX_BENCH_SHARE_DEVICE="1", GPSX_BENCH_BACKEND="gloo", GPSX_BENCH_VERIFY="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--searches", "2", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "VERIFY sharded == unsharded" in res.stdout
+    line = benchline.check([l for l in res.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == 8 and line["communicator"]["rccl_ranks"] == 8 and line["config"]["blocks_per_search"] == 1
+    assert line["config"]["hypotheses_per_step"] == 16 * 32 * 21 * 16368 and line["parity"]["parity_checked"] is True
+    assert "error" not in line["configs3_sharded"] and line["configs3_sharded"]["value"] > 1e9 and line["single_search"]["ms_per_search"] > 0
