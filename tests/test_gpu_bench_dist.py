@@ -12,6 +12,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _free_port(preferred):
+    """`preferred` if nobody listens there, else any free port (a leftover rendezvous of an earlier, killed run must not fail a test)"""
+    import socket
+    for port in (preferred, 0):
+        with socket.socket() as sock:
+            try:
+                sock.bind(("127.0.0.1", port))
+                return sock.getsockname()[1]
+            except OSError:
+                continue
+    return preferred
+
+
 @pytest.mark.parametrize("n_ms, searches, port, ms_mode, algo", [(10, 1, 29571, "blocks", ""), (1, 4, 29572, "", ""),
                                                                 (10, 4, 29573, "walk", "poly"), (10, 5, 29574, "", "")])
 def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode, algo, tmp_path, oracle):
@@ -33,7 +46,7 @@ def test_two_ranks_sharded_sweep_equals_unsharded(n_ms, searches, port, ms_mode,
     if ms_mode or algo:
         env["GPSX_USE_LAB_LIBRARY"] = "1"       # forced kernel forms: the lab build of the library reads those knobs
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "127.0.0.1", "--master-port", str(_free_port(port)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--searches", str(searches), "--no-cpu-baseline", "--n-ms", str(n_ms)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
